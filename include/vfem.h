@@ -1,0 +1,133 @@
+/*
+ * vfem.h -- C ABI of libvfem, the MI355X-native voxel-FEM hot path.
+ *
+ * This is the drop-in boundary for the one path of Nikronic/ndr this repository accelerates
+ * (SURVEY.md section 8): the matrix-free SIMP stiffness apply, the geometric-multigrid
+ * preconditioned CG compliance solve, the compliance sensitivity and the Fourier-feature
+ * MLP density field.  Each entry point names the reference interface it replaces
+ * (paths relative to the reference checkout; "TPS" = VoxelFEM/TensorProductSimulator.hh,
+ * "MG" = VoxelFEM/MultigridSolver.hh, "VoxelFEM.cc" = VoxelFEM/python_bindings/VoxelFEM.cc).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; vfem_last_error() then
+ *     holds the message (the reference throws std::runtime_error -> Python RuntimeError).
+ *   - all `double*` / `float*` / `uint8_t*` array arguments are DEVICE pointers (HBM) unless
+ *     the parameter name ends in `_host`.  vfem_malloc / vfem_copy_* are provided so a caller
+ *     without another HIP allocator (cgo, JNI, plain C) can stage data.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls enqueue work
+ *     and return; calls that return scalars to the host synchronise that stream.
+ *   - grids: row-major, last axis fastest (NDVector.hh:284-292); nodal fields are
+ *     [numNodes][3] doubles (TPS.hh:227); densities/gradients are [numElements] doubles.
+ *   - only degree-1 hexahedral elements in 3-D are on the device path in this release.
+ */
+#ifndef VFEM_H
+#define VFEM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vfem_sim vfem_sim;   /* TensorProductSimulator<1,1,1>              (TPS.hh:219) */
+typedef struct vfem_mg  vfem_mg;    /* MultigridSolver<1,1,1>                      (MG.hh:11)   */
+typedef struct vfem_mlp vfem_mlp;   /* networks.MLP (Fourier features + ReLU MLP)  (networks.py:128) */
+
+const char *vfem_last_error(void);
+int  vfem_device_count(void);                 /* number of visible HIP devices (0 => no GPU) */
+int  vfem_set_device(int device);
+int  vfem_version(void);
+
+/* ---- raw device memory helpers (for callers without their own HIP allocator) ---- */
+int vfem_malloc(void **ptr, size_t bytes);
+int vfem_free(void *ptr);
+int vfem_copy_h2d(void *dst, const void *src_host, size_t bytes, void *stream);
+int vfem_copy_d2h(void *dst_host, const void *src, size_t bytes, void *stream);
+int vfem_copy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+int vfem_memset(void *dst, int value, size_t bytes, void *stream);
+int vfem_stream_sync(void *stream);
+
+/* ---- simulator: TensorProductSimulator(domain, numElemsPerDim), TPS.hh:252-316 ---- */
+int vfem_sim_create(vfem_sim **out, const double bbox_min_host[3], const double bbox_max_host[3],
+                    const int64_t nelems_host[3]);
+int vfem_sim_destroy(vfem_sim *sim);
+int64_t vfem_sim_num_nodes(const vfem_sim *sim);      /* TPS::numNodes,    TPS.hh:1134 */
+int64_t vfem_sim_num_elements(const vfem_sim *sim);   /* TPS::numElements, TPS.hh:1137 */
+
+/* ElasticityTensor::setIsotropic via readMaterial/setETensor (TPS.hh:326-339; ElasticityTensor.hh:100-115) */
+int vfem_sim_set_isotropic(vfem_sim *sim, double young, double poisson);
+/* E_0 / E_min / gamma properties (VoxelFEM.cc:77-79; TPS.hh:1170-1175) */
+int vfem_sim_set_simp(vfem_sim *sim, double E0, double Emin, double gamma);
+/* fullDensityElementStiffnessMatrix (TPS.hh:755): 24x24 doubles, row-major, to HOST */
+int vfem_sim_k0(const vfem_sim *sim, double *K0_host);
+
+/* dirichletMask / dirichletValues properties (TPS.hh:413-442): mask[numNodes] bit c = component c fixed;
+ * values[numNodes][3].  Loads: the nodal force field of buildLoadVector (TPS.hh:893-901). */
+int vfem_sim_set_dirichlet(vfem_sim *sim, const uint8_t *mask_host, const double *values_host);
+int vfem_sim_set_loads(vfem_sim *sim, const double *f, void *stream);   /* f: device [numNodes][3] */
+int vfem_sim_build_load_vector(const vfem_sim *sim, double *f, void *stream);
+
+/* setElementDensities / setUniformDensities / getDensities (TPS.hh:456-461, 567-570, 1157-1161).
+ * Precomputes the SIMP moduli E_e = Emin + rho^gamma (E0-Emin) once (TPS.hh:725-727). */
+int vfem_sim_set_densities(vfem_sim *sim, const double *rho, void *stream);
+int vfem_sim_set_uniform_density(vfem_sim *sim, double rho, void *stream);
+int vfem_sim_get_densities(const vfem_sim *sim, double *rho, void *stream);
+
+/* applyK (TPS.hh:905-952): out = K(rho) u, Dirichlet conditions ignored.
+ * variant 0 = production kernel, 1 = plain gather kernel (cross-check). */
+int vfem_sim_apply_k(const vfem_sim *sim, const double *u, double *out, int variant, void *stream);
+/* complianceGradient (TPS.hh:730-751): g_e = -1/2 gamma rho^(gamma-1) (E0-Emin) u_e^T K0 u_e */
+int vfem_sim_compliance_gradient(const vfem_sim *sim, const double *u, double *g, void *stream);
+/* ComplianceObjective::compliance (TopologyOptimizationObjective.hh:39-41): 1/2 sum f.u, to host */
+int vfem_compliance(const vfem_sim *sim, const double *f, const double *u, double *value_host, void *stream);
+
+/* ---- multigrid: tps.multigridSolver(numCoarseningLevels), MG.hh:22-90 ---- */
+int vfem_mg_create(vfem_mg **out, vfem_sim *fine, int num_coarsening_levels);
+int vfem_mg_destroy(vfem_mg *mg);
+int vfem_mg_num_levels(const vfem_mg *mg);                       /* = numCoarseningLevels + 1 */
+int vfem_mg_level_dims(const vfem_mg *mg, int level, int64_t nelems_host[3]);
+int64_t vfem_mg_level_num_nodes(const vfem_mg *mg, int level);
+int vfem_mg_level_dirichlet_mask(const vfem_mg *mg, int level, uint8_t *mask_host);  /* coarsened masks, MG.hh:57-84 */
+int vfem_mg_set_symmetric_gauss_seidel(vfem_mg *mg, int symmetric);                  /* MG.hh:92-94 */
+/* debug_get_x / debug_get_b (MG.hh:734-735) and the PCG residual handed to it_callback (MG.hh:726-729):
+ * device pointer of an internal field; which = 0: m_x[level], 1: m_b[level], 2: PCG residual r (level ignored). */
+const double *vfem_mg_field_ptr(const vfem_mg *mg, int which, int level);
+
+/* updateElementStiffnessMatrices + updateBlockKs (MG.hh:415-441): rebuild the coarse operators
+ * (Galerkin, MG.hh:604-669) and the coarsest-level factorisation from the current densities. */
+int vfem_mg_update_operators(vfem_mg *mg, void *stream);
+/* MG::applyK(l,u) (MG.hh:353-358), computeResidual (MG.hh:401-413), smoothingMulticoloredGS
+ * (MG.hh:336-340; forward != 0 => forward colour/component order), zeroOutDirichletComponents
+ * (MG.hh:364-378), restriction (MG.hh:146-161), interpolation / accum_interpolation (MG.hh:116-141),
+ * coarsest TPS::solve (TPS.hh:834-865). `level` fields have vfem_mg_level_num_nodes(level) x 3 doubles. */
+int vfem_mg_apply_k(vfem_mg *mg, int level, const double *u, double *out, void *stream);
+int vfem_mg_residual(vfem_mg *mg, int level, const double *u, const double *b, double *r, void *stream);
+int vfem_mg_smooth(vfem_mg *mg, int level, double *u, const double *b, int forward, void *stream);
+int vfem_mg_zero_dirichlet(vfem_mg *mg, int level, double *u, void *stream);
+int vfem_mg_restrict(vfem_mg *mg, int fine_level, const double *fine, double *coarse, void *stream);
+int vfem_mg_interpolate(vfem_mg *mg, int fine_level, const double *coarse, double *fine, int accumulate, void *stream);
+int vfem_mg_coarsest_solve(vfem_mg *mg, const double *b, double *x, void *stream);
+
+/* MG::solve (MG.hh:447-472): numSteps V-cycles (first one a full-multigrid cycle if fmg) on K x = f
+ * starting from x (in/out). */
+int vfem_mg_solve(vfem_mg *mg, double *x, const double *f, int num_steps, int num_smoothing_steps,
+                  int stiffness_updated, int zero_dirichlet, int fmg, void *stream);
+
+/* preconditionedConjugateGradient (MG.hh:679-732).  x is in/out (initial guess u -> solution).
+ * residual_cb, if non-NULL, is called after every iteration with (it, ||r||) on the calling thread
+ * (MultigridComplianceObjective::residual_cb, TopologyOptimizationObjective.hh:87-89, 101). */
+typedef void (*vfem_residual_cb)(void *user, int iteration, double residual_norm);
+int vfem_mg_pcg(vfem_mg *mg, double *x, const double *b, int max_iter, double tol,
+                int mg_iterations, int mg_smoothing_iterations, int fmg,
+                vfem_residual_cb residual_cb, void *cb_user,
+                int *iterations_out_host, double *relres_out_host, void *stream);
+
+/* ---- timers: BENCHMARK_* registry (MeshFEM GlobalBenchmark.hh / Timer.hh; VoxelFEM.cc:245-255) ---- */
+int vfem_timers_reset(void);
+int vfem_timers_report(char *buf_host, size_t buf_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFEM_H */

@@ -1,0 +1,104 @@
+"""ctypes binding of libvfem.so (the C ABI declared in include/vfem.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no GPU is visible,
+every compute entry point raises.  ``load()`` itself only needs the shared object (so the
+symbol/export checks run on a CPU-only box).
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvfem.so")
+_lib = None
+
+RESIDUAL_CB = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_double)
+
+# name -> (restype, argtypes); kept in one table so tests can check it against include/vfem.h
+SIGNATURES = {
+    "vfem_last_error": (c_char_p, []),
+    "vfem_device_count": (c_int, []),
+    "vfem_set_device": (c_int, [c_int]),
+    "vfem_version": (c_int, []),
+    "vfem_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "vfem_free": (c_int, [c_void_p]),
+    "vfem_copy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vfem_copy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vfem_copy_d2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vfem_memset": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
+    "vfem_stream_sync": (c_int, [c_void_p]),
+    "vfem_sim_create": (c_int, [POINTER(c_void_p), POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
+    "vfem_sim_destroy": (c_int, [c_void_p]),
+    "vfem_sim_num_nodes": (c_int64, [c_void_p]),
+    "vfem_sim_num_elements": (c_int64, [c_void_p]),
+    "vfem_sim_set_isotropic": (c_int, [c_void_p, c_double, c_double]),
+    "vfem_sim_set_simp": (c_int, [c_void_p, c_double, c_double, c_double]),
+    "vfem_sim_k0": (c_int, [c_void_p, c_void_p]),
+    "vfem_sim_set_dirichlet": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "vfem_sim_set_loads": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "vfem_sim_build_load_vector": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "vfem_sim_set_densities": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "vfem_sim_set_uniform_density": (c_int, [c_void_p, c_double, c_void_p]),
+    "vfem_sim_get_densities": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "vfem_sim_apply_k": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "vfem_sim_compliance_gradient": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vfem_compliance": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double), c_void_p]),
+    "vfem_mg_create": (c_int, [POINTER(c_void_p), c_void_p, c_int]),
+    "vfem_mg_destroy": (c_int, [c_void_p]),
+    "vfem_mg_num_levels": (c_int, [c_void_p]),
+    "vfem_mg_level_dims": (c_int, [c_void_p, c_int, POINTER(c_int64)]),
+    "vfem_mg_level_num_nodes": (c_int64, [c_void_p, c_int]),
+    "vfem_mg_level_dirichlet_mask": (c_int, [c_void_p, c_int, c_void_p]),
+    "vfem_mg_set_symmetric_gauss_seidel": (c_int, [c_void_p, c_int]),
+    "vfem_mg_field_ptr": (c_void_p, [c_void_p, c_int, c_int]),
+    "vfem_mg_update_operators": (c_int, [c_void_p, c_void_p]),
+    "vfem_mg_apply_k": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "vfem_mg_residual": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vfem_mg_smooth": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "vfem_mg_zero_dirichlet": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "vfem_mg_restrict": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "vfem_mg_interpolate": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "vfem_mg_coarsest_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vfem_mg_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vfem_mg_pcg": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_int, c_int,
+                            RESIDUAL_CB, c_void_p, POINTER(c_int), POINTER(c_double), c_void_p]),
+    "vfem_timers_reset": (c_int, []),
+    "vfem_timers_report": (c_int, [c_char_p, c_size_t]),
+}
+
+
+def load():
+    """Load libvfem.so; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libvfem.so is missing (%s): build it with `make -C ndr_amd/csrc` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        raise RuntimeError(load().vfem_last_error().decode("utf-8", "replace"))
+
+
+_gpu_checked = False
+
+
+def require_gpu():
+    """Fail loudly when the HIP path cannot run (no silent CPU fallback)."""
+    global _gpu_checked
+    if _gpu_checked:
+        return
+    lib = load()
+    if lib.vfem_device_count() < 1:
+        raise RuntimeError("ndr_amd: no HIP device visible; the voxel-FEM path runs only on the GPU")
+    _gpu_checked = True

@@ -1,0 +1,674 @@
+// Host side of libvfem: handle types, reference-element setup, multigrid hierarchy, V-cycle / FMG /
+// PCG drivers and the extern "C" boundary declared in include/vfem.h.
+//
+// Control flow follows the reference (paths relative to the reference checkout):
+//   MultigridSolver ctor (hierarchy, Dirichlet coarsening)   VoxelFEM/MultigridSolver.hh:22-90
+//   vcycle / fullMultigrid / solve / applyPreconditionerInv   VoxelFEM/MultigridSolver.hh:447-553
+//   preconditionedConjugateGradient                           VoxelFEM/MultigridSolver.hh:679-732
+#include "vfem_internal.h"
+
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+
+namespace vfem {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+// ------------------------------------------------------------------------------------------
+// timer registry (BENCHMARK_* of MeshFEM GlobalBenchmark.hh / Timer.hh): host wall time + call count
+// per named section; sections enclosing only asynchronous launches measure enqueue time unless the
+// caller synchronises (the PCG loop does, once per iteration).
+// ------------------------------------------------------------------------------------------
+struct TimerEntry { double seconds = 0.0; long long calls = 0; };
+static std::map<std::string, TimerEntry> g_timers;
+static std::mutex g_timer_mu;
+struct ScopedTimer {
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    explicit ScopedTimer(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
+    ~ScopedTimer() {
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> lk(g_timer_mu);
+        auto &e = g_timers[name];
+        e.seconds += dt; e.calls += 1;
+    }
+};
+
+}  // namespace vfem
+
+using namespace vfem;
+
+#define VFEM_TRY try {
+#define VFEM_CATCH                                                                              \
+    } catch (const std::exception &e) { vfem::set_error(e.what()); return 1; }                  \
+      catch (...) { vfem::set_error("unknown error"); return 1; }                               \
+    return 0;
+
+static inline hipStream_t S(void *s) { return (hipStream_t) s; }
+
+// ------------------------------------------------------------------------------------------
+// reference element: closed-form Q1 stiffness for an axis-aligned box voxel with isotropic C.
+// Same quantity as Element_T::Stiffness (TPS.hh:127-140), which integrates it by 2-point Gauss
+// quadrature (exact for these integrands); derived here from the 1-D integrals
+//   Mm[a][b] = int N_a N_b,  Dd[a][b] = int N_a' N_b',  Gg[a][b] = int N_a' N_b   on [0,1].
+// ------------------------------------------------------------------------------------------
+void vfem_sim::update_k0() {
+    static const double Mm[2][2] = {{1.0 / 3, 1.0 / 6}, {1.0 / 6, 1.0 / 3}};
+    static const double Dd[2][2] = {{1.0, -1.0}, {-1.0, 1.0}};
+    static const double Gg[2][2] = {{-0.5, -0.5}, {0.5, 0.5}};
+    const double vol = h[0] * h[1] * h[2];
+    auto I = [&](int n, int m, int p, int q) {   // int d_p N_n d_q N_m over the reference cube, physical gradients
+        double v = 1.0 / (h[p] * h[q]);
+        for (int dd = 0; dd < 3; ++dd) {
+            const int a = (n >> (2 - dd)) & 1, b = (m >> (2 - dd)) & 1;
+            if (dd == p && dd == q) v *= Dd[a][b];
+            else if (dd == p)       v *= Gg[a][b];
+            else if (dd == q)       v *= Gg[b][a];
+            else                    v *= Mm[a][b];
+        }
+        return v;
+    };
+    for (int n = 0; n < 8; ++n)
+        for (int a = 0; a < 3; ++a)
+            for (int m = 0; m < 8; ++m)
+                for (int b = 0; b < 3; ++b) {
+                    double v = lambda * I(n, m, a, b) + mu * I(n, m, b, a);
+                    if (a == b) v += mu * (I(n, m, 0, 0) + I(n, m, 1, 1) + I(n, m, 2, 2));
+                    K0[(3 * n + a) * 24 + 3 * m + b] = vol * v;
+                }
+    // mode-space form: Dmode = T K0 T^T / 64 with T = H (x) H (x) H, H = [[1,1],[-1,1]] per axis.
+    // For a box voxel with an orthotropic/isotropic tensor only 45 entries survive:
+    // 21 diagonal ones (the three rigid translations are null) and 12 symmetric couplings.
+    double T[8][8];
+    for (int p = 0; p < 8; ++p)
+        for (int n = 0; n < 8; ++n) {
+            double v = 1.0;
+            for (int dd = 0; dd < 3; ++dd) {
+                const int pb = (p >> (2 - dd)) & 1, nb = (n >> (2 - dd)) & 1;
+                if (pb && !nb) v = -v;
+            }
+            T[p][n] = v;
+        }
+    std::vector<double> TK(576), Dfull(576);
+    for (int p = 0; p < 8; ++p)
+        for (int a = 0; a < 3; ++a)
+            for (int col = 0; col < 24; ++col) {
+                double v = 0.0;
+                for (int n = 0; n < 8; ++n) v += T[p][n] * K0[(3 * n + a) * 24 + col];
+                TK[(3 * p + a) * 24 + col] = v;
+            }
+    double maxabs = 0.0;
+    for (int row = 0; row < 24; ++row)
+        for (int q = 0; q < 8; ++q)
+            for (int b = 0; b < 3; ++b) {
+                double v = 0.0;
+                for (int m = 0; m < 8; ++m) v += TK[row * 24 + 3 * m + b] * T[q][m];
+                Dfull[row * 24 + 3 * q + b] = v / 64.0;
+                maxabs = std::max(maxabs, std::fabs(v / 64.0));
+            }
+    // pack: Dm[0..23] diagonal (3p+a); Dm[24..35] couplings (order fixed in kernels_apply.hip)
+    for (int q = 0; q < 64; ++q) Dm[q] = 0.0;
+    std::vector<char> used(576, 0);
+    for (int r = 0; r < 24; ++r) { Dm[r] = Dfull[r * 24 + r]; used[r * 24 + r] = 1; }
+    // coupling list: for each component pair (a<b), third axis t, parity pt of the third axis:
+    //   lambda-type: u_a mode (bit a [+ pt*bit t]) <-> u_b mode (bit b [+ pt*bit t])
+    //   mu-type:     u_a mode (bit b [+ pt*bit t]) <-> u_b mode (bit a [+ pt*bit t])
+    int idx = 24;
+    auto bit = [](int axis) { return 1 << (2 - axis); };
+    for (int a = 0; a < 3; ++a)
+        for (int b = a + 1; b < 3; ++b) {
+            const int t = 3 - a - b;
+            for (int pt = 0; pt < 2; ++pt)
+                for (int type = 0; type < 2; ++type) {
+                    const int pa = (type == 0 ? bit(a) : bit(b)) | (pt ? bit(t) : 0);
+                    const int pb = (type == 0 ? bit(b) : bit(a)) | (pt ? bit(t) : 0);
+                    const int r = 3 * pa + a, c = 3 * pb + b;
+                    Dm[idx++] = Dfull[r * 24 + c];
+                    used[r * 24 + c] = 1; used[c * 24 + r] = 1;
+                }
+        }
+    fast_ok = true;
+    for (int q = 0; q < 576; ++q)
+        if (!used[q] && std::fabs(Dfull[q]) > 1e-13 * maxabs) fast_ok = false;
+    dK0.alloc(576);
+    VFEM_HIP(hipMemcpy(dK0.p, K0, sizeof(K0), hipMemcpyHostToDevice));
+}
+
+// ------------------------------------------------------------------------------------------
+// multigrid internals
+// ------------------------------------------------------------------------------------------
+static void coarsen_dirichlet(const Dims &f, const std::vector<uint8_t> &fm, const Dims &c, std::vector<uint8_t> &cm) {
+    // MG.hh:57-84: a fine Dirichlet node lying on a coarse element vertex/edge/face constrains all coarse
+    // nodes of that entity; a fine Dirichlet node strictly inside a coarse element is an error.
+    cm.assign((size_t) c.nn, 0);
+    for (int i = 0; i < f.NX; ++i)
+        for (int j = 0; j < f.NY; ++j)
+            for (int k = 0; k < f.NZ; ++k) {
+                const uint8_t m = fm[((size_t) i * f.NY + j) * f.NZ + k];
+                if (!m) continue;
+                const int g[3] = {i, j, k}, nce[3] = {c.nx, c.ny, c.nz};
+                int e[3], lo[3], hi[3];
+                bool any = false;
+                for (int dd = 0; dd < 3; ++dd) {
+                    e[dd] = std::min(g[dd] / 2, nce[dd] - 1);
+                    const int loc = g[dd] - 2 * e[dd];
+                    if (loc == 0)      { lo[dd] = hi[dd] = e[dd]; any = true; }
+                    else if (loc == 2) { lo[dd] = hi[dd] = e[dd] + 1; any = true; }
+                    else               { lo[dd] = e[dd]; hi[dd] = e[dd] + 1; }
+                }
+                if (!any) throw Error("Dirichlet constraints on internal nodes are not supported");
+                for (int a = lo[0]; a <= hi[0]; ++a)
+                    for (int b = lo[1]; b <= hi[1]; ++b)
+                        for (int cc = lo[2]; cc <= hi[2]; ++cc) cm[((size_t) a * c.NY + b) * c.NZ + cc] |= m;
+            }
+}
+
+static const double *level_K(const vfem_mg *mg, int l) {
+    return l == 0 ? mg->fine->dK0.p : mg->cK0.p;
+}
+
+static void mg_apply(vfem_mg *mg, int l, const double *u, const double *b, int res, double *out, hipStream_t s) {
+    MgLevel &L = mg->lv[l];
+    if (L.kind == OP_STENCIL) launch_apply_stencil(L.d, L.S.p, u, b, L.maskp, res, out, s);
+    else if (L.kind == OP_MF0 && mg->fine->fast_ok)
+        launch_apply_fast(L.d, mg->fine->Dm, mg->fine->E.p, u, b, L.maskp, res, out, s);
+    else launch_apply_gather(L.d, L.kind, level_K(mg, l), mg->fine->E.p, u, b, L.maskp, res, out, s);
+}
+
+static void mg_smooth(vfem_mg *mg, int l, double *u, const double *b, int forward, hipStream_t s) {
+    MgLevel &L = mg->lv[l];
+    if (L.kind == OP_STENCIL) launch_gs_sweep_stencil(L.d, L.S.p, u, b, L.maskp, forward, s);
+    else launch_gs_sweep_mf(L.d, L.kind, level_K(mg, l), mg->fine->E.p, u, b, L.maskp, forward, s);
+}
+
+static void coarsest_solve(vfem_mg *mg, const double *b, double *x, hipStream_t s) {
+    const long long n = 3 * mg->lv[mg->L].d.nn;
+    launch_gemv_sym(n, mg->Ainv.p, b, x, s);
+}
+
+static void update_operators(vfem_mg *mg, hipStream_t s) {
+    ScopedTimer tm("updateElementStiffnessMatrices");
+    vfem_sim *sim = mg->fine;
+    const int L = mg->L;
+    // Galerkin element matrices for levels >= 2 (level 1 stays virtual: sum_f E_f cK0[f])
+    for (int l = 2; l <= L; ++l) {
+        MgLevel &lv = mg->lv[l];
+        lv.Ke.alloc((size_t) lv.d.ne * 576);
+        if (l == 2) launch_coarsen_ke(lv.d, 1, mg->cK0.p, sim->E.p, nullptr, lv.Ke.p, s);
+        else        launch_coarsen_ke(lv.d, 2, nullptr, nullptr, mg->lv[l - 1].Ke.p, lv.Ke.p, s);
+    }
+    for (int l = 2; l <= L; ++l) {
+        MgLevel &lv = mg->lv[l];
+        lv.S.alloc((size_t) lv.d.nn * 27 * 9);
+        launch_stencil_from_ke(lv.d, lv.Ke.p, lv.S.p, s);
+    }
+    // coarsest level: dense inverse
+    MgLevel &cl = mg->lv[L];
+    const long long n = 3 * cl.d.nn;
+    if (n > 40000) throw Error("coarsest grid too large for the dense coarsest-level solve (" + std::to_string(n) +
+                               " dofs); use more coarsening levels");
+    const double *Sc = cl.S.p;
+    DevBuf<double> tmpS;
+    if (L < 2) {
+        tmpS.alloc((size_t) cl.d.nn * 27 * 9);
+        launch_stencil_from_mf(cl.d, L == 0 ? OP_MF0 : OP_MF1, level_K(mg, L), sim->E.p, tmpS.p, s);
+        Sc = tmpS.p;
+    }
+    mg->Ainv.alloc((size_t) n * n);
+    mg->Ainv.zero(s);
+    launch_dense_from_stencil(cl.d, Sc, cl.maskp, mg->Ainv.p, s);
+    if (!mg->rocblas) {
+        rocblas_handle hnd;
+        if (rocblas_create_handle(&hnd) != rocblas_status_success) throw Error("rocblas_create_handle failed");
+        mg->rocblas = hnd;
+        mg->info.alloc(1);
+    }
+    rocblas_handle hnd = (rocblas_handle) mg->rocblas;
+    rocblas_set_stream(hnd, s);
+    if (rocsolver_dpotrf(hnd, rocblas_fill_lower, (rocblas_int) n, mg->Ainv.p, (rocblas_int) n, mg->info.p) != rocblas_status_success)
+        throw Error("rocsolver_dpotrf failed");
+    int info = 0;
+    VFEM_HIP(hipMemcpyAsync(&info, mg->info.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    VFEM_HIP(hipStreamSynchronize(s));
+    if (info != 0) throw Error("coarsest-level stiffness matrix is not positive definite (potrf info = " + std::to_string(info) + ")");
+    if (rocsolver_dpotri(hnd, rocblas_fill_lower, (rocblas_int) n, mg->Ainv.p, (rocblas_int) n, mg->info.p) != rocblas_status_success)
+        throw Error("rocsolver_dpotri failed");
+    launch_dense_finish_inverse(n, cl.maskp, mg->Ainv.p, s);
+    VFEM_HIP(hipStreamSynchronize(s));   // tmpS lifetime
+    mg->operators_valid = true;
+}
+
+// vcycle, MG.hh:516-553
+static void vcycle(vfem_mg *mg, int l, int nsmooth, bool residual_system, hipStream_t s) {
+    MgLevel &L = mg->lv[l];
+    if (l == mg->L) { coarsest_solve(mg, L.b.p, L.x.p, s); return; }
+    MgLevel &C = mg->lv[l + 1];
+    launch_enforce_dirichlet(L.d.nn, L.maskp, l == 0 ? mg->fine->dvals.p : nullptr, L.x.p, residual_system ? 1 : 0, s);
+    for (int i = 0; i < nsmooth; ++i) mg_smooth(mg, l, L.x.p, L.b.p, 1, s);
+    mg_apply(mg, l, L.x.p, L.b.p, 1, L.r.p, s);                       // computeResidual (Dirichlet zeroed)
+    launch_restrict(C.d, L.r.p, C.b.p, s);
+    C.x.zero(s);
+    vcycle(mg, l + 1, nsmooth, true, s);
+    launch_prolong(C.d, C.x.p, L.x.p, 1, s);
+    for (int i = 0; i < nsmooth; ++i) mg_smooth(mg, l, L.x.p, L.b.p, mg->symmetric_gs ? 0 : 1, s);
+}
+
+// fullMultigrid, MG.hh:486-508
+static void full_multigrid(vfem_mg *mg, int l, int nsmooth, bool residual_system, hipStream_t s) {
+    MgLevel &L = mg->lv[l];
+    if (l == mg->L) { coarsest_solve(mg, L.b.p, L.x.p, s); return; }
+    MgLevel &C = mg->lv[l + 1];
+    launch_restrict(C.d, L.b.p, C.b.p, s);
+    full_multigrid(mg, l + 1, nsmooth, residual_system, s);
+    launch_prolong(C.d, C.x.p, L.x.p, 0, s);
+    vcycle(mg, l, nsmooth, residual_system, s);
+}
+
+// MG::solve on the level-0 work vectors (x[0], b[0] already set), MG.hh:457-471
+static void mg_cycles(vfem_mg *mg, int num_steps, int nsmooth, bool zero_dirichlet, bool fmg, hipStream_t s) {
+    if (fmg) {
+        full_multigrid(mg, 0, nsmooth, zero_dirichlet, s);
+        for (int i = 1; i < num_steps; ++i) vcycle(mg, 0, nsmooth, zero_dirichlet, s);
+    } else {
+        for (int i = 0; i < num_steps; ++i) vcycle(mg, 0, nsmooth, zero_dirichlet, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *vfem_last_error(void) { return vfem::g_err.c_str(); }
+int vfem_version(void) { return 100; }
+
+int vfem_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int vfem_set_device(int device) { VFEM_TRY VFEM_HIP(hipSetDevice(device)); VFEM_CATCH }
+
+int vfem_malloc(void **ptr, size_t bytes) { VFEM_TRY VFEM_HIP(hipMalloc(ptr, bytes)); VFEM_CATCH }
+int vfem_free(void *ptr) { VFEM_TRY VFEM_HIP(hipFree(ptr)); VFEM_CATCH }
+int vfem_copy_h2d(void *dst, const void *src, size_t bytes, void *stream) {
+    VFEM_TRY
+    VFEM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(stream)));
+    VFEM_HIP(hipStreamSynchronize(S(stream)));
+    VFEM_CATCH
+}
+int vfem_copy_d2h(void *dst, const void *src, size_t bytes, void *stream) {
+    VFEM_TRY
+    VFEM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(stream)));
+    VFEM_HIP(hipStreamSynchronize(S(stream)));
+    VFEM_CATCH
+}
+int vfem_copy_d2d(void *dst, const void *src, size_t bytes, void *stream) {
+    VFEM_TRY VFEM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(stream))); VFEM_CATCH
+}
+int vfem_memset(void *dst, int value, size_t bytes, void *stream) {
+    VFEM_TRY VFEM_HIP(hipMemsetAsync(dst, value, bytes, S(stream))); VFEM_CATCH
+}
+int vfem_stream_sync(void *stream) { VFEM_TRY VFEM_HIP(hipStreamSynchronize(S(stream))); VFEM_CATCH }
+
+// ---- simulator ----
+int vfem_sim_create(vfem_sim **out, const double bbmin[3], const double bbmax[3], const int64_t ne[3]) {
+    VFEM_TRY
+    for (int dd = 0; dd < 3; ++dd)
+        if (ne[dd] < 1 || ne[dd] > 4096) throw Error("elements per dimension must be in [1, 4096]");
+    std::unique_ptr<vfem_sim> sim(new vfem_sim);
+    sim->d = Dims(ne[0], ne[1], ne[2]);
+    for (int dd = 0; dd < 3; ++dd) {
+        sim->bbmin[dd] = bbmin[dd]; sim->bbmax[dd] = bbmax[dd];
+        sim->h[dd] = (bbmax[dd] - bbmin[dd]) / (double) ne[dd];          // TPS.hh:287
+        if (!(sim->h[dd] > 0)) throw Error("empty domain bounding box");
+    }
+    sim->update_k0();
+    sim->rho.alloc((size_t) sim->d.ne);   sim->rho.zero(nullptr);
+    sim->E.alloc((size_t) sim->d.ne);
+    launch_simp(sim->d.ne, sim->rho.p, sim->E0, sim->Emin, sim->gamma, sim->E.p, nullptr);
+    sim->dmask.alloc((size_t) sim->d.nn); sim->dmask.zero(nullptr);
+    sim->dvals.alloc((size_t) sim->d.nn * 3); sim->dvals.zero(nullptr);
+    sim->loads.alloc((size_t) sim->d.nn * 3); sim->loads.zero(nullptr);
+    sim->hmask.assign((size_t) sim->d.nn, 0);
+    sim->hvals.assign((size_t) sim->d.nn * 3, 0.0);
+    VFEM_HIP(hipDeviceSynchronize());
+    *out = sim.release();
+    VFEM_CATCH
+}
+int vfem_sim_destroy(vfem_sim *sim) { VFEM_TRY delete sim; VFEM_CATCH }
+int64_t vfem_sim_num_nodes(const vfem_sim *sim) { return sim->d.nn; }
+int64_t vfem_sim_num_elements(const vfem_sim *sim) { return sim->d.ne; }
+
+int vfem_sim_set_isotropic(vfem_sim *sim, double young, double poisson) {
+    VFEM_TRY
+    sim->lambda = poisson * young / ((1.0 + poisson) * (1.0 - 2.0 * poisson));   // ElasticityTensor.hh:105-106
+    sim->mu = young / (2.0 + 2.0 * poisson);
+    sim->update_k0();
+    VFEM_CATCH
+}
+int vfem_sim_set_simp(vfem_sim *sim, double E0, double Emin, double gamma) {
+    VFEM_TRY
+    sim->E0 = E0; sim->Emin = Emin; sim->gamma = gamma;
+    launch_simp(sim->d.ne, sim->rho.p, E0, Emin, gamma, sim->E.p, nullptr);
+    VFEM_HIP(hipDeviceSynchronize());
+    VFEM_CATCH
+}
+int vfem_sim_k0(const vfem_sim *sim, double *K0_host) {
+    VFEM_TRY std::memcpy(K0_host, sim->K0, sizeof(sim->K0)); VFEM_CATCH
+}
+int vfem_sim_set_dirichlet(vfem_sim *sim, const uint8_t *mask_host, const double *values_host) {
+    VFEM_TRY
+    sim->hmask.assign(mask_host, mask_host + sim->d.nn);
+    sim->nonzero_dirichlet = false;
+    if (values_host) {
+        sim->hvals.assign(values_host, values_host + 3 * sim->d.nn);
+        for (long long n = 0; n < sim->d.nn; ++n)
+            for (int c = 0; c < 3; ++c)
+                if (((sim->hmask[n] >> c) & 1) && sim->hvals[3 * n + c] != 0.0) sim->nonzero_dirichlet = true;
+    } else sim->hvals.assign((size_t) sim->d.nn * 3, 0.0);
+    VFEM_HIP(hipMemcpy(sim->dmask.p, sim->hmask.data(), (size_t) sim->d.nn, hipMemcpyHostToDevice));
+    VFEM_HIP(hipMemcpy(sim->dvals.p, sim->hvals.data(), (size_t) sim->d.nn * 3 * sizeof(double), hipMemcpyHostToDevice));
+    VFEM_CATCH
+}
+int vfem_sim_set_loads(vfem_sim *sim, const double *f, void *stream) {
+    VFEM_TRY
+    VFEM_HIP(hipMemcpyAsync(sim->loads.p, f, (size_t) sim->d.nn * 3 * sizeof(double), hipMemcpyDeviceToDevice, S(stream)));
+    VFEM_CATCH
+}
+int vfem_sim_build_load_vector(const vfem_sim *sim, double *f, void *stream) {
+    VFEM_TRY
+    VFEM_HIP(hipMemcpyAsync(f, sim->loads.p, (size_t) sim->d.nn * 3 * sizeof(double), hipMemcpyDeviceToDevice, S(stream)));
+    VFEM_CATCH
+}
+int vfem_sim_set_densities(vfem_sim *sim, const double *rho, void *stream) {
+    VFEM_TRY
+    VFEM_HIP(hipMemcpyAsync(sim->rho.p, rho, (size_t) sim->d.ne * sizeof(double), hipMemcpyDeviceToDevice, S(stream)));
+    launch_simp(sim->d.ne, sim->rho.p, sim->E0, sim->Emin, sim->gamma, sim->E.p, S(stream));
+    VFEM_CATCH
+}
+int vfem_sim_set_uniform_density(vfem_sim *sim, double rho, void *stream) {
+    VFEM_TRY
+    if (rho > 1.0 || rho < 0.0)
+        throw Error("Density value (" + std::to_string(rho) + ") has to be in between 0 and 1");   // TPS.hh:457-458
+    launch_fill(sim->d.ne, rho, sim->rho.p, S(stream));
+    launch_simp(sim->d.ne, sim->rho.p, sim->E0, sim->Emin, sim->gamma, sim->E.p, S(stream));
+    VFEM_CATCH
+}
+int vfem_sim_get_densities(const vfem_sim *sim, double *rho, void *stream) {
+    VFEM_TRY
+    VFEM_HIP(hipMemcpyAsync(rho, sim->rho.p, (size_t) sim->d.ne * sizeof(double), hipMemcpyDeviceToDevice, S(stream)));
+    VFEM_CATCH
+}
+int vfem_sim_apply_k(const vfem_sim *sim, const double *u, double *out, int variant, void *stream) {
+    VFEM_TRY
+    ScopedTimer tm("applyK");
+    if (variant == 0 && sim->fast_ok) launch_apply_fast(sim->d, sim->Dm, sim->E.p, u, nullptr, nullptr, 0, out, S(stream));
+    else launch_apply_gather(sim->d, OP_MF0, sim->dK0.p, sim->E.p, u, nullptr, nullptr, 0, out, S(stream));
+    VFEM_CATCH
+}
+int vfem_sim_compliance_gradient(const vfem_sim *sim, const double *u, double *g, void *stream) {
+    VFEM_TRY
+    launch_compliance_gradient(sim->d, sim->dK0.p, sim->rho.p, sim->E0, sim->Emin, sim->gamma, u, g, S(stream));
+    VFEM_CATCH
+}
+int vfem_compliance(const vfem_sim *sim, const double *f, const double *u, double *value_host, void *stream) {
+    VFEM_TRY
+    DevBuf<double> tmp; tmp.alloc(2048 + 8);
+    launch_dot(3 * sim->d.nn, f, u, tmp.p + 8, tmp.p, S(stream));
+    double v = 0.0;
+    VFEM_HIP(hipMemcpyAsync(&v, tmp.p, sizeof(double), hipMemcpyDeviceToHost, S(stream)));
+    VFEM_HIP(hipStreamSynchronize(S(stream)));
+    *value_host = 0.5 * v;
+    VFEM_CATCH
+}
+
+// ---- multigrid ----
+int vfem_mg_create(vfem_mg **out, vfem_sim *fine, int L) {
+    VFEM_TRY
+    if (L < 0) throw Error("numCoarseningLevels must be >= 0");
+    std::unique_ptr<vfem_mg> mg(new vfem_mg);
+    mg->fine = fine; mg->L = L;
+    mg->lv.resize((size_t) L + 1);
+    long long ne[3] = {fine->d.nx, fine->d.ny, fine->d.nz};
+    for (int l = 0; l <= L; ++l) {
+        MgLevel &lv = mg->lv[l];
+        if (l > 0) {
+            for (int dd = 0; dd < 3; ++dd) {
+                if (ne[dd] % 2 == 1)
+                    throw Error("Grid size currently must be divisible by 2^numCoarseningLevels (nonuniform coarsening not yet implemented)");
+                ne[dd] /= 2;
+            }
+        }
+        lv.d = Dims(ne[0], ne[1], ne[2]);
+        lv.kind = (l == 0) ? OP_MF0 : (l == 1 ? OP_MF1 : OP_STENCIL);
+        if (l == 0) { lv.hmask = fine->hmask; lv.maskp = fine->dmask.p; }
+        else {
+            coarsen_dirichlet(mg->lv[l - 1].d, mg->lv[l - 1].hmask, lv.d, lv.hmask);
+            lv.mask.alloc((size_t) lv.d.nn);
+            VFEM_HIP(hipMemcpy(lv.mask.p, lv.hmask.data(), (size_t) lv.d.nn, hipMemcpyHostToDevice));
+            lv.maskp = lv.mask.p;
+        }
+        lv.x.alloc((size_t) lv.d.nn * 3); lv.b.alloc((size_t) lv.d.nn * 3); lv.r.alloc((size_t) lv.d.nn * 3);
+        lv.x.zero(nullptr); lv.b.zero(nullptr); lv.r.zero(nullptr);
+    }
+    // coarsened reference matrices cK0[g] = I_g^T K0 I_g (MG.hh:644-648), children g = 4gx+2gy+gz
+    {
+        std::vector<double> c(8 * 576, 0.0), T(576);
+        for (int g = 0; g < 8; ++g) {
+            double ph[8][8];
+            for (int fn = 0; fn < 8; ++fn)
+                for (int cn = 0; cn < 8; ++cn) {
+                    double v = 1.0;
+                    for (int dd = 0; dd < 3; ++dd) {
+                        const int sh = 2 - dd;
+                        const double p = 0.5 * ((fn >> sh) & 1) + 0.5 * ((g >> sh) & 1);
+                        v *= ((cn >> sh) & 1) ? p : (1.0 - p);
+                    }
+                    ph[fn][cn] = v;
+                }
+            for (int a = 0; a < 24; ++a)
+                for (int j = 0; j < 8; ++j)
+                    for (int dd = 0; dd < 3; ++dd) {
+                        double v = 0.0;
+                        for (int i = 0; i < 8; ++i) v += fine->K0[a * 24 + 3 * i + dd] * ph[i][j];
+                        T[a * 24 + 3 * j + dd] = v;
+                    }
+            for (int j = 0; j < 8; ++j)
+                for (int cc = 0; cc < 3; ++cc)
+                    for (int b = 0; b < 24; ++b) {
+                        double v = 0.0;
+                        for (int i = 0; i < 8; ++i) v += ph[i][j] * T[(3 * i + cc) * 24 + b];
+                        c[(size_t) g * 576 + (3 * j + cc) * 24 + b] = v;
+                    }
+        }
+        mg->cK0.alloc(8 * 576);
+        VFEM_HIP(hipMemcpy(mg->cK0.p, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    const size_t n3 = (size_t) fine->d.nn * 3;
+    mg->pr.alloc(n3); mg->pd.alloc(n3); mg->pAd.alloc(n3); mg->ps.alloc(n3);
+    mg->scal.alloc(16); mg->scratch.alloc(2048);
+    mg->scal.zero(nullptr);
+    VFEM_HIP(hipDeviceSynchronize());
+    *out = mg.release();
+    VFEM_CATCH
+}
+int vfem_mg_destroy(vfem_mg *mg) {
+    VFEM_TRY
+    if (mg && mg->rocblas) rocblas_destroy_handle((rocblas_handle) mg->rocblas);
+    delete mg;
+    VFEM_CATCH
+}
+int vfem_mg_num_levels(const vfem_mg *mg) { return mg->L + 1; }
+int vfem_mg_level_dims(const vfem_mg *mg, int level, int64_t ne[3]) {
+    VFEM_TRY
+    const Dims &d = mg->lv.at((size_t) level).d;
+    ne[0] = d.nx; ne[1] = d.ny; ne[2] = d.nz;
+    VFEM_CATCH
+}
+int64_t vfem_mg_level_num_nodes(const vfem_mg *mg, int level) {
+    if (level < 0 || level > mg->L) return -1;
+    return mg->lv[(size_t) level].d.nn;
+}
+int vfem_mg_level_dirichlet_mask(const vfem_mg *mg, int level, uint8_t *mask_host) {
+    VFEM_TRY
+    const MgLevel &lv = mg->lv.at((size_t) level);
+    std::memcpy(mask_host, lv.hmask.data(), lv.hmask.size());
+    VFEM_CATCH
+}
+int vfem_mg_set_symmetric_gauss_seidel(vfem_mg *mg, int symmetric) { mg->symmetric_gs = symmetric != 0; return 0; }
+const double *vfem_mg_field_ptr(const vfem_mg *mg, int which, int level) {
+    if (which == 2) return mg->pr.p;
+    if (level < 0 || level > mg->L) return nullptr;
+    return which == 0 ? mg->lv[(size_t) level].x.p : mg->lv[(size_t) level].b.p;
+}
+
+int vfem_mg_update_operators(vfem_mg *mg, void *stream) { VFEM_TRY update_operators(mg, S(stream)); VFEM_CATCH }
+
+static void check_level(const vfem_mg *mg, int level) {
+    if (level < 0 || level > mg->L) throw Error("level out of range");
+}
+
+int vfem_mg_apply_k(vfem_mg *mg, int level, const double *u, double *out, void *stream) {
+    VFEM_TRY
+    check_level(mg, level);
+    if (level >= 2 && !mg->operators_valid) update_operators(mg, S(stream));
+    mg_apply(mg, level, u, nullptr, 0, out, S(stream));
+    VFEM_CATCH
+}
+int vfem_mg_residual(vfem_mg *mg, int level, const double *u, const double *b, double *r, void *stream) {
+    VFEM_TRY
+    check_level(mg, level);
+    if (level >= 2 && !mg->operators_valid) update_operators(mg, S(stream));
+    mg_apply(mg, level, u, b, 1, r, S(stream));
+    VFEM_CATCH
+}
+int vfem_mg_smooth(vfem_mg *mg, int level, double *u, const double *b, int forward, void *stream) {
+    VFEM_TRY
+    check_level(mg, level);
+    if (level >= 2 && !mg->operators_valid) update_operators(mg, S(stream));
+    mg_smooth(mg, level, u, b, forward, S(stream));
+    VFEM_CATCH
+}
+int vfem_mg_zero_dirichlet(vfem_mg *mg, int level, double *u, void *stream) {
+    VFEM_TRY
+    check_level(mg, level);
+    launch_zero_dirichlet(mg->lv[(size_t) level].d.nn, mg->lv[(size_t) level].maskp, u, S(stream));
+    VFEM_CATCH
+}
+int vfem_mg_restrict(vfem_mg *mg, int fine_level, const double *fine, double *coarse, void *stream) {
+    VFEM_TRY
+    check_level(mg, fine_level + 1);
+    launch_restrict(mg->lv[(size_t) fine_level + 1].d, fine, coarse, S(stream));
+    VFEM_CATCH
+}
+int vfem_mg_interpolate(vfem_mg *mg, int fine_level, const double *coarse, double *fine, int accumulate, void *stream) {
+    VFEM_TRY
+    check_level(mg, fine_level + 1);
+    launch_prolong(mg->lv[(size_t) fine_level + 1].d, coarse, fine, accumulate, S(stream));
+    VFEM_CATCH
+}
+int vfem_mg_coarsest_solve(vfem_mg *mg, const double *b, double *x, void *stream) {
+    VFEM_TRY
+    if (!mg->operators_valid) update_operators(mg, S(stream));
+    coarsest_solve(mg, b, x, S(stream));
+    VFEM_CATCH
+}
+
+int vfem_mg_solve(vfem_mg *mg, double *x, const double *f, int num_steps, int nsmooth, int stiffness_updated,
+                  int zero_dirichlet, int fmg, void *stream) {
+    VFEM_TRY
+    ScopedTimer tm("MG Solver");
+    hipStream_t s = S(stream);
+    if (!stiffness_updated || !mg->operators_valid) update_operators(mg, s);
+    if (num_steps == 0) return 0;
+    const size_t bytes = (size_t) mg->fine->d.nn * 3 * sizeof(double);
+    VFEM_HIP(hipMemcpyAsync(mg->lv[0].x.p, x, bytes, hipMemcpyDeviceToDevice, s));
+    VFEM_HIP(hipMemcpyAsync(mg->lv[0].b.p, f, bytes, hipMemcpyDeviceToDevice, s));
+    mg_cycles(mg, num_steps, nsmooth, zero_dirichlet != 0, fmg != 0, s);
+    VFEM_HIP(hipMemcpyAsync(x, mg->lv[0].x.p, bytes, hipMemcpyDeviceToDevice, s));
+    VFEM_CATCH
+}
+
+int vfem_mg_pcg(vfem_mg *mg, double *x, const double *b, int max_iter, double tol, int mg_iterations,
+                int mg_smoothing, int fmg, vfem_residual_cb residual_cb, void *cb_user, int *iters_out,
+                double *relres_out, void *stream) {
+    VFEM_TRY
+    hipStream_t s = S(stream);
+    vfem_sim *sim = mg->fine;
+    const long long nn = sim->d.nn, n3 = 3 * nn;
+    const size_t bytes = (size_t) n3 * sizeof(double);
+    double *r = mg->pr.p, *d = mg->pd.p, *Ad = mg->pAd.p, *sv = mg->ps.p, *sc = mg->scal.p;
+    const uint8_t *mask = mg->lv[0].maskp;
+
+    launch_enforce_dirichlet(nn, mask, sim->dvals.p, x, 0, s);          // MG.hh:687-688
+    update_operators(mg, s);                                            // MG.hh:690-691
+    ScopedTimer tm("CG Iterations");
+    double host_sc[4];
+    launch_dot(n3, b, b, mg->scratch.p, sc + 4, s);                     // ||b||^2
+    mg_apply(mg, 0, x, b, 1, r, s);                                     // r = b - K x, Dirichlet zeroed (MG.hh:696)
+    launch_dot(n3, r, r, mg->scratch.p, sc + 3, s);
+    VFEM_HIP(hipMemcpyAsync(host_sc, sc + 3, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    VFEM_HIP(hipStreamSynchronize(s));
+    double rr = host_sc[0];
+    const double bb = host_sc[1];
+    int it = 0;
+    while (it < max_iter && rr > tol * tol * bb) {                      // MG.hh:711 (counter started at 0)
+        ++it;
+        // s = M^{-1} r  (applyPreconditionerInv, MG.hh:476-479)
+        if (mg_smoothing == 0) {
+            VFEM_HIP(hipMemcpyAsync(sv, r, bytes, hipMemcpyDeviceToDevice, s));
+        } else {
+            mg->lv[0].x.zero(s);
+            VFEM_HIP(hipMemcpyAsync(mg->lv[0].b.p, r, bytes, hipMemcpyDeviceToDevice, s));
+            mg_cycles(mg, mg_iterations, mg_smoothing, true, fmg != 0, s);
+            VFEM_HIP(hipMemcpyAsync(sv, mg->lv[0].x.p, bytes, hipMemcpyDeviceToDevice, s));
+        }
+        launch_zero_dirichlet(nn, mask, sv, s);
+        launch_shift_scalar(sc, s);                                     // rMr_old = rMr
+        launch_dot(n3, r, sv, mg->scratch.p, sc + 0, s);                // rMr = r . s
+        launch_pcg_direction(n3, sv, d, sc, it == 1, s);
+        mg_apply(mg, 0, d, nullptr, 0, Ad, s);                          // Ad = K d
+        launch_zero_dirichlet(nn, mask, Ad, s);
+        launch_dot(n3, d, Ad, mg->scratch.p, sc + 2, s);
+        launch_pcg_step(n3, x, r, d, Ad, sc, s);
+        launch_dot(n3, r, r, mg->scratch.p, sc + 3, s);
+        VFEM_HIP(hipMemcpyAsync(host_sc, sc + 3, sizeof(double), hipMemcpyDeviceToHost, s));
+        VFEM_HIP(hipStreamSynchronize(s));
+        rr = host_sc[0];
+        if (!(rr == rr)) throw Error("PCG produced NaN residual");
+        if (residual_cb) residual_cb(cb_user, it, std::sqrt(rr));
+    }
+    if (iters_out) *iters_out = it;
+    if (relres_out) *relres_out = bb > 0 ? std::sqrt(rr / bb) : 0.0;
+    VFEM_CATCH
+}
+
+int vfem_timers_reset(void) {
+    std::lock_guard<std::mutex> lk(vfem::g_timer_mu);
+    vfem::g_timers.clear();
+    return 0;
+}
+int vfem_timers_report(char *buf, size_t len) {
+    std::lock_guard<std::mutex> lk(vfem::g_timer_mu);
+    std::string out;
+    for (auto &kv : vfem::g_timers) {
+        char line[256];
+        std::snprintf(line, sizeof(line), "%s\t%.6f\t%lld\n", kv.first.c_str(), kv.second.seconds, kv.second.calls);
+        out += line;
+    }
+    if (len == 0) return 0;
+    std::strncpy(buf, out.c_str(), len - 1);
+    buf[len - 1] = 0;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+// Elementwise / reduction kernels: SIMP moduli, Dirichlet masking, CG vector updates with
+// wavefront (64-lane) reductions, compliance sensitivity.
+#include "vfem_internal.h"
+
+namespace vfem {
+
+static inline unsigned grid_for(long long n, int block, int cap = 4096) {
+    long long g = (n + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned) g;
+}
+
+// E_e = Emin + rho^gamma (E0 - Emin)  (TPS.hh:725-727); computed once per density update instead of
+// per element per apply.
+__global__ void __launch_bounds__(256) k_simp(long long n, const double *__restrict__ rho, double E0, double Emin,
+                                              double gamma, double *__restrict__ E) {
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+        const double r = rho[i];
+        const double p = (gamma == 3.0) ? r * r * r : pow(r, gamma);
+        E[i] = Emin + p * (E0 - Emin);
+    }
+}
+void launch_simp(long long n, const double *rho, double E0, double Emin, double gamma, double *E, hipStream_t s) {
+    k_simp<<<grid_for(n, 256), 256, 0, s>>>(n, rho, E0, Emin, gamma, E);
+    VFEM_HIP(hipGetLastError());
+}
+
+__global__ void __launch_bounds__(256) k_fill(long long n, double v, double *__restrict__ x) {
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) x[i] = v;
+}
+void launch_fill(long long n, double v, double *x, hipStream_t s) {
+    k_fill<<<grid_for(n, 256), 256, 0, s>>>(n, v, x);
+    VFEM_HIP(hipGetLastError());
+}
+
+// zeroOutDirichletComponents (MG.hh:364-378)
+__global__ void __launch_bounds__(256) k_zero_dirichlet(long long nn, const uint8_t *__restrict__ mask, double *__restrict__ u) {
+    for (long long n = (long long) blockIdx.x * blockDim.x + threadIdx.x; n < nn; n += (long long) gridDim.x * blockDim.x) {
+        const uint8_t m = mask[n];
+        if (m) {
+            if (m & 1) u[3 * n] = 0.0;
+            if (m & 2) u[3 * n + 1] = 0.0;
+            if (m & 4) u[3 * n + 2] = 0.0;
+        }
+    }
+}
+void launch_zero_dirichlet(long long nn, const uint8_t *mask, double *u, hipStream_t s) {
+    k_zero_dirichlet<<<grid_for(nn, 256), 256, 0, s>>>(nn, mask, u);
+    VFEM_HIP(hipGetLastError());
+}
+
+// enforceDirichletConditions (MG.hh:386-398)
+__global__ void __launch_bounds__(256) k_enforce_dirichlet(long long nn, const uint8_t *__restrict__ mask,
+                                                           const double *__restrict__ vals, double *__restrict__ u, int zero) {
+    for (long long n = (long long) blockIdx.x * blockDim.x + threadIdx.x; n < nn; n += (long long) gridDim.x * blockDim.x) {
+        const uint8_t m = mask[n];
+        if (m) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if ((m >> c) & 1) u[3 * n + c] = (zero || !vals) ? 0.0 : vals[3 * n + c];
+        }
+    }
+}
+void launch_enforce_dirichlet(long long nn, const uint8_t *mask, const double *vals, double *u, int zero, hipStream_t s) {
+    k_enforce_dirichlet<<<grid_for(nn, 256), 256, 0, s>>>(nn, mask, vals, u, zero);
+    VFEM_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------
+// dot product: 1024 blocks of per-wave shuffle reductions -> partials -> one final block.
+// Deterministic (fixed partition and order), unlike an atomic finish.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+
+__device__ __forceinline__ double block_sum_256(double v, double *sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) t = sh[0] + sh[1] + sh[2] + sh[3];
+    return t;   // valid in thread 0
+}
+
+constexpr int DOT_BLOCKS = 1024;
+
+__global__ void __launch_bounds__(256) k_dot_partial(long long n, const double *__restrict__ a, const double *__restrict__ b,
+                                                     double *__restrict__ partial) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
+        acc = fma(a[i], b[i], acc);
+    const double t = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ void __launch_bounds__(256) k_dot_final(int nparts, const double *__restrict__ partial, double *__restrict__ out) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
+    const double t = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) *out = t;
+}
+
+void launch_dot(long long n, const double *a, const double *b, double *scratch, double *out, hipStream_t s) {
+    k_dot_partial<<<DOT_BLOCKS, 256, 0, s>>>(n, a, b, scratch);
+    k_dot_final<<<1, 256, 0, s>>>(DOT_BLOCKS, scratch, out);
+    VFEM_HIP(hipGetLastError());
+}
+
+// d = s + (rMr / rMr_old) d   (MG.hh:717-718); scalars live in HBM so the host never stalls on them
+__global__ void __launch_bounds__(256) k_pcg_direction(long long n, const double *__restrict__ sv, double *__restrict__ dv,
+                                                       const double *__restrict__ sc, int first) {
+    const double beta = first ? 0.0 : sc[0] / sc[1];
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
+        dv[i] = first ? sv[i] : fma(beta, dv[i], sv[i]);
+}
+void launch_pcg_direction(long long n, const double *sv, double *dv, const double *sc, int first, hipStream_t s) {
+    k_pcg_direction<<<grid_for(n, 256), 256, 0, s>>>(n, sv, dv, sc, first);
+    VFEM_HIP(hipGetLastError());
+}
+
+// alpha = rMr / dAd ; x += alpha d ; r -= alpha Ad   (MG.hh:723-725)
+__global__ void __launch_bounds__(256) k_pcg_step(long long n, double *__restrict__ x, double *__restrict__ r,
+                                                  const double *__restrict__ dv, const double *__restrict__ Ad,
+                                                  const double *__restrict__ sc) {
+    const double alpha = sc[0] / sc[2];
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+        x[i] = fma(alpha, dv[i], x[i]);
+        r[i] = fma(-alpha, Ad[i], r[i]);
+    }
+}
+void launch_pcg_step(long long n, double *x, double *r, const double *dv, const double *Ad, const double *sc, hipStream_t s) {
+    k_pcg_step<<<grid_for(n, 256), 256, 0, s>>>(n, x, r, dv, Ad, sc);
+    VFEM_HIP(hipGetLastError());
+}
+
+__global__ void k_shift_scalar(double *sc) { sc[1] = sc[0]; }
+void launch_shift_scalar(double *sc, hipStream_t s) {
+    k_shift_scalar<<<1, 1, 0, s>>>(sc);
+    VFEM_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------
+// complianceGradient (TPS.hh:730-751): g_e = -1/2 gamma rho^(gamma-1) (E0-Emin) u_e^T K0 u_e
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_compliance_gradient(Dims d, const double *__restrict__ K0, const double *__restrict__ rho,
+                                                             double E0, double Emin, double gamma,
+                                                             const double *__restrict__ u, double *__restrict__ g) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    const int i = blockIdx.z;
+    if (k >= d.nz || j >= d.ny) return;
+    const long long sx = (long long) d.NY * d.NZ, sy = d.NZ;
+    const long long base = ((long long) i * d.NY + j) * d.NZ + k;
+    double ue[24];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const long long nm = base + ((m >> 2) & 1) * sx + ((m >> 1) & 1) * sy + (m & 1);
+        ue[3 * m] = u[3 * nm]; ue[3 * m + 1] = u[3 * nm + 1]; ue[3 * m + 2] = u[3 * nm + 2];
+    }
+    double en = 0.0;
+#pragma unroll
+    for (int r = 0; r < 24; ++r) {
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < 24; ++c) acc = fma(K0[r * 24 + c], ue[c], acc);
+        en = fma(ue[r], acc, en);
+    }
+    const long long e = ((long long) i * d.ny + j) * d.nz + k;
+    const double r0 = rho[e];
+    const double p = (gamma == 3.0) ? r0 * r0 : pow(r0, gamma - 1.0);
+    g[e] = -0.5 * gamma * p * (E0 - Emin) * en;
+}
+
+void launch_compliance_gradient(const Dims &d, const double *K0, const double *rho, double E0, double Emin,
+                                double gamma, const double *u, double *g, hipStream_t s) {
+    dim3 blk(64, 4, 1), grd((d.nz + 63) / 64, (d.ny + 3) / 4, d.nx);
+    k_compliance_gradient<<<grd, blk, 0, s>>>(d, K0, rho, E0, Emin, gamma, u, g);
+    VFEM_HIP(hipGetLastError());
+}
+
+}  // namespace vfem

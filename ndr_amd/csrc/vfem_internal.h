@@ -1,0 +1,154 @@
+// Internal declarations shared by the libvfem translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/vfem.h"
+
+namespace vfem {
+
+void set_error(const std::string &msg);
+
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define VFEM_HIP(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            throw ::vfem::Error(std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+// Regular grid of degree-1 hexahedra, row-major with the last axis fastest.
+struct Dims {
+    int nx, ny, nz;      // elements per dim
+    int NX, NY, NZ;      // nodes per dim
+    long long nn, ne;    // totals
+    Dims() = default;
+    Dims(long long ex, long long ey, long long ez)
+        : nx((int) ex), ny((int) ey), nz((int) ez), NX((int) ex + 1), NY((int) ey + 1), NZ((int) ez + 1),
+          nn((ex + 1) * (ey + 1) * (ez + 1)), ne(ex * ey * ez) {}
+};
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void) hipFree(p); p = nullptr; n = 0; } }
+    void alloc(size_t count) {
+        if (count == n && p) return;
+        release();
+        if (count == 0) return;
+        VFEM_HIP(hipMalloc((void **) &p, count * sizeof(T)));
+        n = count;
+    }
+    void zero(hipStream_t s) { if (p) VFEM_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+};
+
+// Operator representation of a multigrid level.
+enum OpKind {
+    OP_MF0 = 0,      // matrix-free, Ke = E_e * K0                       (finest level)
+    OP_MF1 = 1,      // matrix-free Galerkin, Ke = sum_f E_f * cK0[f]    (first coarse level)
+    OP_STENCIL = 2,  // stored 27-point 3x3-block stencil                (deeper levels)
+};
+
+// ------------------------------------------------------------------------------------------
+// kernel launchers (kernels_*.hip)
+// ------------------------------------------------------------------------------------------
+void launch_simp(long long n, const double *rho, double E0, double Emin, double gamma, double *E, hipStream_t s);
+void launch_fill(long long n, double v, double *x, hipStream_t s);
+
+// out = K u (res = 0) or out = zeroDirichlet(b - K u) (res = 1; mask may be null => no zeroing)
+void launch_apply_gather(const Dims &d, OpKind kind, const double *K, const double *E, const double *u,
+                         const double *b, const uint8_t *mask, int res, double *out, hipStream_t s);
+void launch_apply_stencil(const Dims &d, const double *S, const double *u, const double *b, const uint8_t *mask,
+                          int res, double *out, hipStream_t s);
+// production level-0 apply (symmetry-reduced, x-marching)
+void launch_apply_fast(const Dims &d, const double *Dm_host, const double *E, const double *u, const double *b,
+                       const uint8_t *mask, int mode, double *out, hipStream_t s);
+
+void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *E, double *u, const double *b,
+                        const uint8_t *mask, int forward, hipStream_t s);
+void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
+                             int forward, hipStream_t s);
+
+void launch_restrict(const Dims &coarse, const double *fine, double *coarse_out, hipStream_t s);
+void launch_prolong(const Dims &coarse, const double *coarse_in, double *fine, int accumulate, hipStream_t s);
+
+void launch_zero_dirichlet(long long nn, const uint8_t *mask, double *u, hipStream_t s);
+void launch_enforce_dirichlet(long long nn, const uint8_t *mask, const double *vals, double *u, int zero, hipStream_t s);
+
+// Galerkin element matrices: mode 1 = children are virtual level-1 matrices (from fine moduli + cK0),
+// mode 2 = children read from Kef.  `c` = dims of the level being built.
+void launch_coarsen_ke(const Dims &c, int mode, const double *cK0, const double *Efine, const double *Kef,
+                       double *Kec, hipStream_t s);
+void launch_stencil_from_ke(const Dims &d, const double *Ke, double *S, hipStream_t s);
+void launch_stencil_from_mf(const Dims &d, OpKind kind, const double *K, const double *E, double *S, hipStream_t s);
+void launch_dense_from_stencil(const Dims &d, const double *S, const uint8_t *mask, double *A, hipStream_t s);
+void launch_dense_finish_inverse(long long n, const uint8_t *mask, double *A, hipStream_t s);
+void launch_gemv_sym(long long n, const double *A, const double *x, double *y, hipStream_t s);
+
+void launch_compliance_gradient(const Dims &d, const double *K0, const double *rho, double E0, double Emin,
+                                double gamma, const double *u, double *g, hipStream_t s);
+
+// reductions: out[slot] = sum a[i]*b[i]; deterministic two-pass. scratch holds >= 2048 doubles.
+void launch_dot(long long n, const double *a, const double *b, double *scratch, double *out, hipStream_t s);
+// PCG vector updates with device-resident scalars (sc: [0]=rMr [1]=rMr_old [2]=dAd [3]=rr)
+void launch_pcg_direction(long long n, const double *sv, double *dv, const double *sc, int first, hipStream_t s);
+void launch_pcg_step(long long n, double *x, double *r, const double *dv, const double *Ad, const double *sc,
+                     hipStream_t s);
+void launch_shift_scalar(double *sc, hipStream_t s);   // sc[1] = sc[0]
+
+}  // namespace vfem
+
+// ------------------------------------------------------------------------------------------
+// opaque handle definitions
+// ------------------------------------------------------------------------------------------
+struct vfem_sim {
+    vfem::Dims d;
+    double bbmin[3], bbmax[3], h[3];
+    double lambda = 0.0, mu = 0.5;              // ETensor(1, 0) default, TPS.hh:1379
+    double E0 = 1.0, Emin = 1e-9, gamma = 3.0;  // TPS.hh:1392-1394
+    double K0[576];                             // host copy, row-major
+    double Dm[64];                              // symmetry-reduced (mode-space) coefficients, host
+    bool   fast_ok = false;                     // mode-space sparsity pattern verified for this K0
+    vfem::DevBuf<double> dK0, rho, E, dvals, loads;
+    vfem::DevBuf<uint8_t> dmask;
+    std::vector<uint8_t> hmask;                 // host copy of the Dirichlet mask
+    std::vector<double> hvals;
+    bool nonzero_dirichlet = false;
+    void update_k0();
+};
+
+struct MgLevel {
+    vfem::Dims d;
+    vfem::OpKind kind = vfem::OP_MF0;
+    vfem::DevBuf<uint8_t> mask;                 // coarsened Dirichlet masks (levels >= 1)
+    const uint8_t *maskp = nullptr;
+    std::vector<uint8_t> hmask;
+    vfem::DevBuf<double> Ke, S;                 // Galerkin element matrices / stencil (levels >= 2)
+    vfem::DevBuf<double> x, b, r;               // work vectors (m_x, m_b of MG.hh:755-756 + residual)
+};
+
+struct vfem_mg {
+    vfem_sim *fine = nullptr;
+    int L = 0;                                  // numCoarseningLevels
+    std::vector<MgLevel> lv;
+    vfem::DevBuf<double> cK0;                   // 8 x 576 coarsened reference matrices (MG.hh:644-648)
+    vfem::DevBuf<double> Ainv;                  // coarsest-level dense inverse
+    vfem::DevBuf<double> pr, pd, pAd, ps;       // PCG vectors
+    vfem::DevBuf<double> scal, scratch;
+    bool symmetric_gs = true;                   // MG.hh:758
+    bool operators_valid = false;
+    void *rocblas = nullptr;                    // rocblas_handle for the coarsest factorisation
+    vfem::DevBuf<int> info;
+};

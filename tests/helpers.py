@@ -1,0 +1,65 @@
+"""Shared builders for the parity tests: the same problem set up on the CPU oracle and on the HIP path."""
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+MATERIAL = os.path.join(GOLDEN, "materials", "B9Creator.material")
+BC_CANTILEVER = os.path.join(GOLDEN, "bcs", "3d", "cantilever_flexion.bc")
+BC_BRIDGE = os.path.join(GOLDEN, "bcs", "3d", "bridge.bc")
+
+
+def seeded_density(ne, seed=88, kind="uniform"):
+    """D1 (i.i.d. U[0,1]) and D2 ("mid-optimisation" proxy) densities of SURVEY 8(d)."""
+    rng = np.random.default_rng(seed)
+    ne = tuple(int(n) for n in ne)
+    if kind == "uniform":
+        return rng.uniform(0.0, 1.0, size=int(np.prod(ne)))
+    idx = np.stack(np.meshgrid(*[np.linspace(0, 1, n) for n in ne], indexing="ij"), -1)
+    smooth = np.zeros(ne)
+    for _ in range(6):
+        k = rng.uniform(0.5, 3.0, size=len(ne)) * np.pi
+        ph = rng.uniform(0, 2 * np.pi)
+        smooth += np.cos(idx @ k + ph)
+    lo, hi = smooth.min(), smooth.max()
+    for _ in range(60):
+        tau = 0.5 * (lo + hi)
+        rho = 1.0 / (1.0 + np.exp(-8.0 * (smooth - tau)))
+        if rho.mean() > 0.4:
+            lo = tau
+        else:
+            hi = tau
+    return rho.reshape(-1)
+
+
+def make_oracle(ne, domain, bc, rho=None, v0=0.5, Emin=1e-4):
+    from oracle import vfem_oracle as vo
+    sim = vo.OracleSim(domain, ne)
+    sim.read_material(MATERIAL)
+    sim.set_uniform_densities(v0)
+    if bc:
+        sim.apply_bc_file(bc)
+    sim.E0, sim.Emin, sim.gamma = 1.0, Emin, 3.0
+    if rho is not None:
+        sim.set_densities(rho)
+    return sim
+
+
+def make_hip(ne, domain, bc, rho=None, v0=0.5, Emin=1e-4):
+    from ndr_amd import pyVoxelFEM as pv
+    tps = pv.TensorProductSimulator([1, 1, 1], [np.array(domain[0], float), np.array(domain[1], float)], list(ne))
+    tps.readMaterial(MATERIAL)
+    tps.setUniformDensities(v0)
+    if bc:
+        tps.applyDisplacementsAndLoadsFromFile(bc)
+    tps.E_0, tps.E_min, tps.gamma = 1.0, Emin, 3.0
+    if rho is not None:
+        tps.setElementDensities(rho)
+    return tps
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))

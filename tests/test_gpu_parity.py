@@ -1,0 +1,186 @@
+"""-m gpu parity tests: every HIP operator (through the C ABI, via ndr_amd.pyVoxelFEM) against the CPU
+oracle on the same seeded inputs.  fp64 stencil-class operators must agree to 1e-11 relative (different
+summation order only); the converged solve to 1e-8 on compliance (north_star asks 1e-5)."""
+import numpy as np
+import pytest
+
+from helpers import BC_BRIDGE, BC_CANTILEVER, make_hip, make_oracle, relerr, seeded_density
+
+pytestmark = pytest.mark.gpu
+
+TOL_OP = 1e-11
+
+GRIDS = [
+    ((8, 4, 4), ([0, 0, 0], [2, 1, 1])),
+    ((5, 7, 3), ([0, 0, 0], [1, 1, 1])),          # ragged, odd
+    ((16, 8, 8), ([0, 0, 0], [2, 1, 1])),
+    ((6, 10, 70), ([0, 0, 0], [4, 2, 1])),        # two z tiles, non-cubic voxels
+    ((70, 9, 65), ([0, 0, 0], [1, 2, 3])),        # several x chunks, y tiles, z tiles
+    ((1, 1, 1), ([0, 0, 0], [1, 1, 1])),
+]
+
+
+def test_k0_matches_oracle():
+    from oracle import vfem_oracle as vo
+    for h in ([1, 1, 1], [2 / 256, 1 / 256, 1 / 256], [4 / 512, 2 / 256, 1 / 256]):
+        tps = make_hip((2, 2, 2), ([0, 0, 0], [2 * h[0], 2 * h[1], 2 * h[2]]), None)
+        lam, mu = vo.lame(1.0, 0.3, 3)
+        K0 = vo.element_stiffness([1, 1, 1], h, lam, mu)
+        assert relerr(tps.fullDensityElementStiffnessMatrix(), K0) < 1e-13
+
+
+@pytest.mark.parametrize("ne,dom", GRIDS)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_apply_k(ne, dom, variant):
+    rho = seeded_density(ne, 88)
+    o = make_oracle(ne, dom, None, rho)
+    t = make_hip(ne, dom, None, rho)
+    rng = np.random.default_rng(1)
+    u = rng.standard_normal((o.num_nodes, 3))
+    ref = o.apply_k(u)
+    got = t.applyK_device(u, variant).cpu().numpy()
+    assert relerr(got, ref) < TOL_OP
+
+
+def test_apply_k_linearity_and_symmetry_large():
+    """size-independent properties at a size the oracle would not finish quickly: <Ku,v> = <u,Kv>."""
+    import torch
+    ne, dom = (160, 96, 130), ([0, 0, 0], [2, 1, 1])
+    t = make_hip(ne, dom, None, seeded_density(ne, 3, "proxy"))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    u = torch.randn((t.numNodes(), 3), dtype=torch.float64, device="cuda", generator=g)
+    v = torch.randn((t.numNodes(), 3), dtype=torch.float64, device="cuda", generator=g)
+    Ku, Kv = t.applyK_device(u), t.applyK_device(v)
+    a, b = float((Ku * v).sum()), float((u * Kv).sum())
+    assert abs(a - b) < 1e-10 * abs(a)
+    Kg = t.applyK_device(u, 1)
+    assert float((Ku - Kg).abs().max() / Kg.abs().max()) < TOL_OP
+    K2 = t.applyK_device(2.0 * u - 3.0 * v)
+    assert float((K2 - (2.0 * Ku - 3.0 * Kv)).abs().max() / Ku.abs().max()) < 1e-12
+    # rigid translation is in the null space
+    one = torch.ones_like(u)
+    assert float(t.applyK_device(one).abs().max()) < 1e-9 * float(Ku.abs().max())
+
+
+@pytest.mark.parametrize("ne,dom", GRIDS[:5])
+def test_compliance_gradient(ne, dom):
+    rho = seeded_density(ne, 5)
+    o = make_oracle(ne, dom, None, rho)
+    t = make_hip(ne, dom, None, rho)
+    u = np.random.default_rng(2).standard_normal((o.num_nodes, 3))
+    assert relerr(t.complianceGradient_device(u).cpu().numpy(), o.compliance_gradient(u)) < TOL_OP
+
+
+def _mg_pair(ne, dom, bc, levels, kind="uniform"):
+    from oracle import vfem_oracle as vo
+    rho = seeded_density(ne, 88, kind)
+    o = make_oracle(ne, dom, bc, rho)
+    t = make_hip(ne, dom, bc, rho)
+    omg = vo.OracleMG(o, levels, nthreads=4)
+    omg.update_element_stiffness()
+    tmg = t.multigridSolver(levels)
+    tmg.updateElementStiffnessMatrices()
+    return o, t, omg, tmg
+
+
+@pytest.mark.parametrize("bc", [BC_CANTILEVER, BC_BRIDGE])
+def test_dirichlet_coarsening(bc):
+    o, t, omg, tmg = _mg_pair((16, 8, 8), ([0, 0, 0], [2, 1, 1]), bc, 3)
+    assert np.array_equal(t.dirichletMask, o.dmask.astype(bool))
+    for l in range(1, 4):
+        assert np.array_equal(tmg.getSimulator(l).dirichletMask, omg.sims[l].dmask.astype(bool)), l
+
+
+@pytest.mark.parametrize("ne,levels", [((16, 8, 8), 3), ((24, 8, 16), 2), ((8, 8, 8), 1)])
+def test_mg_operators(ne, levels):
+    dom = ([0, 0, 0], [2, 1, 1])
+    o, t, omg, tmg = _mg_pair(ne, dom, BC_CANTILEVER, levels)
+    rng = np.random.default_rng(7)
+    for l in range(levels + 1):
+        n = omg.sims[l].num_nodes
+        u = rng.standard_normal((n, 3))
+        b = rng.standard_normal((n, 3))
+        assert relerr(tmg.applyK(l, u), omg.apply_k(l, u)) < TOL_OP, ("applyK", l)
+        assert relerr(tmg.computeResidual(l, u, b), omg.residual(l, u.copy(), b)) < TOL_OP, ("residual", l)
+        if l < levels:
+            for fwd in (True, False):
+                uo = u.copy()
+                omg.enforce_dirichlet(l, uo, True)
+                us = uo.copy()
+                omg.smoothing(l, us, b, fwd)
+                got = tmg.smoothing_device(l, uo, b, fwd).cpu().numpy()
+                assert relerr(got, us) < 1e-10, ("smoothing", l, fwd)
+            r = rng.standard_normal((n, 3))
+            assert relerr(tmg.restriction_device(l, r).cpu().numpy(), omg.restriction(l, r)) < TOL_OP, ("restrict", l)
+            c = rng.standard_normal((omg.sims[l + 1].num_nodes, 3))
+            assert relerr(tmg.interpolation_device(l, c).cpu().numpy(), omg.interpolation(l, c)) < TOL_OP
+    bL = rng.standard_normal((omg.sims[levels].num_nodes, 3))
+    ref = omg.sims[levels].solve(bL)
+    assert relerr(tmg.coarsestSolve_device(bL).cpu().numpy(), ref) < 1e-8
+
+
+def test_transfer_adjointness():
+    o, t, omg, tmg = _mg_pair((16, 8, 8), ([0, 0, 0], [2, 1, 1]), BC_CANTILEVER, 2)
+    rng = np.random.default_rng(3)
+    r = rng.standard_normal((omg.sims[0].num_nodes, 3))
+    c = rng.standard_normal((omg.sims[1].num_nodes, 3))
+    lhs = float(np.sum(tmg.restriction_device(0, r).cpu().numpy() * c))
+    rhs = float(np.sum(r * tmg.interpolation_device(0, c).cpu().numpy()))
+    assert abs(lhs - rhs) < 1e-12 * abs(lhs)
+
+
+@pytest.mark.parametrize("fmg", [False, True])
+def test_mg_solve_cycles(fmg):
+    o, t, omg, tmg = _mg_pair((16, 8, 8), ([0, 0, 0], [2, 1, 1]), BC_CANTILEVER, 2)
+    f = o.build_load_vector()
+    ref = omg.solve(np.zeros_like(f), f, 2, 2, True, False, fmg)
+    got = tmg.solve(np.zeros_like(f), f, 2, 2, True, False, None, fmg)
+    assert relerr(got, ref) < 1e-9
+
+
+@pytest.mark.parametrize("bc,ne,dom,levels,kind", [
+    (BC_CANTILEVER, (32, 16, 16), ([0, 0, 0], [2, 1, 1]), 2, "uniform"),
+    (BC_BRIDGE, (32, 16, 8), ([0, 0, 0], [4, 2, 1]), 2, "proxy"),
+    (BC_CANTILEVER, (32, 16, 16), ([0, 0, 0], [2, 1, 1]), 3, "proxy"),
+])
+def test_pcg_matches_oracle(bc, ne, dom, levels, kind):
+    o, t, omg, tmg = _mg_pair(ne, dom, bc, levels, kind)
+    f = o.build_load_vector()
+    assert relerr(t.buildLoadVector(), f) < 1e-15
+    uo = omg.pcg(np.zeros_like(f), f, 100, 1e-6, 1, 2, True)
+    ug = tmg.preconditionedConjugateGradient(np.zeros_like(f), f, 100, 1e-6, None, 1, 2, True)
+    assert tmg.last_iterations == omg.last_iters
+    co, cg = float(np.sum(f * uo)), float(np.sum(f * ug))
+    assert abs(co - cg) < 1e-8 * abs(co)
+    assert relerr(ug, uo) < 1e-6
+    # sensitivity parity (north_star: 1e-5 relative)
+    assert relerr(t.complianceGradient_device(ug).cpu().numpy(), o.compliance_gradient(uo)) < 1e-6
+    # direct-solve cross check of the converged answer
+    ud = o.solve(f)
+    assert abs(float(np.sum(f * ud)) - cg) < 1e-5 * abs(cg)
+
+
+def test_objective_and_problem_api():
+    """the pyVoxelFEM call sequence of fem.ground_truth_topopt (fem.py:31-87) on a small cantilever"""
+    from ndr_amd import pyVoxelFEM as pv
+    from oracle import vfem_oracle as vo
+    ne, dom = (16, 8, 8), ([0, 0, 0], [2, 1, 1])
+    t = make_hip(ne, dom, BC_CANTILEVER, None, v0=0.5)
+    obj = pv.MultigridComplianceObjective(t.multigridSolver(2))
+    top = pv.TopologyOptimizationProblem(t, obj, [pv.TotalVolumeConstraint(0.5)],
+                                         [pv.SmoothingFilter(), pv.ProjectionFilter()])
+    obj.tol, obj.mgIterations, obj.fullMultigrid, obj.zeroInit, obj.mgSmoothingIterations = 1e-8, 1, True, False, 2
+    oco = pv.OCOptimizer(top)
+    top.setVars(t.getDensities())
+    o = make_oracle(ne, dom, BC_CANTILEVER, None, v0=0.5)
+    oobj = vo.OracleComplianceObjective(o)
+    otop = vo.OracleProblem(o, oobj, [vo.OracleVolumeConstraint(0.5)], [vo.OracleSmoothingFilter(), vo.OracleProjectionFilter()])
+    ooc = vo.OracleOC(otop)
+    otop.set_vars(o.rho.copy())
+    for _ in range(3):
+        a, b = 2.0 * top.evaluateObjective(), 2.0 * otop.evaluate_objective()
+        assert abs(a - b) < 1e-6 * abs(b)
+        assert relerr(top.evaluateObjectiveGradient(), otop.evaluate_objective_gradient()) < 1e-5
+        oco.step()
+        ooc.step()
+    assert relerr(top.getVars(), otop.cached[0]) < 1e-4
