@@ -411,7 +411,8 @@ int vfem_sim_get_densities(const vfem_sim *sim, double *rho, void *stream) {
 int vfem_sim_apply_k(const vfem_sim *sim, const double *u, double *out, int variant, void *stream) {
     VFEM_TRY
     ScopedTimer tm("applyK");
-    if (variant == 0 && sim->fast_ok) launch_apply_fast(sim->d, sim->Dm, sim->E.p, u, nullptr, nullptr, 0, out, S(stream));
+    if (variant != 1 && sim->fast_ok)
+        launch_apply_fast(sim->d, sim->Dm, sim->E.p, u, nullptr, nullptr, variant == 0 ? 0 : 3, out, S(stream));
     else launch_apply_gather(sim->d, OP_MF0, sim->dK0.p, sim->E.p, u, nullptr, nullptr, 0, out, S(stream));
     VFEM_CATCH
 }

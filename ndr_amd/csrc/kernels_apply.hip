@@ -16,31 +16,33 @@
 // accumulates per-face sums in registers across the two adjacent element layers and scatters to the 4
 // nodes of the face through LDS: no global atomics, deterministic order.
 //
-// Tile: 8 x 64 element columns need 9 x 65 node columns and complete 7 x 63 node columns (one-sided
-// overlap), i.e. 86 % of the lanes produce output.  blockIdx.x is the x-chunk: consecutive block ids are
+// Tile: TY x 64 element columns need (TY+1) x 65 node columns and complete (TY-1) x 63 node columns
+// (one-sided overlap), i.e. 82 % of the lanes produce output at TY = 6.  blockIdx.x is the x-chunk: consecutive block ids are
 // dealt round-robin to the 8 XCDs, so with a multiple of 8 chunks every XCD owns one slab of x-planes and
 // the halo rows/columns shared by neighbouring tiles are served by that XCD's own L2.
 #include "vfem_internal.h"
 
 namespace vfem {
 
-constexpr int TY = 8;          // element rows per tile (waves per block)
+constexpr int TY = 8;          // element rows per tile = waves per block (2 per SIMD, one block per CU)
 constexpr int TZ = 64;         // element columns per tile (lanes)
 constexpr int ROW_D = 196;     // doubles per staged node row (65 nodes x 3 = 195 used)
+constexpr int PD = 2;          // planes of u kept in flight in registers
+constexpr int NLD = 4;         // staged doubles per thread and plane: (TY+1)*195 = 1755 <= 4 * 512
+constexpr int SU_SIZE = (TY + 1) * ROW_D;               // element 195 of every row is the dump slot of unused staging slots
 
 struct DmArgs { double v[36]; };
 
-template <int MODE>   // 0: out = K u   1: out = zeroDirichlet(b - K u)   2: out = zeroDirichlet(K u)
-__global__ void __launch_bounds__(TY * TZ) k_apply_fast(Dims d, DmArgs dm, const double *__restrict__ E,
+template <int MODE, int WPS>   // MODE 0: out = K u   1: out = zeroDirichlet(b - K u)   2: out = zeroDirichlet(K u)
+__global__ void __launch_bounds__(TY * TZ, WPS) k_apply_fast(Dims d, DmArgs dm, const double *__restrict__ E,
                                                         const double *__restrict__ u, const double *__restrict__ b,
                                                         const uint8_t *__restrict__ mask, double *__restrict__ out,
                                                         int planes_per_chunk) {
-    __shared__ double su[(TY + 1) * ROW_D];
-    __shared__ double sB[3 * TY * TZ];
-    __shared__ double sC[3 * TY * TZ];
-    __shared__ double sD[3 * TY * TZ];
+    __shared__ double su2[2 * SU_SIZE];          // staged node planes, double-buffered
+    __shared__ double sS[2 * 9 * TY * TZ];        // face -> node scatter slots (B, C, D shares), double-buffered
 
     const int tz = threadIdx.x, ty = threadIdx.y;
+    const int tid = ty * TZ + tz;
     const int k0 = blockIdx.y * (TZ - 1) - 1;      // node column of lane 0
     const int j0 = blockIdx.z * (TY - 1) - 1;      // node row of wave 0
     const int p0 = blockIdx.x * planes_per_chunk;  // first output plane of this chunk
@@ -52,29 +54,47 @@ __global__ void __launch_bounds__(TY * TZ) k_apply_fast(Dims d, DmArgs dm, const
     const bool elem_ok = ej >= 0 && ej < d.ny && ek >= 0 && ek < d.nz;
     const bool out_ok = ty >= 1 && tz >= 1 && ej < d.NY && ek < d.NZ;   // ej, ek >= 0 follows from ty, tz >= 1
     const long long plane = (long long) d.NY * d.NZ;
+    const int plane3 = 3 * d.NY * d.NZ;
 
-    // stage one node plane (9 rows x 195 doubles) into su; rows/columns outside the grid read as zero
-    auto stage_plane = [&](int i) {
-        auto load_row = [&](int r, int q) {
-            const int jj = j0 + r;
-            const int kk = k0 + q / 3;
-            double v = 0.0;
-            if (q < 195 && jj >= 0 && jj < d.NY && kk >= 0 && kk < d.NZ)
-                v = u[3 * ((long long) i * plane + (long long) jj * d.NZ + k0) + q];
-            if (q < 195) su[r * ROW_D + q] = v;
-        };
-        load_row(ty, tz);
-        load_row(ty, tz + 64);
-        load_row(ty, tz + 128);
-        if (tz < 3) load_row(ty, tz + 192);
-        if (ty < 4) {   // ninth row: split over waves 0..3
-            const int q = ty * 64 + tz;
-            load_row(TY, q);
-        }
+    // Staging slots: the (TY+1) x 195 doubles of a node plane are dealt to the TY*64 threads, 4 per thread.
+    // Offsets do not depend on the plane, so they are computed once.  Loads are unconditional: rows/columns
+    // outside the grid read some in-bounds (finite) value instead, which only ever meets elements outside
+    // the grid, and those carry modulus 0.
+    int goff[NLD];            // offset (in doubles) from the start of a plane, clamped into the plane
+    int loff[NLD];            // LDS offset (unused slots land in the dump area)
+#pragma unroll
+    for (int s4 = 0; s4 < NLD; ++s4) {
+        const int L = s4 * (TY * TZ) + tid;
+        const int r = L / 195, q = L - r * 195;
+        const bool slot = r <= TY;
+        int jj = j0 + r;
+        jj = jj < 0 ? 0 : (jj > d.NY - 1 ? d.NY - 1 : jj);
+        int g = 3 * (jj * d.NZ + k0) + q;
+        g = g < 0 ? 0 : (g > plane3 - 1 ? plane3 - 1 : g);
+        goff[s4] = g;
+        loff[s4] = slot ? r * ROW_D + q : (tid % (TY + 1)) * ROW_D + 195;
+    }
+    const int ejc = ej < 0 ? 0 : (ej > d.ny - 1 ? d.ny - 1 : ej);
+    const int ekc = ek < 0 ? 0 : (ek > d.nz - 1 ? d.nz - 1 : ek);
+    const int eoff = ejc * d.nz + ekc;
+    const long long elayer = (long long) d.ny * d.nz;
+
+    auto issue_loads = [&](int i, double v[NLD], double &Ev) {     // plane i of u, element layer i of E
+        const double *up = u + 3 * (long long) i * plane;
+#pragma unroll
+        for (int s4 = 0; s4 < NLD; ++s4) v[s4] = up[goff[s4]];
+        const int il = i < d.nx ? i : d.nx - 1;
+        Ev = E[il * elayer + eoff];
+    };
+    auto stage_store = [&](const double v[NLD], int buf) {
+        double *su = su2 + buf * SU_SIZE;
+#pragma unroll
+        for (int s4 = 0; s4 < NLD; ++s4) su[loff[s4]] = v[s4];
     };
 
     // y/z transform of the face (ty,tz) of the staged plane: f[2*py+pz][c]
-    auto face_modes = [&](double f[4][3]) {
+    auto face_modes = [&](double f[4][3], int buf) {
+        const double *su = su2 + buf * SU_SIZE;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const double a  = su[ty * ROW_D + 3 * tz + c];
@@ -90,7 +110,8 @@ __global__ void __launch_bounds__(TY * TZ) k_apply_fast(Dims d, DmArgs dm, const
     };
 
     // transposed y/z transform of the face sums + scatter to the 4 nodes of the face; returns own share
-    auto scatter_face = [&](const double acc[4][3], double wa[3]) {
+    auto scatter_face = [&](const double acc[4][3], double wa[3], int buf) {
+        double *sB = sS + buf * (9 * TY * TZ), *sC = sB + 3 * TY * TZ, *sD = sC + 3 * TY * TZ;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const double p = acc[0][c] - acc[2][c], q = acc[1][c] - acc[3][c];
@@ -102,8 +123,9 @@ __global__ void __launch_bounds__(TY * TZ) k_apply_fast(Dims d, DmArgs dm, const
         }
     };
 
-    auto emit_plane = [&](int i, const double wa[3]) {
+    auto emit_plane = [&](int i, const double wa[3], int buf) {
         if (!out_ok) return;
+        const double *sB = sS + buf * (9 * TY * TZ), *sC = sB + 3 * TY * TZ, *sD = sC + 3 * TY * TZ;
         const long long n = (long long) i * plane + (long long) ej * d.NZ + ek;
         double w[3];
 #pragma unroll
@@ -130,18 +152,13 @@ __global__ void __launch_bounds__(TY * TZ) k_apply_fast(Dims d, DmArgs dm, const
 
     const int i_start = p0 > 0 ? p0 - 1 : 0;
     const int i_end = p1 + 1 < d.NX - 1 ? p1 + 1 : d.NX - 1;
-    stage_plane(i_start);
-    __syncthreads();
-    face_modes(fold);
-    __syncthreads();
 
-    for (int i = i_start + 1; i <= i_end; ++i) {
-        stage_plane(i);
-        const double Ee = elem_ok ? E[((long long) (i - 1) * d.ny + ej) * d.nz + ek] : 0.0;
-        __syncthreads();
+    // element layer i-1 between the staged plane i (in su2[buf]) and the previous one (in fold); leaves the
+    // face sums of plane i-1 in the scatter slots sS[buf] and returns this thread's own share in wa
+    auto process = [&](double Ee, int buf, double wa[3]) {
+        if (!elem_ok) Ee = 0.0;
         double fnew[4][3];
-        face_modes(fnew);
-        // x stage: modes m[4*px + 2*py + pz][c] of element layer i-1
+        face_modes(fnew, buf);
         double m[8][3];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -156,7 +173,7 @@ __global__ void __launch_bounds__(TY * TZ) k_apply_fast(Dims d, DmArgs dm, const
 #pragma unroll
         for (int p = 0; p < 8; ++p)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) qv[p][c] = dm.v[3 * p + c] * m[p][c];
+            for (int c = 0; c < 3; ++c) qv[p][c] = (p == 0) ? 0.0 : dm.v[3 * p + c] * m[p][c];   // translations are null modes
         {
             int idx = 24;
 #pragma unroll
@@ -183,21 +200,58 @@ __global__ void __launch_bounds__(TY * TZ) k_apply_fast(Dims d, DmArgs dm, const
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const double lo = Ee * qv[q][c], hi = Ee * qv[4 + q][c];
-                acc[q][c] = carry[q][c] + (lo - hi);
-                carry[q][c] = lo + hi;
+                acc[q][c] = fma(Ee, qv[q][c] - qv[4 + q][c], carry[q][c]);
+                carry[q][c] = Ee * (qv[q][c] + qv[4 + q][c]);
             }
-        double wa[3];
-        scatter_face(acc, wa);
-        __syncthreads();
-        if (i - 1 >= p0) emit_plane(i - 1, wa);
+        scatter_face(acc, wa, buf);
+    };
+
+    // Software pipeline, one barrier per plane.  While plane i is processed out of su2[buf], plane i+1 is
+    // written to the other LDS buffer and the loads of planes i+2 .. i+1+PD are in flight in registers
+    // (the kernel is latency-bound otherwise: ~18 KB per plane and CU, one block per CU).
+    double R[PD][NLD], ER[PD];
+    issue_loads(i_start, R[0], ER[0]);               // plane i_start, element layer i_start
+    stage_store(R[0], 0);
+    double Eim1 = 0.0, Ei = ER[0];
+#pragma unroll
+    for (int k = 0; k < PD; ++k)
+        if (i_start + 1 + k <= i_end) issue_loads(i_start + 1 + k, R[k], ER[k]);   // R[k]: plane i_start+1+k (+ m PD)
+    __syncthreads();
+    face_modes(fold, 0);
+    if (i_start + 1 <= i_end) {
+        stage_store(R[0], 1);
+        Eim1 = Ei; Ei = ER[0];
+        if (i_start + 1 + PD <= i_end) issue_loads(i_start + 1 + PD, R[0], ER[0]);
+    }
+    __syncthreads();
+
+    int buf = 1;     // LDS buffer holding plane i
+    for (int i = i_start + 1; i <= i_end; i += PD) {
+#pragma unroll
+        for (int kk = 0; kk < PD; ++kk) {
+            const int ii = i + kk;
+            if (ii > i_end) break;
+            constexpr int dummy = 0; (void) dummy;
+            const int k = (kk + 1) % PD;             // register set holding plane ii+1
+            double Enext = 0.0;
+            if (ii + 1 <= i_end) {
+                stage_store(R[k], buf ^ 1);
+                Enext = ER[k];
+                if (ii + 1 + PD <= i_end) issue_loads(ii + 1 + PD, R[k], ER[k]);
+            }
+            double wa[3];
+            process(Eim1, buf, wa);
+            __syncthreads();
+            if (ii - 1 >= p0) emit_plane(ii - 1, wa, buf);
+            buf ^= 1;
+            Eim1 = Ei; Ei = Enext;
+        }
     }
     if (p1 == d.NX - 1) {   // last plane of the grid: only the element layer below contributes
         double wa[3];
+        scatter_face(carry, wa, buf);
         __syncthreads();
-        scatter_face(carry, wa);
-        __syncthreads();
-        emit_plane(d.NX - 1, wa);
+        emit_plane(d.NX - 1, wa, buf);
     }
 }
 
@@ -209,9 +263,10 @@ void launch_apply_fast(const Dims &d, const double *Dm_host, const double *E, co
     if (d.NX >= 1024) nchunks = 16;
     const int ppc = (d.NX + nchunks - 1) / nchunks;
     dim3 blk(TZ, TY, 1), grd((d.NX + ppc - 1) / ppc, (d.NZ + TZ - 2) / (TZ - 1), (d.NY + TY - 2) / (TY - 1));
-    if (mode == 0)      k_apply_fast<0><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc);
-    else if (mode == 1) k_apply_fast<1><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc);
-    else                k_apply_fast<2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc);
+    if (mode == 0)      k_apply_fast<0, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc);
+    else if (mode == 1) k_apply_fast<1, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc);
+    else if (mode == 2) k_apply_fast<2, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc);
+    else                k_apply_fast<0, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc);   // tuning variant
     VFEM_HIP(hipGetLastError());
 }
 

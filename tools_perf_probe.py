@@ -31,7 +31,8 @@ def t_pcg(ne, dom, levels):
 
 if __name__ == '__main__':
     for n in (128, 256):
-        for v in (0, 1): t_apply(n, v)
-    t_apply(512, 0, 5)
+        for v in (0, 2, 1): t_apply(n, v)
+    t_apply(512, 0, 5); t_apply(512, 2, 5)
+    sys.exit(0)
     t_pcg((128, 64, 64), ([0, 0, 0], [2, 1, 1]), 3)
     t_pcg((256, 128, 128), ([0, 0, 0], [2, 1, 1]), 4)
