@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Benchmark of the voxel-FEM hot path on MI355X (contract: see the task statement / DESIGN.md section 6).
+
+A "step" is one matrix-free stiffness apply  Ku = K(rho) u  (the SpMV of BASELINE.json's metric) over the
+whole Q1 fp64 voxel grid (default 512^3, `--grid` to change) with u, rho and Ku resident in HBM.  With N > 1
+ranks the grid is split into x-slabs (one per GPU) and every step includes the halo exchange of u
+(`ndr_amd.distributed`); the work is fixed as N grows (strong scaling).  Beside the headline value the same
+JSON line reports
+  * CG-MG iterations/s of the multigrid-preconditioned CG compliance solve (reference settings: tol 1e-4,
+    one full-multigrid cycle per iteration, 2+2 symmetric coloured Gauss-Seidel sweeps, zero initial guess),
+  * `roofline`: algorithmic HBM bytes of one apply / its measured duration, against the 8 TB/s HBM peak,
+  * `cpu_baseline`: the CPU oracle (a port of the reference's element loop with its thread-private
+    accumulators) timed on this host on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(ne):
+    """read u once, write Ku once (numNodes x 3 fp64 each), read rho once."""
+    nn = (ne[0] + 1) * (ne[1] + 1) * (ne[2] + 1)
+    nel = ne[0] * ne[1] * ne[2]
+    return 2 * nn * 3 * 8 + nel * 8
+
+
+def time_apply(tps, u, steps, warmup, variant=0):
+    """kernel time per launch from HIP events on the launch stream (torch's current stream)."""
+    for _ in range(warmup):
+        tps.applyK_device(u, variant)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    out = torch.empty_like(u)
+    from ndr_amd import _lib
+    from ndr_amd.pyVoxelFEM import _ptr, _stream
+    lib = _lib.load()
+    for a, b in evs:
+        a.record()
+        _lib.check(lib.vfem_sim_apply_k(tps._h, _ptr(u), _ptr(out), int(variant), _stream()))
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e-3
+
+
+def cpu_baseline(sample_ne, seconds_budget=12.0):
+    """The oracle's element-loop applyK (ParallelAssembly-style private accumulators) on the host cores."""
+    from oracle import vfem_oracle as vo
+    from helpers import make_oracle, seeded_density
+    cores = os.cpu_count() or 1
+    threads = min(cores, 8)          # the reference drivers cap applyK at min(physical cores, 8) threads
+    o = make_oracle(sample_ne, ([0, 0, 0], [1, 1, 1]), None, seeded_density(sample_ne, 88))
+    u = np.random.default_rng(0).standard_normal((o.num_nodes, 3))
+    o.apply_k(u, threads)
+    t0, reps = time.perf_counter(), 0
+    while True:
+        o.apply_k(u, threads)
+        reps += 1
+        if time.perf_counter() - t0 > seconds_budget or reps >= 50:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": o.num_elems / dt / 1e9, "unit": "GVoxel/s", "cores": threads, "kind": "port",
+            "sample": "%dx%dx%d Q1 fp64 applyK, %d repetitions, %d OpenMP threads of %d host cores"
+                      % (sample_ne[0], sample_ne[1], sample_ne[2], reps, threads, cores)}
+
+
+def pcg_rate(ne, levels, dom):
+    from helpers import BC_CANTILEVER, make_hip
+    tps = make_hip(ne, dom, BC_CANTILEVER, None, v0=0.5)
+    g = torch.Generator(device="cuda").manual_seed(88)
+    tps.setElementDensities(torch.rand(tps.numElements(), dtype=torch.float64, device="cuda", generator=g))
+    mg = tps.multigridSolver(levels)
+    f = tps.buildLoadVector_device()
+    x0 = torch.zeros_like(f)
+    mg.preconditionedConjugateGradient_device(x0, f, 1, 1e-4, None, 1, 2, True)       # warm-up (operator build)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    u = mg.preconditionedConjugateGradient_device(x0, f, 100, 1e-4, None, 1, 2, True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"grid": "%dx%dx%d" % tuple(ne), "levels": levels, "iterations": mg.last_iterations,
+            "seconds": dt, "iterations_per_s": mg.last_iterations / dt,
+            "relative_residual": mg.last_relative_residual, "compliance": float((f * u).sum())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, nargs=3, default=[512, 512, 512])
+    ap.add_argument("--no-cg", action="store_true", help="skip the CG-MG side measurements")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py "
+                             "--gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; the voxel-FEM path has no CPU fallback")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    ne = tuple(args.grid)
+
+    if world > 1:
+        from ndr_amd import distributed as vd
+        res = vd.bench_apply(ne, args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps(res))
+        return
+
+    from helpers import make_hip
+    tps = make_hip(ne, ([0, 0, 0], [1, 1, 1]), None, None, v0=0.5)
+    g = torch.Generator(device="cuda").manual_seed(88)
+    tps.setElementDensities(torch.rand(tps.numElements(), dtype=torch.float64, device="cuda", generator=g))
+    u = torch.randn((tps.numNodes(), 3), dtype=torch.float64, device="cuda", generator=g)
+
+    # timed region: exactly K steps between two synchronisations (single rank: no barrier partner)
+    for _ in range(args.warmup):
+        tps.applyK_device(u)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tps.applyK_device(u)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms_per_step = wall / args.steps * 1e3
+    nvox = ne[0] * ne[1] * ne[2]
+
+    kernel_s = time_apply(tps, u, args.steps, 1)
+    ab = algorithmic_bytes(ne)
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "apply_traffic.json")
+    if os.path.exists(prof):
+        with open(prof) as fh:
+            t = json.load(fh)
+        if t.get("grid") == list(ne):
+            traffic = t.get("hbm_bytes_per_launch")
+    roofline = {"bound": "hbm", "achieved": ab / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ab / kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "vfem::k_apply_fast", "algorithmic_bytes_per_launch": ab, "kernel_ms": kernel_s * 1e3}
+    del out
+
+    result = {
+        "metric": "matrix-free SpMV GVoxel/s (Q1 fp64, %dx%dx%d); CG-MG iterations/s reported in cg_mg" % ne,
+        "value": nvox / (wall / args.steps) / 1e9, "unit": "GVoxel/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "K(rho) u on a %dx%dx%d voxel grid, trilinear hexahedra, fp64, seeded U[0,1] densities "
+                               "(SIMP p=3, Emin=1e-4), u ~ N(0,1)" % ne,
+                   "grid": list(ne), "parallelism": "1 GPU"},
+        "roofline": roofline,
+    }
+    if not args.no_cg:
+        del u
+        torch.cuda.empty_cache()
+        cg = []
+        try:
+            cg.append(pcg_rate((256, 256, 256), 5, ([0, 0, 0], [2, 1, 1])))
+            if ne == (512, 512, 512):
+                cg.append(pcg_rate((512, 512, 512), 6, ([0, 0, 0], [2, 1, 1])))
+        except RuntimeError as e:       # reported, never hidden
+            cg.append({"error": str(e)})
+        result["cg_mg"] = cg
+    if not args.no_cpu:
+        result["cpu_baseline"] = cpu_baseline((160, 160, 160))
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

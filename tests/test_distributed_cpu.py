@@ -1,0 +1,91 @@
+"""world_size-2 gloo test of the x-slab decomposition host logic (partition, halo exchange, owned-plane
+reductions).  The per-rank numerics are the CPU oracle here, so the test runs without a GPU; on the GPU box
+the same classes drive libvfem (tests/test_gpu_distributed.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleLocalOps:
+    def __init__(self, part, bbmin, bbmax):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import make_oracle
+        lo, hi = part.local_bbox(bbmin, bbmax)
+        self.sim = make_oracle(part.local_ne, (lo, hi), None)
+
+    def set_densities(self, rho):
+        self.sim.set_densities(rho.numpy())
+
+    def apply(self, u):
+        return torch.from_numpy(self.sim.apply_k(u.numpy()))
+
+
+def _worker(rank, world, port, ne, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ndr_amd import distributed as vd
+    from helpers import make_oracle
+    dom = ([0, 0, 0], [2, 1, 1])
+    part = vd.SlabPartition(ne, world, rank, align=2)
+    ops = OracleLocalOps(part, *dom)
+    ops.set_densities(vd.seeded_slab_density(part))
+    u = vd.seeded_slab_field(part)
+    # poison the ghost planes: the exchange must repair them
+    uv = u.view(part.n_planes, -1)
+    if part.gl:
+        uv[0] = 1e30
+    if part.gr:
+        uv[-1] = -1e30
+    K = vd.DistributedStiffness(part, ops)
+    out = K.apply(u)
+    nrm = K.halo.dot(out, out)
+    # global reference on every rank
+    full = vd.SlabPartition(ne, 1, 0)
+    g = make_oracle(ne, dom, None, vd.seeded_slab_density(full).numpy())
+    ref = g.apply_k(vd.seeded_slab_field(full).numpy()).reshape(ne[0] + 1, -1)
+    mine = out.numpy().reshape(part.n_planes, -1)[part.first_owned:part.last_owned + 1]
+    want = ref[part.x0:part.x1 + 1]
+    err = np.abs(mine - want).max() / np.abs(want).max()
+    q.put((rank, float(err), float(nrm.item()), float((ref * ref).sum())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ne", [(2, (8, 4, 6)), (3, (12, 4, 4))])
+def test_slab_apply_matches_global(world, ne):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ne, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, nrm, ref in res:
+        assert err < 1e-12, (rank, err)
+        assert abs(nrm - ref) < 1e-10 * ref, (rank, nrm, ref)
+
+
+def test_partition_properties():
+    sys.path.insert(0, ROOT)
+    from ndr_amd.distributed import SlabPartition
+    for world in (1, 2, 4, 8):
+        parts = [SlabPartition((512, 256, 256), world, r, align=64) for r in range(world)]
+        assert parts[0].x0 == 0 and parts[-1].x1 == 512
+        for a, b in zip(parts, parts[1:]):
+            assert a.x1 == b.x0 and a.x1 % 64 == 0
+        planes = sum(p.reduction_weight_planes()[1] - p.reduction_weight_planes()[0] for p in parts)
+        assert planes == 513
+    with pytest.raises(RuntimeError):
+        SlabPartition((6, 4, 4), 4, 0, align=2)

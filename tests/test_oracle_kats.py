@@ -1,0 +1,135 @@
+"""Pins the CPU oracle against the reference's own numbers: compliance values the reference logged
+(tests/golden/reference_logs.json, from logs/slurm/gt/*.log), textbook element-stiffness entries, exactness of
+its Gauss rules on monomials (what VoxelFEM/tests/test_tp_gauss_quadrature.cc checks), and structural
+identities of the operators."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from helpers import BC_BRIDGE, BC_CANTILEVER, GOLDEN, MATERIAL, make_oracle, seeded_density  # noqa: E402
+from oracle import vfem_oracle as vo  # noqa: E402
+
+LOGS = json.load(open(os.path.join(GOLDEN, "reference_logs.json")))
+
+
+def test_gauss_rules_exact_on_monomials():
+    for npts in range(1, 6):
+        x, w = vo.gauss_rule(npts)
+        assert abs(w.sum() - 1.0) < 1e-15
+        for deg in range(0, 2 * npts):
+            assert abs(np.sum(w * x ** deg) - 1.0 / (deg + 1)) < 5e-16, (npts, deg)
+    # tensor rule, every monomial x^a y^b z^c up to degree 3 per variable with the 2-point rule per axis
+    for a in range(4):
+        for b in range(4):
+            for c in range(4):
+                v = vo.integrate_tensor(lambda x, y, z: x ** a * y ** b * z ** c, [3, 3, 3])
+                assert abs(v - 1.0 / ((a + 1) * (b + 1) * (c + 1))) < 5e-16
+
+
+def test_k0_textbook_entries_and_null_space():
+    lam, mu = vo.lame(1.0, 0.3, 3)
+    K0 = vo.element_stiffness([1, 1, 1], [1, 1, 1], lam, mu)
+    assert abs(K0[0, 0] - 0.2350427350427350) < 1e-15      # top3d KE(1,1)
+    assert abs(K0[0, 1] - 0.0801282051282051) < 1e-15      # top3d KE(1,2)
+    assert np.abs(K0 - K0.T).max() == 0.0
+    assert np.linalg.matrix_rank(K0) == 18                   # 6 rigid-body modes
+    lam2, mu2 = vo.lame(1.0, 0.3, 2)
+    K2 = vo.element_stiffness([1, 1], [1, 1], lam2, mu2)
+    assert abs(K2[0, 0] - (0.5 - 0.3 / 6) / (1 - 0.09)) < 1e-15   # 99-line top.m KE(1,1), plane stress
+    assert np.linalg.matrix_rank(K2) == 5
+
+
+def _mbb(ne, dom, bc, v0):
+    sim = vo.OracleSim(dom, ne)
+    sim.read_material(MATERIAL)
+    sim.set_uniform_densities(v0)
+    sim.apply_bc_file(bc)
+    sim.E0, sim.Emin, sim.gamma = 1.0, 1e-4, 3.0
+    obj = vo.OracleComplianceObjective(sim)
+    top = vo.OracleProblem(sim, obj, [vo.OracleVolumeConstraint(v0)], [vo.OracleSmoothingFilter(), vo.OracleProjectionFilter()])
+    top.set_vars(sim.rho.copy())
+    return sim, top
+
+
+def test_2d_mbb_log_kat():
+    k = LOGS["2d_mbb_300x100"]
+    sim, top = _mbb([300, 100], ([0, 0], [3, 1]), os.path.join(GOLDEN, "bcs", "2d", "mbb_beam.bc"), 0.3)
+    assert abs(2 * top.evaluate_objective() - k["compliance"][0]) < 5e-7 * k["compliance"][0]
+    oc = vo.OracleOC(top)
+    obj, con, lam = oc.step()
+    assert abs(obj - k["oc_step1"]["objective"]) < 1e-5 * obj              # logged with 6 significant digits
+    assert abs(lam - k["oc_step1"]["lambda"]) < 1e-5 * lam
+    assert abs(con - k["oc_step1"]["constraint"]) < 2e-10
+    assert abs(2 * top.evaluate_objective() - k["compliance"][1]) < 5e-7 * k["compliance"][1]
+
+
+def test_2d_bridge_log_kat():
+    k = LOGS["2d_bridge_250x125"]
+    sim, top = _mbb([250, 125], ([0, 0], [2, 1]), os.path.join(GOLDEN, "bcs", "2d", "bridge.bc"), 0.4)
+    assert abs(2 * top.evaluate_objective() - k["compliance"][0]) < 5e-7 * k["compliance"][0]
+
+
+def test_3d_small_mg_pcg_equals_direct_solve():
+    ne, dom = (16, 8, 8), ([0, 0, 0], [2, 1, 1])
+    for bc in (BC_CANTILEVER, BC_BRIDGE):
+        o = make_oracle(ne, dom, bc, seeded_density(ne, 88))
+        f = o.build_load_vector()
+        ud = o.solve(f)
+        mg = vo.OracleMG(o, 2, nthreads=4)
+        u = mg.pcg(np.zeros_like(f), f, 100, 1e-9, 1, 2, True)
+        assert mg.last_iters < 60
+        assert abs(np.sum(f * u) - np.sum(f * ud)) < 1e-9 * abs(np.sum(f * ud))
+
+
+def test_galerkin_and_adjointness_identities():
+    ne, dom = (8, 4, 4), ([0, 0, 0], [2, 1, 1])
+    o = make_oracle(ne, dom, BC_CANTILEVER, seeded_density(ne, 1))
+    mg = vo.OracleMG(o, 2)
+    mg.update_element_stiffness()
+    rng = np.random.default_rng(0)
+    for l in (0, 1):
+        xc = rng.standard_normal((mg.sims[l + 1].num_nodes, 3))
+        lhs = mg.apply_k(l + 1, xc)
+        rhs = mg.restriction(l, mg.apply_k(l, mg.interpolation(l, xc)))
+        assert np.abs(lhs - rhs).max() < 1e-13 * np.abs(lhs).max()          # K_c = P^T K_f P
+        r = rng.standard_normal((mg.sims[l].num_nodes, 3))
+        assert abs(np.sum(mg.restriction(l, r) * xc) - np.sum(r * mg.interpolation(l, xc))) < 1e-12 * abs(np.sum(r * r))
+
+
+def test_sensitivity_finite_difference():
+    """Numerical_Derivatives.ipynb recipe: centred FD of the compliance vs the analytic gradient."""
+    ne, dom = (8, 4, 4), ([0, 0, 0], [2, 1, 1])
+    rho = 0.3 + 0.4 * seeded_density(ne, 2)
+    o = make_oracle(ne, dom, BC_CANTILEVER, rho)
+    f = o.build_load_vector()
+    u = o.solve(f)
+    g = o.compliance_gradient(u)
+    for e in (0, 17, 100):
+        h = 1e-5
+        vals = []
+        for s in (+1, -1):
+            r2 = rho.copy()
+            r2[e] += s * h
+            o.set_densities(r2)
+            vals.append(0.5 * np.sum(f * o.solve(f)))
+        fd = (vals[0] - vals[1]) / (2 * h)
+        assert abs(fd - g[e]) < 1e-5 * abs(g[e]) + 1e-10
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(os.environ.get("NDR_SLOW", "0") != "1", reason="about 10 minutes of CPU; run with NDR_SLOW=1")
+def test_3d_cantilever_log_kat_full_size():
+    k = LOGS["3d_cantilever_256x128x128"]
+    ne, dom = (256, 128, 128), ([0, 0, 0], [2, 1, 1])
+    o = make_oracle(ne, dom, BC_CANTILEVER, None, v0=0.5)
+    mg = vo.OracleMG(o, 3, nthreads=8)
+    f = o.build_load_vector()
+    u = mg.pcg(np.zeros_like(f), f, 100, 1e-6, 1, 2, True)
+    assert abs(np.sum(f * u) - k["compliance"][0]) < 1e-5 * k["compliance"][0]
