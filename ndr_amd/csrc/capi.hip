@@ -140,6 +140,10 @@ void vfem_sim::update_k0() {
         if (!used[q] && std::fabs(Dfull[q]) > 1e-13 * maxabs) fast_ok = false;
     dK0.alloc(576);
     VFEM_HIP(hipMemcpy(dK0.p, K0, sizeof(K0), hipMemcpyHostToDevice));
+    double tab[36 * 24];
+    vfem::build_gs_table(K0, tab);
+    dGsTab.alloc(36 * 24);
+    VFEM_HIP(hipMemcpy(dGsTab.p, tab, sizeof(tab), hipMemcpyHostToDevice));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -186,7 +190,7 @@ static void mg_apply(vfem_mg *mg, int l, const double *u, const double *b, int r
 static void mg_smooth(vfem_mg *mg, int l, double *u, const double *b, int forward, hipStream_t s) {
     MgLevel &L = mg->lv[l];
     if (L.kind == OP_STENCIL) launch_gs_sweep_stencil(L.d, L.S.p, u, b, L.maskp, forward, s);
-    else launch_gs_sweep_mf(L.d, L.kind, level_K(mg, l), mg->fine->E.p, u, b, L.maskp, forward, s);
+    else launch_gs_sweep_mf(L.d, L.kind, level_K(mg, l), l == 0 ? mg->fine->dGsTab.p : nullptr, mg->fine->E.p, u, b, L.maskp, forward, s);
 }
 
 static void coarsest_solve(vfem_mg *mg, const double *b, double *x, hipStream_t s) {

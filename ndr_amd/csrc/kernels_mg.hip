@@ -87,6 +87,8 @@ __device__ __forceinline__ void mf_node(const Dims &d, const double *__restrict_
     }
 }
 
+int g_gs_variant = 0;   // 0: row-streaming level-0 sweep, 1: plain gather sweep (cross-check)
+
 // component-sequential 3x3 solve of m_smoothNode (MG.hh:254-264)
 __device__ __forceinline__ void gs_solve(const double bms[3], const double M[9], uint8_t mask, bool forward,
                                          double ud[3]) {
@@ -167,14 +169,205 @@ __global__ void __launch_bounds__(256) k_gs_color_mf(Dims d, const double *__res
     for (int c = 0; c < 3; ++c) u[3 * n + c] += ud[c];
 }
 
-void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *E, double *u, const double *b,
-                        const uint8_t *mask, int forward, hipStream_t s) {
+// ------------------------------------------------------------------------------------------
+// Row-streaming colour sweep for the finest level (Ke = E_e K0).
+//
+// The plain kernel above has every lane issue ~190 strided 8-byte loads (colour stride 2 nodes = 48 B), which
+// saturates the address path long before the 576 FMA per node matter.  Here a wave owns 64 colour nodes of one
+// grid row and walks the 9 neighbouring rows (dx,dy): each row segment (129 nodes = 3.1 KB) is fetched with
+// dense 8-byte-per-lane loads, staged in a per-wave LDS buffer, and every lane then reads its z-1,z,z+1
+// neighbours with conflict-free 16-byte LDS reads.  Per incident element an unscaled 3-vector T_e accumulates
+// K0[rows of n] . u_e; the element moduli enter once at the end (S = sum_e E_e T_e, M = sum_e E_e K0_nn).
+// The next row's loads are in flight while the current row is consumed.
+// ------------------------------------------------------------------------------------------
+constexpr int GS_ROWBUF = 392;   // 129 nodes x 3 doubles (+ pad)
+
+typedef double d8_t __attribute__((ext_vector_type(8)));
+
+// 8 consecutive doubles of a wave-uniform table into SGPRs, issued exactly here (the compiler would otherwise
+// hoist all 576 coefficient loads to the top of the kernel and spill them through v_writelane/v_readlane)
+__device__ __forceinline__ d8_t sload8(const double *p, int byte_off) {
+    d8_t r;
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(r) : "s"(p), "s"(byte_off));
+    return r;
+}
+__device__ __forceinline__ void swait3(d8_t &a, d8_t &b, d8_t &c) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c));
+}
+
+// Host-side layout of the coefficient table consumed by k_gs_rows_mf0 (same loop nest as the kernel):
+// 32 half-groups of 24 doubles: [mz][r][c] = K0[(3 ln + r)*24 + 3 lm + c] for the two nodes mz of the element
+// pair, padded to 24; then 4 groups of 24 doubles with the diagonal blocks of local nodes 2g, 2g+1.
+void build_gs_table(const double *K0, double *tab /* 36*24 */) {
+    int hg = 0;
+    for (int r9 = 0; r9 < 9; ++r9) {
+        const int dx = r9 / 3 - 1, dy = r9 % 3 - 1;
+        for (int di = 0; di < 2; ++di)
+            for (int mx = 0; mx < 2; ++mx) {
+                if (di - 1 + mx != dx) continue;
+                for (int dj = 0; dj < 2; ++dj)
+                    for (int my = 0; my < 2; ++my) {
+                        if (dj - 1 + my != dy) continue;
+                        for (int dk = 0; dk < 2; ++dk) {
+                            const int ln = (1 - di) * 4 + (1 - dj) * 2 + (1 - dk);
+                            for (int mz = 0; mz < 2; ++mz) {
+                                const int lm = mx * 4 + my * 2 + mz;
+                                for (int r = 0; r < 3; ++r)
+                                    for (int c = 0; c < 3; ++c)
+                                        tab[hg * 24 + mz * 9 + r * 3 + c] = K0[(3 * ln + r) * 24 + 3 * lm + c];
+                            }
+                            for (int q = 18; q < 24; ++q) tab[hg * 24 + q] = 0.0;
+                            ++hg;
+                        }
+                    }
+            }
+    }
+    for (int g = 0; g < 4; ++g) {
+        for (int h = 0; h < 2; ++h) {
+            const int ln = 2 * g + h;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) tab[(32 + g) * 24 + h * 9 + r * 3 + c] = K0[(3 * ln + r) * 24 + 3 * ln + c];
+        }
+        for (int q = 18; q < 24; ++q) tab[(32 + g) * 24 + q] = 0.0;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__restrict__ tab, const double *__restrict__ E,
+                                                     double *__restrict__ u, const double *__restrict__ b,
+                                                     const uint8_t *__restrict__ mask, int cx, int cy, int cz, int forward) {
+    __shared__ double rowbuf[4][GS_ROWBUF];
+    const int lane = threadIdx.x, wy = threadIdx.y;
+    const int l0 = blockIdx.x * 64;
+    const int x = 2 * blockIdx.z + cx;
+    const int y = 2 * (blockIdx.y * 4 + wy) + cy;
+    if (y >= d.NY || x >= d.NX) return;                 // wave-uniform; no block-level barrier below
+    const int z = 2 * (l0 + lane) + cz;
+    const int zlo = 2 * l0 + cz - 1;                    // first node of the staged segment
+    double *buf = rowbuf[wy];
+    const bool node_ok = z < d.NZ;
+
+    // staged doubles q = lane + 64 s; loads are unconditional with the offset clamped into the row: values
+    // outside the grid only ever meet elements outside the grid, whose modulus is 0
+    int qc[7];
+#pragma unroll
+    for (int s7 = 0; s7 < 7; ++s7) {
+        int q = lane + 64 * s7;
+        const int lo = -3 * zlo > 0 ? -3 * zlo : 0, hi = 3 * (d.NZ - zlo) - 1;
+        q = q < lo ? lo : (q > hi ? hi : q);
+        qc[s7] = q;
+    }
+
+    double T[8][3];
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) { T[sl][0] = 0.0; T[sl][1] = 0.0; T[sl][2] = 0.0; }
+
+    double pre[7];
+    auto issue = [&](int r9) {
+        int gx = x + r9 / 3 - 1, gy = y + r9 % 3 - 1;
+        gx = gx < 0 ? 0 : (gx > d.NX - 1 ? d.NX - 1 : gx);
+        gy = gy < 0 ? 0 : (gy > d.NY - 1 ? d.NY - 1 : gy);
+        const double *rowp = u + 3 * (((long long) gx * d.NY + gy) * d.NZ + zlo);
+#pragma unroll
+        for (int s7 = 0; s7 < 7; ++s7) pre[s7] = rowp[qc[s7]];
+    };
+    issue(0);
+    int hg = 0;
+#pragma unroll
+    for (int r9 = 0; r9 < 9; ++r9) {
+        const int dx = r9 / 3 - 1, dy = r9 % 3 - 1;
+#pragma unroll
+        for (int s7 = 0; s7 < 7; ++s7) {
+            const int q = lane + 64 * s7;
+            if (q < GS_ROWBUF) buf[q] = pre[s7];
+        }
+        if (r9 + 1 < 9) issue(r9 + 1);
+        __builtin_amdgcn_wave_barrier();
+        double u3[3][3];
+#pragma unroll
+        for (int n3 = 0; n3 < 3; ++n3)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) u3[n3][c] = buf[6 * lane + 3 * n3 + c];
+        __builtin_amdgcn_wave_barrier();
+        // elements touching row (dx,dy): (di,mx) with di-1+mx == dx, (dj,my) with dj-1+my == dy
+#pragma unroll
+        for (int di = 0; di < 2; ++di)
+#pragma unroll
+            for (int mx = 0; mx < 2; ++mx) {
+                if (di - 1 + mx != dx) continue;
+#pragma unroll
+                for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+                    for (int my = 0; my < 2; ++my) {
+                        if (dj - 1 + my != dy) continue;
+#pragma unroll
+                        for (int dk = 0; dk < 2; ++dk) {
+                            d8_t k0 = sload8(tab, hg * 192), k1 = sload8(tab, hg * 192 + 64), k2 = sload8(tab, hg * 192 + 128);
+                            ++hg;
+                            swait3(k0, k1, k2);
+                            double kk[24];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) { kk[q] = k0[q]; kk[8 + q] = k1[q]; kk[16 + q] = k2[q]; }
+                            const int sl = di * 4 + dj * 2 + dk;
+#pragma unroll
+                            for (int mz = 0; mz < 2; ++mz) {
+                                const int n3 = dk + mz;            // dz + 1
+#pragma unroll
+                                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                                    for (int c = 0; c < 3; ++c) T[sl][r] = fma(kk[mz * 9 + r * 3 + c], u3[n3][c], T[sl][r]);
+                            }
+                            // pin: the FMAs of this half-group retire before the next coefficient load is issued
+                            asm volatile("" : "+v"(T[sl][0]), "+v"(T[sl][1]), "+v"(T[sl][2]));
+                        }
+                    }
+            }
+    }
+    if (!node_ok) return;
+    double S[3] = {0.0, 0.0, 0.0}, M[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) M[q] = 0.0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        d8_t k0 = sload8(tab, (32 + g) * 192), k1 = sload8(tab, (32 + g) * 192 + 64), k2 = sload8(tab, (32 + g) * 192 + 128);
+        swait3(k0, k1, k2);
+        double kk[24];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { kk[q] = k0[q]; kk[8 + q] = k1[q]; kk[16 + q] = k2[q]; }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ln = 2 * g + h;                    // local index of the node in its element
+            const int sl = 7 - ln;                       // slot (di,dj,dk) = complement of ln
+            const int di = (sl >> 2) & 1, dj = (sl >> 1) & 1, dk = sl & 1;
+            const int ex = x - 1 + di, ey = y - 1 + dj, ez = z - 1 + dk;
+            const bool ok = ex >= 0 && ex < d.nx && ey >= 0 && ey < d.ny && ez >= 0 && ez < d.nz;
+            const double Ee = ok ? E[eidx(d, ex < 0 ? 0 : ex, ey < 0 ? 0 : ey, ez < 0 ? 0 : ez)] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                S[r] = fma(Ee, T[sl][r], S[r]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) M[3 * r + c] = fma(Ee, kk[h * 9 + 3 * r + c], M[3 * r + c]);
+            }
+        }
+        asm volatile("" : "+v"(M[0]), "+v"(M[4]), "+v"(M[8]), "+v"(S[0]));
+    }
+    const long long n = nidx(d, x, y, z);
+    double bms[3], ud[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bms[c] = b[3 * n + c] - S[c];
+    gs_solve(bms, M, mask[n], forward != 0, ud);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) u[3 * n + c] += ud[c];
+}
+
+void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *gs_tab, const double *E, double *u,
+                        const double *b, const uint8_t *mask, int forward, hipStream_t s) {
     for (int ci = 0; ci < 8; ++ci) {
         const int lni = forward ? ci : 7 - ci;
         const int cx = (lni >> 2) & 1, cy = (lni >> 1) & 1, cz = lni & 1;
         const int cntx = (d.NX - 1 - cx) / 2 + 1, cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
         dim3 blk(64, 4, 1), grd((cntz + 63) / 64, (cnty + 3) / 4, cntx);
-        if (kind == OP_MF0) k_gs_color_mf<0><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
+        if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab) k_gs_rows_mf0<<<grd, blk, 0, s>>>(d, gs_tab, E, u, b, mask, cx, cy, cz, forward);
+        else if (kind == OP_MF0) k_gs_color_mf<0><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
         else                k_gs_color_mf<1><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
     }
     VFEM_HIP(hipGetLastError());

@@ -76,8 +76,9 @@ void launch_apply_stencil(const Dims &d, const double *S, const double *u, const
 void launch_apply_fast(const Dims &d, const double *Dm_host, const double *E, const double *u, const double *b,
                        const uint8_t *mask, int mode, double *out, hipStream_t s);
 
-void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *E, double *u, const double *b,
-                        const uint8_t *mask, int forward, hipStream_t s);
+void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *gs_tab, const double *E, double *u,
+                        const double *b, const uint8_t *mask, int forward, hipStream_t s);
+void build_gs_table(const double *K0, double *tab /* 36*24 doubles */);
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
                              int forward, hipStream_t s);
 
@@ -121,7 +122,7 @@ struct vfem_sim {
     double K0[576];                             // host copy, row-major
     double Dm[64];                              // symmetry-reduced (mode-space) coefficients, host
     bool   fast_ok = false;                     // mode-space sparsity pattern verified for this K0
-    vfem::DevBuf<double> dK0, rho, E, dvals, loads;
+    vfem::DevBuf<double> dK0, dGsTab, rho, E, dvals, loads;
     vfem::DevBuf<uint8_t> dmask;
     std::vector<uint8_t> hmask;                 // host copy of the Dirichlet mask
     std::vector<double> hvals;
