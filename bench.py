@@ -93,6 +93,31 @@ def pcg_rate(ne, levels, dom):
             "relative_residual": mg.last_relative_residual, "compliance": float((f * u).sum())}
 
 
+def mlp_rate(side=(512, 256, 256), es=1024, nn_=512, nl=4, sigma=4.0, reps=3):
+    """MLP-forward voxels/s at the run.md sizes (2048 -> 512 -> 512 -> 512 -> 1), random-init weights, whole grid."""
+    from ndr_amd.mlp import MLP
+    rng = np.random.default_rng(88)
+    B = (rng.standard_normal((es, 3)) * sigma).astype(np.float32)
+    Ws = [rng.standard_normal((nn_, 2 * es)).astype(np.float32) / np.sqrt(2 * es)]
+    Ws += [rng.standard_normal((nn_, nn_)).astype(np.float32) / np.sqrt(nn_) for _ in range(nl - 2)]
+    Ws += [rng.standard_normal((1, nn_)).astype(np.float32) / np.sqrt(nn_)]
+    bs = [rng.standard_normal(nn_).astype(np.float32) * 0.1 for _ in range(nl - 1)] + [np.array([0.4], np.float32)]
+    m = MLP(3, 1, nn_, nl, es, sigma)
+    m.load_arrays(B, Ws, bs)
+    m.forward_grid(side)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m.forward_grid(side)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    nv = int(np.prod(side))
+    flop = 2.0 * (3 * es + 2 * es * nn_ + (nl - 2) * nn_ * nn_ + nn_) * nv          # SURVEY 8(d) M3
+    return {"grid": "%dx%dx%d" % tuple(side), "network": "%d->%d x%d->1" % (2 * es, nn_, nl - 1), "operands": "f16, f32 accumulate",
+            "seconds": dt, "voxels_per_s": nv / dt, "tflops": flop / dt / 1e12,
+            "mfma_frac_of_2.5PF": flop / dt / 2.5e15}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +201,10 @@ def main():
         except RuntimeError as e:       # reported, never hidden
             cg.append({"error": str(e)})
         result["cg_mg"] = cg
+        try:
+            result["mlp_forward"] = mlp_rate()
+        except RuntimeError as e:
+            result["mlp_forward"] = {"error": str(e)}
     if not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline((160, 160, 160))
     print(json.dumps(result))

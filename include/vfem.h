@@ -123,6 +123,23 @@ int vfem_mg_pcg(vfem_mg *mg, double *x, const double *b, int max_iter, double to
                 vfem_residual_cb residual_cb, void *cb_user,
                 int *iterations_out_host, double *relres_out_host, void *stream);
 
+/* ---- Fourier-feature MLP density field: networks.MLP (networks.py:128-185), out_features = 1 ----
+ * n_layers counts Linear layers as the reference does: Linear(2 es, nn), (n_layers - 2) x Linear(nn, nn), Linear(nn, 1).
+ * Weights are handed over as fp32 HOST arrays in torch layout ([out][in] row-major) and converted once:
+ *   B [es][3] (MLP.B, already multiplied by `scale`), W_first [nn][2 es], W_hidden [(n_layers-2)][nn][nn],
+ *   biases [(n_layers-1)][nn] (first layer, then hidden layers), w_out [nn], b_out.
+ * Requirements of the MFMA tiling: es % 32 == 0, nn % 32 == 0, nn <= 512. */
+int vfem_mlp_create(vfem_mlp **out, int embedding_size, int n_neurons, int n_layers, int sigmoid_output);
+int vfem_mlp_destroy(vfem_mlp *mlp);
+int vfem_mlp_load_weights(vfem_mlp *mlp, const float *B_host, const float *W_first_host, const float *W_hidden_host,
+                          const float *biases_host, const float *w_out_host, float b_out);
+/* forward on an explicit coordinate list [nvox][3] fp32 (device); either output pointer may be NULL */
+int vfem_mlp_forward(vfem_mlp *mlp, const float *coords, int64_t nvox, float *out_f32, double *out_f64, void *stream);
+/* forward on the regular grid of utils.get_mgrid (utils.py:35-53): n[d] points linspace(lo[d], hi[d]) incl. both ends,
+ * flattened z-fastest = the solver's element order (train_xdg.py:245-247, 287) */
+int vfem_mlp_forward_grid(vfem_mlp *mlp, const int64_t n_host[3], const double lo_host[3], const double hi_host[3],
+                          float *out_f32, double *out_f64, void *stream);
+
 /* ---- timers: BENCHMARK_* registry (MeshFEM GlobalBenchmark.hh / Timer.hh; VoxelFEM.cc:245-255) ---- */
 int vfem_timers_reset(void);
 int vfem_timers_report(char *buf_host, size_t buf_len);

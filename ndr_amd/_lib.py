@@ -62,6 +62,12 @@ SIGNATURES = {
     "vfem_mg_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vfem_mg_pcg": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_int, c_int,
                             RESIDUAL_CB, c_void_p, POINTER(c_int), POINTER(c_double), c_void_p]),
+    "vfem_mlp_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int]),
+    "vfem_mlp_destroy": (c_int, [c_void_p]),
+    "vfem_mlp_load_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float]),
+    "vfem_mlp_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "vfem_mlp_forward_grid": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double), c_void_p,
+                                      c_void_p, c_void_p]),
     "vfem_timers_reset": (c_int, []),
     "vfem_timers_report": (c_int, [c_char_p, c_size_t]),
 }

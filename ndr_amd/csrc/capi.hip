@@ -657,6 +657,78 @@ int vfem_mg_pcg(vfem_mg *mg, double *x, const double *b, int max_iter, double to
     VFEM_CATCH
 }
 
+// ---- MLP ----
+int vfem_mlp_create(vfem_mlp **out, int es, int nn, int n_layers, int sigmoid) {
+    VFEM_TRY
+    if (es <= 0 || es % 32 != 0) throw Error("embedding_size must be a positive multiple of 32");
+    if (nn <= 0 || nn % 32 != 0 || nn > 512) throw Error("n_neurons must be a multiple of 32, at most 512");
+    if (n_layers < 2) throw Error("n_layers must be at least 2");
+    std::unique_ptr<vfem_mlp> m(new vfem_mlp);
+    m->es = es; m->nn = nn; m->n_layers = n_layers; m->sigmoid = sigmoid;
+    *out = m.release();
+    VFEM_CATCH
+}
+int vfem_mlp_destroy(vfem_mlp *mlp) { VFEM_TRY delete mlp; VFEM_CATCH }
+int vfem_mlp_load_weights(vfem_mlp *m, const float *B, const float *W1, const float *Wh, const float *biases,
+                          const float *wout, float bout) {
+    VFEM_TRY
+    const int nh = m->n_layers - 2;
+    auto up = [](DevBuf<float> &d, const float *h, size_t n) {
+        d.alloc(n);
+        if (n) VFEM_HIP(hipMemcpy(d.p, h, n * sizeof(float), hipMemcpyHostToDevice));
+    };
+    auto up16 = [](DevBuf<uint16_t> &d, const float *h, size_t n) {
+        d.alloc(n);
+        if (!n) return;
+        DevBuf<float> tmp; tmp.alloc(n);
+        VFEM_HIP(hipMemcpy(tmp.p, h, n * sizeof(float), hipMemcpyHostToDevice));
+        launch_f32_to_f16((long long) n, tmp.p, d.p, nullptr);
+        VFEM_HIP(hipDeviceSynchronize());
+    };
+    up(m->B, B, (size_t) m->es * 3);
+    up16(m->W1, W1, (size_t) m->nn * 2 * m->es);
+    up16(m->Wh, Wh, (size_t) nh * m->nn * m->nn);
+    up(m->bias, biases, (size_t) (nh + 1) * m->nn);
+    up(m->wout, wout, (size_t) m->nn);
+    m->bout = bout;
+    m->loaded = true;
+    VFEM_CATCH
+}
+}  // extern "C" (reopened below)
+#include "mlp_args.h"
+static vfem::MlpArgs mlp_base_args(const vfem_mlp *m) {
+    vfem::MlpArgs a{};
+    a.es = m->es; a.nn = m->nn; a.n_hidden = m->n_layers - 2; a.sigmoid = m->sigmoid;
+    a.B = m->B.p; a.W1 = m->W1.p; a.Wh = m->Wh.p; a.bias = m->bias.p; a.wout = m->wout.p; a.bout = m->bout;
+    return a;
+}
+extern "C" {
+int vfem_mlp_forward(vfem_mlp *m, const float *coords, int64_t nvox, float *o32, double *o64, void *stream) {
+    VFEM_TRY
+    if (!m->loaded) throw Error("vfem_mlp_load_weights has not been called");
+    MlpArgs a = mlp_base_args(m);
+    a.coords = coords; a.nvox = nvox; a.out32 = o32; a.out64 = o64;
+    launch_mlp_forward(a, S(stream));
+    VFEM_CATCH
+}
+int vfem_mlp_forward_grid(vfem_mlp *m, const int64_t n[3], const double lo[3], const double hi[3], float *o32, double *o64,
+                          void *stream) {
+    VFEM_TRY
+    if (!m->loaded) throw Error("vfem_mlp_load_weights has not been called");
+    MlpArgs a = mlp_base_args(m);
+    a.coords = nullptr;
+    a.nvox = 1;
+    for (int dd = 0; dd < 3; ++dd) {
+        a.gn[dd] = (int) n[dd];
+        a.glo[dd] = (float) lo[dd];
+        a.gstep[dd] = n[dd] > 1 ? (float) ((hi[dd] - lo[dd]) / (double) (n[dd] - 1)) : 0.f;
+        a.nvox *= n[dd];
+    }
+    a.out32 = o32; a.out64 = o64;
+    launch_mlp_forward(a, S(stream));
+    VFEM_CATCH
+}
+
 int vfem_timers_reset(void) {
     std::lock_guard<std::mutex> lk(vfem::g_timer_mu);
     vfem::g_timers.clear();

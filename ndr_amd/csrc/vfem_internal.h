@@ -109,6 +109,10 @@ void launch_pcg_step(long long n, double *x, double *r, const double *dv, const 
                      hipStream_t s);
 void launch_shift_scalar(double *sc, hipStream_t s);   // sc[1] = sc[0]
 
+struct MlpArgs;
+void launch_mlp_forward(const MlpArgs &a, hipStream_t s);
+void launch_f32_to_f16(long long n, const float *in, void *out, hipStream_t s);
+
 }  // namespace vfem
 
 // ------------------------------------------------------------------------------------------
@@ -152,4 +156,12 @@ struct vfem_mg {
     bool operators_valid = false;
     void *rocblas = nullptr;                    // rocblas_handle for the coarsest factorisation
     vfem::DevBuf<int> info;
+};
+
+struct vfem_mlp {
+    int es = 0, nn = 0, n_layers = 0, sigmoid = 0;
+    vfem::DevBuf<float> B, bias, wout;
+    vfem::DevBuf<uint16_t> W1, Wh;               // fp16 bit patterns
+    float bout = 0.f;
+    bool loaded = false;
 };
