@@ -143,7 +143,7 @@ def main():
 
     if world > 1:
         from ndr_amd import distributed as vd
-        res = vd.bench_apply(ne, args.steps, args.warmup)
+        res = vd.bench_apply(ne, args.steps, args.warmup, with_cg=not args.no_cg)
         if rank == 0:
             print(json.dumps(res))
         return

@@ -85,6 +85,32 @@ int vfem_compliance(const vfem_sim *sim, const double *f, const double *u, doubl
 /* ---- multigrid: tps.multigridSolver(numCoarseningLevels), MG.hh:22-90 ---- */
 int vfem_mg_create(vfem_mg **out, vfem_sim *fine, int num_coarsening_levels);
 int vfem_mg_destroy(vfem_mg *mg);
+
+/* ---- x-slab decomposition support (one process per GPU).  The reference is single-process; these entry
+ * points let a host-side driver (ndr_amd/distributed.py) run the same V-cycle / PCG control flow (MG.hh:447-732) over
+ * slabs, with one ghost node plane per interior side at every level.
+ *   - vfem_sim_set_next_element_padding: the NEXT vfem_sim_create allocates its element arrays (densities, moduli) with
+ *     extra_lo / extra_hi additional x-layers in front of / behind the node grid (so that the Galerkin operators of the
+ *     ghost elements of coarser levels can be built locally); vfem_sim_set_densities then expects all stored layers.
+ *   - vfem_mg_create_slab: local hierarchy with explicit per-level extents and Dirichlet masks (masks_host[l] has the
+ *     level's local numNodes bytes); no coarsest-level solver.
+ *   - vfem_mg_create_partial: hierarchy on a whole (replicated) grid whose levels < first_active_level are never cycled.
+ *   - vfem_mg_smooth_colors: colours [first, first+count) of one sweep (halo exchanges happen between half sweeps).
+ *   - vfem_mg_cycle_from_level: V-cycle (x in/out) or full-multigrid cycle (x out) of the residual system at `level`. */
+typedef struct {
+    int64_t nx;               /* local elements in x (owned layers + one ghost layer per interior side) */
+    int64_t elem_extra_lo;    /* extra element x-layers stored in front of the node grid at this level */
+    int64_t elem_extra_hi;
+    int64_t xshift;           /* level >= 1: (finer level's local plane of this level's local plane 0) = xshift (0 or -1) */
+    int32_t xparity;          /* global x-parity of local node plane 0 (Gauss-Seidel colours follow the global grid) */
+} vfem_slab_level;
+int vfem_sim_set_next_element_padding(int64_t extra_lo, int64_t extra_hi);
+int64_t vfem_sim_num_stored_elements(const vfem_sim *sim);
+int vfem_mg_create_slab(vfem_mg **out, vfem_sim *fine_local, int n_levels, const vfem_slab_level *levels_host,
+                        const uint8_t *const *masks_host);
+int vfem_mg_create_partial(vfem_mg **out, vfem_sim *fine, int num_coarsening_levels, int first_active_level);
+int vfem_mg_smooth_colors(vfem_mg *mg, int level, double *u, const double *b, int forward, int first, int count, void *stream);
+int vfem_mg_cycle_from_level(vfem_mg *mg, int level, double *x, const double *b, int num_smoothing_steps, int fmg, void *stream);
 int vfem_mg_num_levels(const vfem_mg *mg);                       /* = numCoarseningLevels + 1 */
 int vfem_mg_level_dims(const vfem_mg *mg, int level, int64_t nelems_host[3]);
 int64_t vfem_mg_level_num_nodes(const vfem_mg *mg, int level);

@@ -45,6 +45,12 @@ SIGNATURES = {
     "vfem_compliance": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double), c_void_p]),
     "vfem_mg_create": (c_int, [POINTER(c_void_p), c_void_p, c_int]),
     "vfem_mg_destroy": (c_int, [c_void_p]),
+    "vfem_sim_set_next_element_padding": (c_int, [c_int64, c_int64]),
+    "vfem_sim_num_stored_elements": (c_int64, [c_void_p]),
+    "vfem_mg_create_slab": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p, POINTER(c_void_p)]),
+    "vfem_mg_create_partial": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
+    "vfem_mg_smooth_colors": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "vfem_mg_cycle_from_level": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "vfem_mg_num_levels": (c_int, [c_void_p]),
     "vfem_mg_level_dims": (c_int, [c_void_p, c_int, POINTER(c_int64)]),
     "vfem_mg_level_num_nodes": (c_int64, [c_void_p, c_int]),

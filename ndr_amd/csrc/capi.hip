@@ -178,19 +178,27 @@ static void coarsen_dirichlet(const Dims &f, const std::vector<uint8_t> &fm, con
 static const double *level_K(const vfem_mg *mg, int l) {
     return l == 0 ? mg->fine->dK0.p : mg->cK0.p;
 }
+// fine-moduli pointer seen by the matrix-free kernels of level l (0 or 1): element (ex,ey,ez) of the level's node grid
+// must land on the right entry of the fine array, which may hold extra x-layers (slab decomposition)
+static const double *level_E(const vfem_mg *mg, int l) {
+    const vfem_sim *sim = mg->fine;
+    if (l == 0) return sim->Ep();
+    return sim->E.p + 2 * mg->lv[1].ex_lo * (long long) sim->d.ny * sim->d.nz;
+}
 
 static void mg_apply(vfem_mg *mg, int l, const double *u, const double *b, int res, double *out, hipStream_t s) {
     MgLevel &L = mg->lv[l];
     if (L.kind == OP_STENCIL) launch_apply_stencil(L.d, L.S.p, u, b, L.maskp, res, out, s);
     else if (L.kind == OP_MF0 && mg->fine->fast_ok)
-        launch_apply_fast(L.d, mg->fine->Dm, mg->fine->E.p, u, b, L.maskp, res, out, s);
-    else launch_apply_gather(L.d, L.kind, level_K(mg, l), mg->fine->E.p, u, b, L.maskp, res, out, s);
+        launch_apply_fast(L.d, mg->fine->Dm, level_E(mg, 0), u, b, L.maskp, res, out, s);
+    else launch_apply_gather(L.d, L.kind, level_K(mg, l), level_E(mg, l), u, b, L.maskp, res, out, s);
 }
 
-static void mg_smooth(vfem_mg *mg, int l, double *u, const double *b, int forward, hipStream_t s) {
+static void mg_smooth(vfem_mg *mg, int l, double *u, const double *b, int forward, hipStream_t s, int first = 0, int count = 8) {
     MgLevel &L = mg->lv[l];
-    if (L.kind == OP_STENCIL) launch_gs_sweep_stencil(L.d, L.S.p, u, b, L.maskp, forward, s);
-    else launch_gs_sweep_mf(L.d, L.kind, level_K(mg, l), l == 0 ? mg->fine->dGsTab.p : nullptr, mg->fine->E.p, u, b, L.maskp, forward, s);
+    if (L.kind == OP_STENCIL) launch_gs_sweep_stencil(L.d, L.S.p, u, b, L.maskp, forward, L.xparity, first, count, s);
+    else launch_gs_sweep_mf(L.d, L.kind, level_K(mg, l), l == 0 ? mg->fine->dGsTab.p : nullptr, level_E(mg, l), u, b, L.maskp,
+                            forward, L.xparity, first, count, s);
 }
 
 static void coarsest_solve(vfem_mg *mg, const double *b, double *x, hipStream_t s) {
@@ -201,19 +209,21 @@ static void coarsest_solve(vfem_mg *mg, const double *b, double *x, hipStream_t 
 static void update_operators(vfem_mg *mg, hipStream_t s) {
     ScopedTimer tm("updateElementStiffnessMatrices");
     vfem_sim *sim = mg->fine;
-    const int L = mg->L;
+    const int L = mg->slab ? mg->L - 1 : mg->L;      // the last level of a slab hierarchy only serves the grid transfers
     // Galerkin element matrices for levels >= 2 (level 1 stays virtual: sum_f E_f cK0[f])
+    // (element arrays cover lv.da = node grid + extra x-layers; array origins halve exactly from level to level)
     for (int l = 2; l <= L; ++l) {
         MgLevel &lv = mg->lv[l];
-        lv.Ke.alloc((size_t) lv.d.ne * 576);
-        if (l == 2) launch_coarsen_ke(lv.d, 1, mg->cK0.p, sim->E.p, nullptr, lv.Ke.p, s);
-        else        launch_coarsen_ke(lv.d, 2, nullptr, nullptr, mg->lv[l - 1].Ke.p, lv.Ke.p, s);
+        lv.Ke.alloc((size_t) lv.da.ne * 576);
+        if (l == 2) launch_coarsen_ke(lv.da, 1, mg->cK0.p, sim->E.p, nullptr, lv.Ke.p, s);
+        else        launch_coarsen_ke(lv.da, 2, nullptr, nullptr, mg->lv[l - 1].Ke.p, lv.Ke.p, s);
     }
-    for (int l = 2; l <= L; ++l) {
+    for (int l = std::max(2, mg->first_active); l <= L; ++l) {
         MgLevel &lv = mg->lv[l];
         lv.S.alloc((size_t) lv.d.nn * 27 * 9);
-        launch_stencil_from_ke(lv.d, lv.Ke.p, lv.S.p, s);
+        launch_stencil_from_ke(lv.d, lv.Ke.p + lv.ex_lo * (long long) lv.d.ny * lv.d.nz * 576, lv.S.p, s);
     }
+    if (mg->slab) { mg->operators_valid = true; return; }       // the coarse levels live in the replicated hierarchy
     // coarsest level: dense inverse
     MgLevel &cl = mg->lv[L];
     const long long n = 3 * cl.d.nn;
@@ -223,7 +233,7 @@ static void update_operators(vfem_mg *mg, hipStream_t s) {
     DevBuf<double> tmpS;
     if (L < 2) {
         tmpS.alloc((size_t) cl.d.nn * 27 * 9);
-        launch_stencil_from_mf(cl.d, L == 0 ? OP_MF0 : OP_MF1, level_K(mg, L), sim->E.p, tmpS.p, s);
+        launch_stencil_from_mf(cl.d, L == 0 ? OP_MF0 : OP_MF1, level_K(mg, L), level_E(mg, L), tmpS.p, s);
         Sc = tmpS.p;
     }
     mg->Ainv.alloc((size_t) n * n);
@@ -258,10 +268,10 @@ static void vcycle(vfem_mg *mg, int l, int nsmooth, bool residual_system, hipStr
     launch_enforce_dirichlet(L.d.nn, L.maskp, l == 0 ? mg->fine->dvals.p : nullptr, L.x.p, residual_system ? 1 : 0, s);
     for (int i = 0; i < nsmooth; ++i) mg_smooth(mg, l, L.x.p, L.b.p, 1, s);
     mg_apply(mg, l, L.x.p, L.b.p, 1, L.r.p, s);                       // computeResidual (Dirichlet zeroed)
-    launch_restrict(C.d, L.r.p, C.b.p, s);
+    launch_restrict(C.d, L.d.NX, C.xshift, L.r.p, C.b.p, s);
     C.x.zero(s);
     vcycle(mg, l + 1, nsmooth, true, s);
-    launch_prolong(C.d, C.x.p, L.x.p, 1, s);
+    launch_prolong(C.d, L.d.NX, C.xshift, C.x.p, L.x.p, 1, s);
     for (int i = 0; i < nsmooth; ++i) mg_smooth(mg, l, L.x.p, L.b.p, mg->symmetric_gs ? 0 : 1, s);
 }
 
@@ -270,9 +280,9 @@ static void full_multigrid(vfem_mg *mg, int l, int nsmooth, bool residual_system
     MgLevel &L = mg->lv[l];
     if (l == mg->L) { coarsest_solve(mg, L.b.p, L.x.p, s); return; }
     MgLevel &C = mg->lv[l + 1];
-    launch_restrict(C.d, L.b.p, C.b.p, s);
+    launch_restrict(C.d, L.d.NX, C.xshift, L.b.p, C.b.p, s);
     full_multigrid(mg, l + 1, nsmooth, residual_system, s);
-    launch_prolong(C.d, C.x.p, L.x.p, 0, s);
+    launch_prolong(C.d, L.d.NX, C.xshift, C.x.p, L.x.p, 0, s);
     vcycle(mg, l, nsmooth, residual_system, s);
 }
 
@@ -324,6 +334,12 @@ int vfem_memset(void *dst, int value, size_t bytes, void *stream) {
 int vfem_stream_sync(void *stream) { VFEM_TRY VFEM_HIP(hipStreamSynchronize(S(stream))); VFEM_CATCH }
 
 // ---- simulator ----
+static thread_local long long g_next_sim_extra[2] = {0, 0};
+int vfem_sim_set_next_element_padding(int64_t extra_lo, int64_t extra_hi) {
+    if (extra_lo < 0 || extra_hi < 0) { vfem::set_error("negative padding"); return 1; }
+    g_next_sim_extra[0] = extra_lo; g_next_sim_extra[1] = extra_hi;
+    return 0;
+}
 int vfem_sim_create(vfem_sim **out, const double bbmin[3], const double bbmax[3], const int64_t ne[3]) {
     VFEM_TRY
     for (int dd = 0; dd < 3; ++dd)
@@ -336,9 +352,11 @@ int vfem_sim_create(vfem_sim **out, const double bbmin[3], const double bbmax[3]
         if (!(sim->h[dd] > 0)) throw Error("empty domain bounding box");
     }
     sim->update_k0();
-    sim->rho.alloc((size_t) sim->d.ne);   sim->rho.zero(nullptr);
-    sim->E.alloc((size_t) sim->d.ne);
-    launch_simp(sim->d.ne, sim->rho.p, sim->E0, sim->Emin, sim->gamma, sim->E.p, nullptr);
+    sim->ex_lo = g_next_sim_extra[0]; sim->ex_hi = g_next_sim_extra[1];
+    g_next_sim_extra[0] = g_next_sim_extra[1] = 0;
+    sim->rho.alloc((size_t) sim->n_store());   sim->rho.zero(nullptr);
+    sim->E.alloc((size_t) sim->n_store());
+    launch_simp(sim->n_store(), sim->rho.p, sim->E0, sim->Emin, sim->gamma, sim->E.p, nullptr);
     sim->dmask.alloc((size_t) sim->d.nn); sim->dmask.zero(nullptr);
     sim->dvals.alloc((size_t) sim->d.nn * 3); sim->dvals.zero(nullptr);
     sim->loads.alloc((size_t) sim->d.nn * 3); sim->loads.zero(nullptr);
@@ -351,6 +369,7 @@ int vfem_sim_create(vfem_sim **out, const double bbmin[3], const double bbmax[3]
 int vfem_sim_destroy(vfem_sim *sim) { VFEM_TRY delete sim; VFEM_CATCH }
 int64_t vfem_sim_num_nodes(const vfem_sim *sim) { return sim->d.nn; }
 int64_t vfem_sim_num_elements(const vfem_sim *sim) { return sim->d.ne; }
+int64_t vfem_sim_num_stored_elements(const vfem_sim *sim) { return sim->n_store(); }
 
 int vfem_sim_set_isotropic(vfem_sim *sim, double young, double poisson) {
     VFEM_TRY
@@ -362,7 +381,7 @@ int vfem_sim_set_isotropic(vfem_sim *sim, double young, double poisson) {
 int vfem_sim_set_simp(vfem_sim *sim, double E0, double Emin, double gamma) {
     VFEM_TRY
     sim->E0 = E0; sim->Emin = Emin; sim->gamma = gamma;
-    launch_simp(sim->d.ne, sim->rho.p, E0, Emin, gamma, sim->E.p, nullptr);
+    launch_simp(sim->n_store(), sim->rho.p, E0, Emin, gamma, sim->E.p, nullptr);
     VFEM_HIP(hipDeviceSynchronize());
     VFEM_CATCH
 }
@@ -395,34 +414,34 @@ int vfem_sim_build_load_vector(const vfem_sim *sim, double *f, void *stream) {
 }
 int vfem_sim_set_densities(vfem_sim *sim, const double *rho, void *stream) {
     VFEM_TRY
-    VFEM_HIP(hipMemcpyAsync(sim->rho.p, rho, (size_t) sim->d.ne * sizeof(double), hipMemcpyDeviceToDevice, S(stream)));
-    launch_simp(sim->d.ne, sim->rho.p, sim->E0, sim->Emin, sim->gamma, sim->E.p, S(stream));
+    VFEM_HIP(hipMemcpyAsync(sim->rho.p, rho, (size_t) sim->n_store() * sizeof(double), hipMemcpyDeviceToDevice, S(stream)));
+    launch_simp(sim->n_store(), sim->rho.p, sim->E0, sim->Emin, sim->gamma, sim->E.p, S(stream));
     VFEM_CATCH
 }
 int vfem_sim_set_uniform_density(vfem_sim *sim, double rho, void *stream) {
     VFEM_TRY
     if (rho > 1.0 || rho < 0.0)
         throw Error("Density value (" + std::to_string(rho) + ") has to be in between 0 and 1");   // TPS.hh:457-458
-    launch_fill(sim->d.ne, rho, sim->rho.p, S(stream));
-    launch_simp(sim->d.ne, sim->rho.p, sim->E0, sim->Emin, sim->gamma, sim->E.p, S(stream));
+    launch_fill(sim->n_store(), rho, sim->rho.p, S(stream));
+    launch_simp(sim->n_store(), sim->rho.p, sim->E0, sim->Emin, sim->gamma, sim->E.p, S(stream));
     VFEM_CATCH
 }
 int vfem_sim_get_densities(const vfem_sim *sim, double *rho, void *stream) {
     VFEM_TRY
-    VFEM_HIP(hipMemcpyAsync(rho, sim->rho.p, (size_t) sim->d.ne * sizeof(double), hipMemcpyDeviceToDevice, S(stream)));
+    VFEM_HIP(hipMemcpyAsync(rho, sim->rho.p, (size_t) sim->n_store() * sizeof(double), hipMemcpyDeviceToDevice, S(stream)));
     VFEM_CATCH
 }
 int vfem_sim_apply_k(const vfem_sim *sim, const double *u, double *out, int variant, void *stream) {
     VFEM_TRY
     ScopedTimer tm("applyK");
     if (variant != 1 && sim->fast_ok)
-        launch_apply_fast(sim->d, sim->Dm, sim->E.p, u, nullptr, nullptr, variant == 0 ? 0 : 3, out, S(stream));
-    else launch_apply_gather(sim->d, OP_MF0, sim->dK0.p, sim->E.p, u, nullptr, nullptr, 0, out, S(stream));
+        launch_apply_fast(sim->d, sim->Dm, sim->Ep(), u, nullptr, nullptr, variant == 0 ? 0 : 3, out, S(stream));
+    else launch_apply_gather(sim->d, OP_MF0, sim->dK0.p, sim->Ep(), u, nullptr, nullptr, 0, out, S(stream));
     VFEM_CATCH
 }
 int vfem_sim_compliance_gradient(const vfem_sim *sim, const double *u, double *g, void *stream) {
     VFEM_TRY
-    launch_compliance_gradient(sim->d, sim->dK0.p, sim->rho.p, sim->E0, sim->Emin, sim->gamma, u, g, S(stream));
+    launch_compliance_gradient(sim->d, sim->dK0.p, sim->rhop(), sim->E0, sim->Emin, sim->gamma, u, g, S(stream));
     VFEM_CATCH
 }
 int vfem_compliance(const vfem_sim *sim, const double *f, const double *u, double *value_host, void *stream) {
@@ -437,11 +456,60 @@ int vfem_compliance(const vfem_sim *sim, const double *f, const double *u, doubl
 }
 
 // ---- multigrid ----
-int vfem_mg_create(vfem_mg **out, vfem_sim *fine, int L) {
+static void finish_mg_create(vfem_mg *mg) {
+    vfem_sim *fine = mg->fine;
+    // coarsened reference matrices cK0[g] = I_g^T K0 I_g (MG.hh:644-648), children g = 4gx+2gy+gz
+    std::vector<double> c(8 * 576, 0.0), T(576);
+    for (int g = 0; g < 8; ++g) {
+        double ph[8][8];
+        for (int fn = 0; fn < 8; ++fn)
+            for (int cn = 0; cn < 8; ++cn) {
+                double v = 1.0;
+                for (int dd = 0; dd < 3; ++dd) {
+                    const int sh = 2 - dd;
+                    const double p = 0.5 * ((fn >> sh) & 1) + 0.5 * ((g >> sh) & 1);
+                    v *= ((cn >> sh) & 1) ? p : (1.0 - p);
+                }
+                ph[fn][cn] = v;
+            }
+        for (int a = 0; a < 24; ++a)
+            for (int j = 0; j < 8; ++j)
+                for (int dd = 0; dd < 3; ++dd) {
+                    double v = 0.0;
+                    for (int i = 0; i < 8; ++i) v += fine->K0[a * 24 + 3 * i + dd] * ph[i][j];
+                    T[a * 24 + 3 * j + dd] = v;
+                }
+        for (int j = 0; j < 8; ++j)
+            for (int cc = 0; cc < 3; ++cc)
+                for (int b = 0; b < 24; ++b) {
+                    double v = 0.0;
+                    for (int i = 0; i < 8; ++i) v += ph[i][j] * T[(3 * i + cc) * 24 + b];
+                    c[(size_t) g * 576 + (3 * j + cc) * 24 + b] = v;
+                }
+    }
+    mg->cK0.alloc(8 * 576);
+    VFEM_HIP(hipMemcpy(mg->cK0.p, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice));
+    for (int l = mg->first_active; l <= mg->L; ++l) {
+        MgLevel &lv = mg->lv[(size_t) l];
+        lv.x.alloc((size_t) lv.d.nn * 3); lv.b.alloc((size_t) lv.d.nn * 3); lv.r.alloc((size_t) lv.d.nn * 3);
+        lv.x.zero(nullptr); lv.b.zero(nullptr); lv.r.zero(nullptr);
+    }
+    if (mg->first_active == 0 && !mg->slab) {
+        const size_t n3 = (size_t) fine->d.nn * 3;
+        mg->pr.alloc(n3); mg->pd.alloc(n3); mg->pAd.alloc(n3); mg->ps.alloc(n3);
+    }
+    mg->scal.alloc(16); mg->scratch.alloc(2048);
+    mg->scal.zero(nullptr);
+    VFEM_HIP(hipDeviceSynchronize());
+}
+
+static int mg_create_common(vfem_mg **out, vfem_sim *fine, int L, int first_active) {
     VFEM_TRY
     if (L < 0) throw Error("numCoarseningLevels must be >= 0");
+    if (first_active < 0 || first_active > L) throw Error("first active level out of range");
+    if (fine->ex_lo || fine->ex_hi) throw Error("simulators with element padding need vfem_mg_create_slab");
     std::unique_ptr<vfem_mg> mg(new vfem_mg);
-    mg->fine = fine; mg->L = L;
+    mg->fine = fine; mg->L = L; mg->first_active = first_active;
     mg->lv.resize((size_t) L + 1);
     long long ne[3] = {fine->d.nx, fine->d.ny, fine->d.nz};
     for (int l = 0; l <= L; ++l) {
@@ -454,6 +522,8 @@ int vfem_mg_create(vfem_mg **out, vfem_sim *fine, int L) {
             }
         }
         lv.d = Dims(ne[0], ne[1], ne[2]);
+        lv.da = lv.d;
+        lv.fineNX = l > 0 ? mg->lv[l - 1].d.NX : 0;
         lv.kind = (l == 0) ? OP_MF0 : (l == 1 ? OP_MF1 : OP_STENCIL);
         if (l == 0) { lv.hmask = fine->hmask; lv.maskp = fine->dmask.p; }
         else {
@@ -462,47 +532,47 @@ int vfem_mg_create(vfem_mg **out, vfem_sim *fine, int L) {
             VFEM_HIP(hipMemcpy(lv.mask.p, lv.hmask.data(), (size_t) lv.d.nn, hipMemcpyHostToDevice));
             lv.maskp = lv.mask.p;
         }
-        lv.x.alloc((size_t) lv.d.nn * 3); lv.b.alloc((size_t) lv.d.nn * 3); lv.r.alloc((size_t) lv.d.nn * 3);
-        lv.x.zero(nullptr); lv.b.zero(nullptr); lv.r.zero(nullptr);
     }
-    // coarsened reference matrices cK0[g] = I_g^T K0 I_g (MG.hh:644-648), children g = 4gx+2gy+gz
-    {
-        std::vector<double> c(8 * 576, 0.0), T(576);
-        for (int g = 0; g < 8; ++g) {
-            double ph[8][8];
-            for (int fn = 0; fn < 8; ++fn)
-                for (int cn = 0; cn < 8; ++cn) {
-                    double v = 1.0;
-                    for (int dd = 0; dd < 3; ++dd) {
-                        const int sh = 2 - dd;
-                        const double p = 0.5 * ((fn >> sh) & 1) + 0.5 * ((g >> sh) & 1);
-                        v *= ((cn >> sh) & 1) ? p : (1.0 - p);
-                    }
-                    ph[fn][cn] = v;
-                }
-            for (int a = 0; a < 24; ++a)
-                for (int j = 0; j < 8; ++j)
-                    for (int dd = 0; dd < 3; ++dd) {
-                        double v = 0.0;
-                        for (int i = 0; i < 8; ++i) v += fine->K0[a * 24 + 3 * i + dd] * ph[i][j];
-                        T[a * 24 + 3 * j + dd] = v;
-                    }
-            for (int j = 0; j < 8; ++j)
-                for (int cc = 0; cc < 3; ++cc)
-                    for (int b = 0; b < 24; ++b) {
-                        double v = 0.0;
-                        for (int i = 0; i < 8; ++i) v += ph[i][j] * T[(3 * i + cc) * 24 + b];
-                        c[(size_t) g * 576 + (3 * j + cc) * 24 + b] = v;
-                    }
+    finish_mg_create(mg.get());
+    *out = mg.release();
+    VFEM_CATCH
+}
+
+int vfem_mg_create(vfem_mg **out, vfem_sim *fine, int L) { return mg_create_common(out, fine, L, 0); }
+int vfem_mg_create_partial(vfem_mg **out, vfem_sim *fine, int L, int first_active_level) {
+    return mg_create_common(out, fine, L, first_active_level);
+}
+
+int vfem_mg_create_slab(vfem_mg **out, vfem_sim *fine, int n_levels, const vfem_slab_level *lv_in,
+                        const uint8_t *const *masks_host) {
+    VFEM_TRY
+    if (n_levels < 1) throw Error("need at least one level");
+    std::unique_ptr<vfem_mg> mg(new vfem_mg);
+    mg->fine = fine; mg->L = n_levels - 1; mg->slab = true;
+    mg->lv.resize((size_t) n_levels);
+    long long ny = fine->d.ny, nz = fine->d.nz;
+    for (int l = 0; l < n_levels; ++l) {
+        MgLevel &lv = mg->lv[l];
+        if (l > 0) {
+            if (ny % 2 || nz % 2) throw Error("Grid size currently must be divisible by 2^numCoarseningLevels (nonuniform coarsening not yet implemented)");
+            ny /= 2; nz /= 2;
         }
-        mg->cK0.alloc(8 * 576);
-        VFEM_HIP(hipMemcpy(mg->cK0.p, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice));
+        lv.d = Dims(lv_in[l].nx, ny, nz);
+        lv.ex_lo = lv_in[l].elem_extra_lo; lv.ex_hi = lv_in[l].elem_extra_hi;
+        lv.da = Dims(lv_in[l].nx + lv.ex_lo + lv.ex_hi, ny, nz);
+        lv.xshift = (int) lv_in[l].xshift; lv.xparity = lv_in[l].xparity & 1;
+        lv.fineNX = l > 0 ? mg->lv[l - 1].d.NX : 0;
+        lv.kind = (l == 0) ? OP_MF0 : (l == 1 ? OP_MF1 : OP_STENCIL);
+        if (l > 0 && l < n_levels - 1 && mg->lv[l - 1].da.nx != 2 * lv.da.nx)
+            throw Error("slab element arrays must halve exactly between levels");   // (the last level only serves the transfers)
+        lv.hmask.assign(masks_host[l], masks_host[l] + lv.d.nn);
+        lv.mask.alloc((size_t) lv.d.nn);
+        VFEM_HIP(hipMemcpy(lv.mask.p, lv.hmask.data(), (size_t) lv.d.nn, hipMemcpyHostToDevice));
+        lv.maskp = lv.mask.p;
     }
-    const size_t n3 = (size_t) fine->d.nn * 3;
-    mg->pr.alloc(n3); mg->pd.alloc(n3); mg->pAd.alloc(n3); mg->ps.alloc(n3);
-    mg->scal.alloc(16); mg->scratch.alloc(2048);
-    mg->scal.zero(nullptr);
-    VFEM_HIP(hipDeviceSynchronize());
+    if (fine->d.nx != mg->lv[0].d.nx || fine->ex_lo != mg->lv[0].ex_lo || fine->ex_hi != mg->lv[0].ex_hi)
+        throw Error("level 0 of the slab hierarchy does not match the simulator");
+    finish_mg_create(mg.get());
     *out = mg.release();
     VFEM_CATCH
 }
@@ -572,19 +642,46 @@ int vfem_mg_zero_dirichlet(vfem_mg *mg, int level, double *u, void *stream) {
 int vfem_mg_restrict(vfem_mg *mg, int fine_level, const double *fine, double *coarse, void *stream) {
     VFEM_TRY
     check_level(mg, fine_level + 1);
-    launch_restrict(mg->lv[(size_t) fine_level + 1].d, fine, coarse, S(stream));
+    launch_restrict(mg->lv[(size_t) fine_level + 1].d, mg->lv[(size_t) fine_level].d.NX, mg->lv[(size_t) fine_level + 1].xshift, fine, coarse, S(stream));
     VFEM_CATCH
 }
 int vfem_mg_interpolate(vfem_mg *mg, int fine_level, const double *coarse, double *fine, int accumulate, void *stream) {
     VFEM_TRY
     check_level(mg, fine_level + 1);
-    launch_prolong(mg->lv[(size_t) fine_level + 1].d, coarse, fine, accumulate, S(stream));
+    launch_prolong(mg->lv[(size_t) fine_level + 1].d, mg->lv[(size_t) fine_level].d.NX, mg->lv[(size_t) fine_level + 1].xshift, coarse, fine, accumulate, S(stream));
     VFEM_CATCH
 }
 int vfem_mg_coarsest_solve(vfem_mg *mg, const double *b, double *x, void *stream) {
     VFEM_TRY
     if (!mg->operators_valid) update_operators(mg, S(stream));
     coarsest_solve(mg, b, x, S(stream));
+    VFEM_CATCH
+}
+
+int vfem_mg_smooth_colors(vfem_mg *mg, int level, double *u, const double *b, int forward, int first, int count, void *stream) {
+    VFEM_TRY
+    check_level(mg, level);
+    if (first < 0 || count < 0 || first + count > 8) throw Error("colour range out of [0, 8)");
+    if (level >= 2 && !mg->operators_valid) update_operators(mg, S(stream));
+    mg_smooth(mg, level, u, b, forward, S(stream), first, count);
+    VFEM_CATCH
+}
+int vfem_mg_cycle_from_level(vfem_mg *mg, int level, double *x, const double *b, int nsmooth, int fmg, void *stream) {
+    VFEM_TRY
+    check_level(mg, level);
+    if (level < mg->first_active) throw Error("level below the first active level of this hierarchy");
+    if (mg->slab) throw Error("slab hierarchies are cycled by the distributed driver");
+    hipStream_t s = S(stream);
+    if (!mg->operators_valid) update_operators(mg, s);
+    MgLevel &L = mg->lv[(size_t) level];
+    const size_t bytes = (size_t) L.d.nn * 3 * sizeof(double);
+    VFEM_HIP(hipMemcpyAsync(L.b.p, b, bytes, hipMemcpyDeviceToDevice, s));
+    if (fmg) full_multigrid(mg, level, nsmooth, true, s);
+    else {
+        VFEM_HIP(hipMemcpyAsync(L.x.p, x, bytes, hipMemcpyDeviceToDevice, s));
+        vcycle(mg, level, nsmooth, true, s);
+    }
+    VFEM_HIP(hipMemcpyAsync(x, L.x.p, bytes, hipMemcpyDeviceToDevice, s));
     VFEM_CATCH
 }
 
@@ -609,6 +706,7 @@ int vfem_mg_pcg(vfem_mg *mg, double *x, const double *b, int max_iter, double to
     VFEM_TRY
     hipStream_t s = S(stream);
     vfem_sim *sim = mg->fine;
+    if (mg->slab || mg->first_active != 0) throw Error("this hierarchy is driven by the distributed solver");
     const long long nn = sim->d.nn, n3 = 3 * nn;
     const size_t bytes = (size_t) n3 * sizeof(double);
     double *r = mg->pr.p, *d = mg->pd.p, *Ad = mg->pAd.p, *sv = mg->ps.p, *sc = mg->scal.p;

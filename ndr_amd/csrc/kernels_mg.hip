@@ -360,10 +360,11 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
 }
 
 void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *gs_tab, const double *E, double *u,
-                        const double *b, const uint8_t *mask, int forward, hipStream_t s) {
-    for (int ci = 0; ci < 8; ++ci) {
+                        const double *b, const uint8_t *mask, int forward, int xparity, int first, int count, hipStream_t s) {
+    for (int ci = first; ci < first + count; ++ci) {
         const int lni = forward ? ci : 7 - ci;
-        const int cx = (lni >> 2) & 1, cy = (lni >> 1) & 1, cz = lni & 1;
+        const int cx = ((lni >> 2) & 1) ^ (xparity & 1), cy = (lni >> 1) & 1, cz = lni & 1;   // global -> local x parity
+        if (cx > d.NX - 1) continue;
         const int cntx = (d.NX - 1 - cx) / 2 + 1, cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
         dim3 blk(64, 4, 1), grd((cntz + 63) / 64, (cnty + 3) / 4, cntx);
         if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab) k_gs_rows_mf0<<<grd, blk, 0, s>>>(d, gs_tab, E, u, b, mask, cx, cy, cz, forward);
@@ -449,10 +450,11 @@ __global__ void __launch_bounds__(256) k_gs_color_stencil(Dims d, const double *
 }
 
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
-                             int forward, hipStream_t s) {
-    for (int ci = 0; ci < 8; ++ci) {
+                             int forward, int xparity, int first, int count, hipStream_t s) {
+    for (int ci = first; ci < first + count; ++ci) {
         const int lni = forward ? ci : 7 - ci;
-        const int cx = (lni >> 2) & 1, cy = (lni >> 1) & 1, cz = lni & 1;
+        const int cx = ((lni >> 2) & 1) ^ (xparity & 1), cy = (lni >> 1) & 1, cz = lni & 1;
+        if (cx > d.NX - 1) continue;
         const int cntx = (d.NX - 1 - cx) / 2 + 1, cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
         dim3 blk(64, 4, 1), grd((cntz + 63) / 64, (cnty + 3) / 4, cntx);
         k_gs_color_stencil<<<grd, blk, 0, s>>>(d, S, u, b, mask, cx, cy, cz, forward);
@@ -463,15 +465,16 @@ void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const do
 // ------------------------------------------------------------------------------------------
 // grid transfer (trilinear weights 1, 1/2, 1/4, 1/8; no 1/2^N scaling), gather form
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_restrict(Dims c, const double *__restrict__ fine, double *__restrict__ coarse) {
+__global__ void __launch_bounds__(256) k_restrict(Dims c, int FX, int shift, const double *__restrict__ fine,
+                                                  double *__restrict__ coarse) {
     const int k = blockIdx.x * 64 + threadIdx.x;
     const int j = blockIdx.y * 4 + threadIdx.y;
     const int i = blockIdx.z;
     if (k >= c.NZ || j >= c.NY) return;
-    const int FX = 2 * c.nx + 1, FY = 2 * c.ny + 1, FZ = 2 * c.nz + 1;
+    const int FY = 2 * c.ny + 1, FZ = 2 * c.nz + 1;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     for (int di = -1; di <= 1; ++di) {
-        const int fi = 2 * i + di;
+        const int fi = 2 * i + shift + di;
         if (fi < 0 || fi >= FX) continue;
         for (int dj = -1; dj <= 1; ++dj) {
             const int fj = 2 * j + dj;
@@ -492,27 +495,28 @@ __global__ void __launch_bounds__(256) k_restrict(Dims c, const double *__restri
     coarse[3 * n] = a0; coarse[3 * n + 1] = a1; coarse[3 * n + 2] = a2;
 }
 
-void launch_restrict(const Dims &c, const double *fine, double *coarse, hipStream_t s) {
+void launch_restrict(const Dims &c, int fineNX, int shift, const double *fine, double *coarse, hipStream_t s) {
     dim3 blk(64, 4, 1), grd((c.NZ + 63) / 64, (c.NY + 3) / 4, c.NX);
-    k_restrict<<<grd, blk, 0, s>>>(c, fine, coarse);
+    k_restrict<<<grd, blk, 0, s>>>(c, fineNX, shift, fine, coarse);
     VFEM_HIP(hipGetLastError());
 }
 
 template <bool ACC>
-__global__ void __launch_bounds__(256) k_prolong(Dims c, const double *__restrict__ coarse, double *__restrict__ fine) {
-    const int FX = 2 * c.nx + 1, FY = 2 * c.ny + 1, FZ = 2 * c.nz + 1;
+__global__ void __launch_bounds__(256) k_prolong(Dims c, int shift, const double *__restrict__ coarse, double *__restrict__ fine) {
+    const int FY = 2 * c.ny + 1, FZ = 2 * c.nz + 1;
     const int k = blockIdx.x * 64 + threadIdx.x;
     const int j = blockIdx.y * 4 + threadIdx.y;
     const int i = blockIdx.z;
     if (k >= FZ || j >= FY) return;
-    (void) FX;
-    const int i0 = i >> 1, j0 = j >> 1, k0 = k >> 1;
-    const int oi = i & 1, oj = j & 1, ok = k & 1;
+    const int ig = i - shift;                     // >= 0: shift is 0 or -1
+    const int i0 = ig >> 1, j0 = j >> 1, k0 = k >> 1;
+    const int oi = ig & 1, oj = j & 1, ok = k & 1;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int qi = (q >> 2) & 1, qj = (q >> 1) & 1, qk = q & 1;
         if ((qi && !oi) || (qj && !oj) || (qk && !ok)) continue;
+        if (i0 + qi > c.NX - 1) continue;         // beyond the local slab (only for ghost planes, refreshed by the exchange)
         const double w = (oi ? 0.5 : 1.0) * (oj ? 0.5 : 1.0) * (ok ? 0.5 : 1.0);
         const long long m = nidx(c, i0 + qi, j0 + qj, k0 + qk);
         a0 = fma(w, coarse[3 * m], a0);
@@ -524,11 +528,11 @@ __global__ void __launch_bounds__(256) k_prolong(Dims c, const double *__restric
     else     { fine[3 * n] = a0;  fine[3 * n + 1] = a1;  fine[3 * n + 2] = a2; }
 }
 
-void launch_prolong(const Dims &c, const double *coarse, double *fine, int accumulate, hipStream_t s) {
-    const int FX = 2 * c.nx + 1, FY = 2 * c.ny + 1, FZ = 2 * c.nz + 1;
-    dim3 blk(64, 4, 1), grd((FZ + 63) / 64, (FY + 3) / 4, FX);
-    if (accumulate) k_prolong<true><<<grd, blk, 0, s>>>(c, coarse, fine);
-    else            k_prolong<false><<<grd, blk, 0, s>>>(c, coarse, fine);
+void launch_prolong(const Dims &c, int fineNX, int shift, const double *coarse, double *fine, int accumulate, hipStream_t s) {
+    const int FY = 2 * c.ny + 1, FZ = 2 * c.nz + 1;
+    dim3 blk(64, 4, 1), grd((FZ + 63) / 64, (FY + 3) / 4, fineNX);
+    if (accumulate) k_prolong<true><<<grd, blk, 0, s>>>(c, shift, coarse, fine);
+    else            k_prolong<false><<<grd, blk, 0, s>>>(c, shift, coarse, fine);
     VFEM_HIP(hipGetLastError());
 }
 

@@ -76,14 +76,17 @@ void launch_apply_stencil(const Dims &d, const double *S, const double *u, const
 void launch_apply_fast(const Dims &d, const double *Dm_host, const double *E, const double *u, const double *b,
                        const uint8_t *mask, int mode, double *out, hipStream_t s);
 
+// colours are processed in the reference order (global parity); `xparity` = global x-parity of local plane 0,
+// [first, first+count) selects a sub-range of the 8 colours (half sweeps between halo exchanges)
 void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *gs_tab, const double *E, double *u,
-                        const double *b, const uint8_t *mask, int forward, hipStream_t s);
+                        const double *b, const uint8_t *mask, int forward, int xparity, int first, int count, hipStream_t s);
 void build_gs_table(const double *K0, double *tab /* 36*24 doubles */);
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
-                             int forward, hipStream_t s);
+                             int forward, int xparity, int first, int count, hipStream_t s);
 
-void launch_restrict(const Dims &coarse, const double *fine, double *coarse_out, hipStream_t s);
-void launch_prolong(const Dims &coarse, const double *coarse_in, double *fine, int accumulate, hipStream_t s);
+// fine local plane index = 2 * (coarse local plane) + shift + {-1,0,1}; fineNX = fine local node planes
+void launch_restrict(const Dims &coarse, int fineNX, int shift, const double *fine, double *coarse_out, hipStream_t s);
+void launch_prolong(const Dims &coarse, int fineNX, int shift, const double *coarse_in, double *fine, int accumulate, hipStream_t s);
 
 void launch_zero_dirichlet(long long nn, const uint8_t *mask, double *u, hipStream_t s);
 void launch_enforce_dirichlet(long long nn, const uint8_t *mask, const double *vals, double *u, int zero, hipStream_t s);
@@ -131,11 +134,21 @@ struct vfem_sim {
     std::vector<uint8_t> hmask;                 // host copy of the Dirichlet mask
     std::vector<double> hvals;
     bool nonzero_dirichlet = false;
+    // slab decomposition: element arrays (rho, E) may hold extra x-layers in front of / behind the node grid
+    long long ex_lo = 0, ex_hi = 0;
+    long long n_store() const { return (long long) (d.nx + ex_lo + ex_hi) * d.ny * d.nz; }
+    const double *Ep() const { return E.p + ex_lo * d.ny * d.nz; }
+    const double *rhop() const { return rho.p + ex_lo * d.ny * d.nz; }
     void update_k0();
 };
 
 struct MgLevel {
-    vfem::Dims d;
+    vfem::Dims d;                               // node grid (local: owned + one ghost element layer per interior side)
+    vfem::Dims da;                              // element-array dims (d plus ex_lo/ex_hi extra x-layers)
+    long long ex_lo = 0, ex_hi = 0;
+    int xshift = 0;                             // finer-level local plane of this level's local plane 0
+    int xparity = 0;                            // global x-parity of local plane 0
+    int fineNX = 0;                             // node planes of the next finer level (for the transfers)
     vfem::OpKind kind = vfem::OP_MF0;
     vfem::DevBuf<uint8_t> mask;                 // coarsened Dirichlet masks (levels >= 1)
     const uint8_t *maskp = nullptr;
@@ -152,6 +165,8 @@ struct vfem_mg {
     vfem::DevBuf<double> Ainv;                  // coarsest-level dense inverse
     vfem::DevBuf<double> pr, pd, pAd, ps;       // PCG vectors
     vfem::DevBuf<double> scal, scratch;
+    bool slab = false;                          // local part of an x-slab decomposition: no coarsest solver here
+    int first_active = 0;                       // levels below are never cycled (replicated coarse hierarchy)
     bool symmetric_gs = true;                   // MG.hh:758
     bool operators_valid = false;
     void *rocblas = nullptr;                    // rocblas_handle for the coarsest factorisation

@@ -182,7 +182,36 @@ def seeded_slab_field(part, seed=7):
     return out.reshape(-1, 3)
 
 
-def bench_apply(ne, steps, warmup):
+def bench_pcg(ne, levels, tol=1e-4):
+    """distributed CG-MG iterations/s with the reference settings (1 FMG cycle / iteration, 2+2 symmetric sweeps)"""
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bc = os.path.join(here, "tests", "golden", "bcs", "3d", "cantilever_flexion.bc")
+    mat = os.path.join(here, "tests", "golden", "materials", "B9Creator.material")
+    ds = DistributedMGSolver(ne, [0.0, 0.0, 0.0], [2.0, 1.0, 1.0], bc, mat, levels)
+    g = torch.Generator(device="cuda").manual_seed(88)
+    rho = torch.rand(ne[0] * ne[1] * ne[2], dtype=torch.float64, device="cuda", generator=g)   # same on every rank
+    ds.set_global_densities(rho)
+    del rho
+    f = ds.local_loads()
+    ds.pcg(torch.zeros_like(f), f, 1, tol, 1, 2, True)              # warm-up (operator build, NCCL channels)
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    t0 = time.perf_counter()
+    u = ds.pcg(torch.zeros_like(f), f, 100, tol, 1, 2, True)
+    torch.cuda.synchronize()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if dist.is_initialized():
+        if dist.get_backend() != "gloo":
+            dt = dt.cuda()
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    return {"grid": "%dx%dx%d" % tuple(ne), "levels": levels, "distributed_levels": ds.Ld + 1, "iterations": ds.last_iterations,
+            "seconds": dt, "iterations_per_s": ds.last_iterations / dt, "relative_residual": ds.last_relative_residual,
+            "compliance": 2.0 * ds.compliance(f, u)}
+
+
+def bench_apply(ne, steps, warmup, with_cg=True):
     """bench.py's N > 1 leg: K steps of {halo exchange + local apply}, max over ranks, whole-grid GVoxel/s."""
     init_process_group_from_env()
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -208,6 +237,15 @@ def bench_apply(ne, steps, warmup):
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     wall = float(dt.item())
     chk = K.halo.dot(out, out)
+    del out, u, K, ops
+    torch.cuda.empty_cache()
+    cg = []
+    if with_cg:
+        for cg_ne, cg_levels in ([((256, 256, 256), 5)] + ([((512, 512, 512), 6)] if tuple(ne) == (512, 512, 512) else [])):
+            try:
+                cg.append(bench_pcg(cg_ne, cg_levels))
+            except RuntimeError as e:          # reported, never hidden
+                cg.append({"grid": "%dx%dx%d" % cg_ne, "error": str(e)})
     nvox = ne[0] * ne[1] * ne[2]
     nn = (ne[0] + 1) * (ne[1] + 1) * (ne[2] + 1)
     ab = 2 * nn * 24 + nvox * 8
@@ -223,4 +261,281 @@ def bench_apply(ne, steps, warmup):
                      "frac": ab / (wall / steps) / 1e9 / (8000.0 * world), "traffic": None,
                      "note": "whole-step time (halo exchange included), aggregate peak of all GPUs"},
         "checksum_KuKu": float(chk.item()),
+        "cg_mg": cg,
     }
+
+
+# ==============================================================================================
+# Distributed multigrid-preconditioned CG (MultigridSolver::preconditionedConjugateGradient, MG.hh:679-732,
+# with vcycle / fullMultigrid of MG.hh:486-553) over x-slabs.
+#
+# Levels 0..Ld are distributed (every rank smooths its slab; one ghost node plane per interior side at every
+# level; the element arrays of coarser levels' ghost elements are built locally from a wider padding of the fine
+# moduli, so operator construction needs no communication beyond one density gather per solve).  Levels below
+# are tiny: their right-hand side is gathered (sum of disjoint contributions) and every rank runs the same
+# coarse cycle on a replicated hierarchy.  Per Gauss-Seidel half sweep (4 colours = one x-parity) the ghost
+# planes are refreshed; dot products count interface planes once and finish with one all-reduce.
+# ==============================================================================================
+
+class _LevelGeom:
+    def __init__(self, part, l, Ld, ne0):
+        s = 2 ** l
+        self.l = l
+        self.X0, self.X1 = part.x0 // s, part.x1 // s
+        self.gl, self.gr = part.gl, part.gr
+        self.nx = self.X1 - self.X0 + self.gl + self.gr
+        self.ny, self.nz = ne0[1] // s, ne0[2] // s
+        self.n_planes = self.nx + 1
+        self.plane = (self.ny + 1) * (self.nz + 1)
+        self.first_owned = self.gl
+        self.last_owned = self.gl + (self.X1 - self.X0)
+        self.xoffn = self.X0 - self.gl
+        pad = (2 ** (Ld - l) - 1) if l <= Ld else 0
+        self.extra_lo, self.extra_hi = self.gl * pad, self.gr * pad
+        self.xshift = -self.gl if l > 0 else 0
+        self.xparity = self.xoffn & 1
+        self.rank, self.world = part.rank, part.world
+
+    # HaloExchanger duck-typing
+    def reduction_weight_planes(self):
+        return self.first_owned, self.last_owned + (1 if self.rank == self.world - 1 else 0)
+
+
+class DistributedMGSolver:
+    """Slab-decomposed multigrid PCG on the HIP kernels (one instance per rank)."""
+
+    def __init__(self, ne, bbmin, bbmax, bc_path, material_path, num_levels, dist_levels=None, E0=1.0, Emin=1e-4,
+                 gamma=3.0, group=None):
+        import ctypes
+        from . import _lib
+        from . import pyVoxelFEM as pv
+        self._ct, self._lib_mod, self._pv = ctypes, _lib, pv
+        self.lib = _lib.load()
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.ne = tuple(int(v) for v in ne)
+        self.L = int(num_levels)
+        if dist_levels is None:
+            dist_levels = 0
+            while (dist_levels + 1 < self.L and self.ne[0] % (self.world * 2 ** (dist_levels + 2)) == 0
+                   and self.ne[0] // (self.world * 2 ** (dist_levels + 1)) >= 2):
+                dist_levels += 1
+        self.Ld = int(dist_levels)
+        if self.Ld + 1 > self.L:
+            raise RuntimeError("need at least one replicated level below the distributed ones")
+        self.T = self.Ld + 1
+        self.part = SlabPartition(self.ne, self.world, self.rank, align=2 ** (self.Ld + 1))
+        self.geom = [_LevelGeom(self.part, l, self.Ld, self.ne) for l in range(self.T + 1)]
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+
+        # replicated (global) simulator + hierarchy: Dirichlet masks of every level, loads, coarse cycles
+        self.gsim = pv.TensorProductSimulator1_1_1([np.asarray(bbmin, float), np.asarray(bbmax, float)], list(self.ne))
+        self.gsim.readMaterial(material_path)
+        self.gsim.applyDisplacementsAndLoadsFromFile(bc_path)
+        self.gsim.E_0, self.gsim.E_min, self.gsim.gamma = E0, Emin, gamma
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.vfem_mg_create_partial(ctypes.byref(h), self.gsim._h, self.L, self.T))
+        self.gmg = h
+
+        # local slab simulator (node grid: owned + ghost layers; element arrays padded)
+        g0 = self.geom[0]
+        lo, hi = self.part.local_bbox(bbmin, bbmax)
+        _lib.check(self.lib.vfem_sim_set_next_element_padding(g0.extra_lo, g0.extra_hi))
+        self.lsim = pv.TensorProductSimulator1_1_1([lo, hi], [g0.nx, self.ne[1], self.ne[2]])
+        self.lsim.readMaterial(material_path)
+        self.lsim.E_0, self.lsim.E_min, self.lsim.gamma = E0, Emin, gamma
+
+        # per-level local Dirichlet masks = slices of the global coarsened masks
+        masks = []
+        for l, g in enumerate(self.geom):
+            nn = int(self.lib.vfem_mg_level_num_nodes(self.gmg, l))
+            m = np.empty(nn, dtype=np.uint8)
+            _lib.check(self.lib.vfem_mg_level_dirichlet_mask(self.gmg, l, m.ctypes.data_as(ctypes.c_void_p)))
+            m = m.reshape(-1, g.plane)[g.xoffn:g.xoffn + g.n_planes]
+            masks.append(np.ascontiguousarray(m.reshape(-1)))
+        self._masks = masks
+        m0 = masks[0]
+        self.lsim._mask = np.stack([(m0 >> c) & 1 for c in range(3)], axis=1).astype(bool)
+        self.lsim._dvals = np.zeros((m0.size, 3))
+        self.lsim._push_dirichlet()
+
+        class _SL(ctypes.Structure):
+            _fields_ = [("nx", ctypes.c_int64), ("elem_extra_lo", ctypes.c_int64), ("elem_extra_hi", ctypes.c_int64),
+                        ("xshift", ctypes.c_int64), ("xparity", ctypes.c_int32)]
+        arr = (_SL * len(self.geom))()
+        for l, g in enumerate(self.geom):
+            arr[l].nx, arr[l].elem_extra_lo, arr[l].elem_extra_hi = g.nx, g.extra_lo, g.extra_hi
+            arr[l].xshift, arr[l].xparity = g.xshift, g.xparity
+        mptrs = (ctypes.c_void_p * len(masks))(*[m.ctypes.data_as(ctypes.c_void_p).value for m in masks])
+        h2 = ctypes.c_void_p()
+        _lib.check(self.lib.vfem_mg_create_slab(ctypes.byref(h2), self.lsim._h, len(self.geom), arr, mptrs))
+        self.lmg = h2
+        self.halos = [HaloExchanger(g, group) for g in self.geom]
+        for hx, g in zip(self.halos, self.geom):
+            hx.p.world, hx.p.rank = self.world, self.rank
+        z = lambda g: torch.zeros((g.n_planes * g.plane, 3), dtype=torch.float64, device=self.dev)
+        self.x = [z(g) for g in self.geom]
+        self.b = [z(g) for g in self.geom]
+        self.r = [z(g) for g in self.geom[:-1]]
+        gT = int(self.lib.vfem_mg_level_num_nodes(self.gmg, self.T))
+        self.xT = torch.zeros((gT, 3), dtype=torch.float64, device=self.dev)
+        self.bT = torch.zeros((gT, 3), dtype=torch.float64, device=self.dev)
+        self.symmetric_gs = True
+        self.last_iterations, self.last_relative_residual = 0, 0.0
+
+    # ---- small helpers -------------------------------------------------------------------
+    def _s(self):
+        return self._ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _p(self, t):
+        return self._ct.c_void_p(t.data_ptr())
+
+    def _chk(self, status):
+        self._lib_mod.check(status)
+
+    def _allreduce(self, t):
+        if self.world > 1:
+            if t.is_cuda and dist.get_backend(self.group) == "gloo":
+                h = t.cpu()
+                dist.all_reduce(h, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, group=self.group)
+        return t
+
+    def local_loads(self):
+        g = self.geom[0]
+        f = self.gsim.buildLoadVector_device().view(self.ne[0] + 1, -1)[g.xoffn:g.xoffn + g.n_planes]
+        return f.reshape(-1, 3).clone()
+
+    def set_global_densities(self, rho_global):
+        """rho_global: [nx*ny*nz] float64 device tensor, identical on every rank"""
+        self.gsim.setElementDensities(rho_global)
+        g = self.geom[0]
+        a0, b0 = g.xoffn - g.extra_lo, g.xoffn + g.nx + g.extra_hi
+        self.lsim.setElementDensities_padded(rho_global.view(self.ne[0], -1)[a0:b0].reshape(-1))
+
+    def update_operators(self):
+        self._chk(self.lib.vfem_mg_update_operators(self.lmg, self._s()))
+        self._chk(self.lib.vfem_mg_update_operators(self.gmg, self._s()))
+
+    # ---- operators on distributed levels -----------------------------------------------------
+    def halo(self, l, f):
+        self.halos[l].exchange(f)
+
+    def smooth(self, l, x, b, forward):
+        for first in (0, 4):
+            self._chk(self.lib.vfem_mg_smooth_colors(self.lmg, l, self._p(x), self._p(b), int(forward), first, 4, self._s()))
+            self.halo(l, x)
+
+    def residual(self, l, x, b, out):
+        self._chk(self.lib.vfem_mg_residual(self.lmg, l, self._p(x), self._p(b), self._p(out), self._s()))
+        return out
+
+    def apply_k(self, d_, out):
+        self._chk(self.lib.vfem_mg_apply_k(self.lmg, 0, self._p(d_), self._p(out), self._s()))
+        self._chk(self.lib.vfem_mg_zero_dirichlet(self.lmg, 0, self._p(out), self._s()))
+        return out
+
+    def restrict(self, l, fine, coarse):
+        self._chk(self.lib.vfem_mg_restrict(self.lmg, l, self._p(fine), self._p(coarse), self._s()))
+
+    def prolong(self, l, coarse, fine, accumulate):
+        self._chk(self.lib.vfem_mg_interpolate(self.lmg, l, self._p(coarse), self._p(fine), int(accumulate), self._s()))
+
+    def dot(self, a, b):
+        return float(self.halos[0].dot(a, b).item())
+
+    # ---- replicated coarse cycle ---------------------------------------------------------------
+    def coarse_cycle(self, fmg):
+        g = self.geom[self.T]
+        lo, hi = g.reduction_weight_planes()
+        self.bT.zero_()
+        bv = self.bT.view(-1, g.plane * 3)
+        bv[g.xoffn + lo:g.xoffn + hi] = self.b[self.T].view(g.n_planes, -1)[lo:hi]
+        self._allreduce(self.bT)
+        self.xT.zero_()
+        self._chk(self.lib.vfem_mg_cycle_from_level(self.gmg, self.T, self._p(self.xT), self._p(self.bT), self._nsmooth,
+                                                   int(fmg), self._s()))
+        self.x[self.T].view(g.n_planes, -1).copy_(self.xT.view(-1, g.plane * 3)[g.xoffn:g.xoffn + g.n_planes])
+
+    # ---- cycles (MG.hh:486-553) ----------------------------------------------------------------
+    def vcycle(self, l):
+        if l == self.T:
+            self.coarse_cycle(False)
+            return
+        x, b, r = self.x[l], self.b[l], self.r[l]
+        self._chk(self.lib.vfem_mg_zero_dirichlet(self.lmg, l, self._p(x), self._s()))      # residual system
+        for _ in range(self._nsmooth):
+            self.smooth(l, x, b, True)
+        self.residual(l, x, b, r)
+        self.halo(l, r)
+        self.restrict(l, r, self.b[l + 1])
+        self.x[l + 1].zero_()
+        self.vcycle(l + 1)
+        self.prolong(l, self.x[l + 1], x, True)
+        self.halo(l, x)
+        for _ in range(self._nsmooth):
+            self.smooth(l, x, b, not self.symmetric_gs)
+
+    def full_multigrid(self, l):
+        if l == self.T:
+            self.coarse_cycle(True)
+            return
+        self.halo(l, self.b[l])
+        self.restrict(l, self.b[l], self.b[l + 1])
+        self.full_multigrid(l + 1)
+        self.prolong(l, self.x[l + 1], self.x[l], False)
+        self.halo(l, self.x[l])
+        self.vcycle(l)
+
+    def precondition(self, r, mg_iterations, nsmooth, fmg):
+        self._nsmooth = nsmooth
+        self.x[0].zero_()
+        self.b[0].copy_(r)
+        if fmg:
+            self.full_multigrid(0)
+            for _ in range(1, mg_iterations):
+                self.vcycle(0)
+        else:
+            for _ in range(mg_iterations):
+                self.vcycle(0)
+        return self.x[0]
+
+    # ---- PCG (MG.hh:679-732) -------------------------------------------------------------------
+    def pcg(self, x, b, max_iter, tol, mg_iterations=1, nsmooth=1, fmg=False, callback=None):
+        self._nsmooth = nsmooth
+        self._chk(self.lib.vfem_mg_zero_dirichlet(self.lmg, 0, self._p(x), self._s()))      # zero Dirichlet values only
+        self.update_operators()
+        bb = self.dot(b, b)
+        self.halo(0, x)
+        r = torch.empty_like(x)
+        self.residual(0, x, b, r)
+        rr = self.dot(r, r)
+        d = torch.zeros_like(x)
+        Ad = torch.empty_like(x)
+        rMr, it = 0.0, 0
+        while it < max_iter and rr > tol * tol * bb:
+            it += 1
+            s = self.precondition(r, mg_iterations, nsmooth, fmg) if nsmooth > 0 else r.clone()
+            self._chk(self.lib.vfem_mg_zero_dirichlet(self.lmg, 0, self._p(s), self._s()))
+            rMr_old, rMr = rMr, self.dot(r, s)
+            if it == 1:
+                d.copy_(s)
+            else:
+                d.mul_(rMr / rMr_old).add_(s)
+            self.halo(0, d)
+            self.apply_k(d, Ad)
+            alpha = rMr / self.dot(d, Ad)
+            x.add_(d, alpha=alpha)
+            r.add_(Ad, alpha=-alpha)
+            rr = self.dot(r, r)
+            if callback:
+                callback(it, rr ** 0.5)
+        self.last_iterations = it
+        self.last_relative_residual = (rr / bb) ** 0.5 if bb > 0 else 0.0
+        return x
+
+    def compliance(self, f, u):
+        return 0.5 * self.dot(f, u)

@@ -220,11 +220,19 @@ class TensorProductSimulator1_1_1:
         _lib.check(self._lib.vfem_sim_set_uniform_density(self._h, float(density), _stream()))
 
     def setElementDensities(self, rho):
+        if int(self._lib.vfem_sim_num_stored_elements(self._h)) != self.numElements():
+            raise RuntimeError("padded slab simulator: use setElementDensities_padded")
         t = _to_dev(rho, (self.numElements(),))
         _lib.check(self._lib.vfem_sim_set_densities(self._h, _ptr(t), _stream()))
 
+    def setElementDensities_padded(self, rho):
+        """slab simulators: densities for every stored element layer (node grid + padding)"""
+        n = int(self._lib.vfem_sim_num_stored_elements(self._h))
+        t = _to_dev(rho, (n,))
+        _lib.check(self._lib.vfem_sim_set_densities(self._h, _ptr(t), _stream()))
+
     def getDensities_device(self):
-        t = torch.empty(self.numElements(), dtype=torch.float64, device=_dev())
+        t = torch.empty(int(self._lib.vfem_sim_num_stored_elements(self._h)), dtype=torch.float64, device=_dev())
         _lib.check(self._lib.vfem_sim_get_densities(self._h, _ptr(t), _stream()))
         return t
 

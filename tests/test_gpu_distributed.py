@@ -58,3 +58,52 @@ def test_two_ranks_one_gpu_apply():
     for rank, err, nrm, ref in res:
         assert err < 1e-12, (rank, err)
         assert abs(nrm - ref) < 1e-10 * ref
+
+
+def _pcg_worker(rank, world, port, ne, levels, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from helpers import BC_CANTILEVER, MATERIAL, make_hip, seeded_density
+    from ndr_amd import distributed as vd
+    dom = ([0.0, 0.0, 0.0], [2.0, 1.0, 1.0])
+    rho = torch.from_numpy(seeded_density(ne, 88)).cuda()
+    ds = vd.DistributedMGSolver(ne, dom[0], dom[1], BC_CANTILEVER, MATERIAL, levels)
+    ds.set_global_densities(rho)
+    f = ds.local_loads()
+    u = ds.pcg(torch.zeros_like(f), f, 100, 1e-8, 1, 2, True)
+    comp = 2.0 * ds.compliance(f, u)
+    # single-process reference with the same kernels
+    t = make_hip(ne, dom, BC_CANTILEVER, rho.cpu().numpy())
+    mg = t.multigridSolver(levels)
+    fg = t.buildLoadVector_device()
+    ug = mg.preconditionedConjugateGradient_device(torch.zeros_like(fg), fg, 100, 1e-8, None, 1, 2, True)
+    cg = float((fg * ug).sum())
+    g = ds.geom[0]
+    mine = u.view(g.n_planes, -1)[g.first_owned:g.last_owned + 1]
+    want = ug.view(ne[0] + 1, -1)[ds.part.x0:ds.part.x1 + 1]
+    err = float((mine - want).abs().max() / want.abs().max())
+    q.put((rank, ds.Ld, ds.last_iterations, mg.last_iterations, comp, cg, err))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ne,levels", [(2, (32, 16, 16), 3), (2, (48, 8, 16), 2)])
+def test_distributed_pcg_matches_single_process(world, ne, levels):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 1000) + levels
+    procs = [ctx.Process(target=_pcg_worker, args=(r, world, port, ne, levels, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, Ld, it_d, it_s, comp, cg, err in res:
+        assert Ld >= 1
+        assert it_d == it_s, (it_d, it_s)
+        assert abs(comp - cg) < 1e-9 * abs(cg), (comp, cg)
+        assert err < 1e-7, err
