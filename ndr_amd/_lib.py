@@ -20,6 +20,7 @@ SIGNATURES = {
     "vfem_device_count": (c_int, []),
     "vfem_set_device": (c_int, [c_int]),
     "vfem_version": (c_int, []),
+    "vfem_debug_set": (c_int, [c_int, c_int]),
     "vfem_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
     "vfem_free": (c_int, [c_void_p]),
     "vfem_copy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

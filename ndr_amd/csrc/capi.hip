@@ -19,6 +19,7 @@
 
 namespace vfem {
 
+extern int g_apply_pd, g_apply_skeleton, g_gs_variant, g_apply_store;
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
@@ -303,6 +304,15 @@ extern "C" {
 
 const char *vfem_last_error(void) { return vfem::g_err.c_str(); }
 int vfem_version(void) { return 100; }
+int vfem_debug_set(int key, int value) {
+    if (key == 0) vfem::g_apply_pd = value;
+    else if (key == 1) vfem::g_apply_skeleton = value;
+    else if (key == 2) vfem::g_gs_variant = value;
+    else if (key == 3) vfem::g_apply_store = value;
+    else if (key == 4) vfem::g_apply_impl = value;
+    else return 1;
+    return 0;
+}
 
 int vfem_device_count(void) {
     int n = 0;
@@ -434,8 +444,12 @@ int vfem_sim_get_densities(const vfem_sim *sim, double *rho, void *stream) {
 int vfem_sim_apply_k(const vfem_sim *sim, const double *u, double *out, int variant, void *stream) {
     VFEM_TRY
     ScopedTimer tm("applyK");
-    if (variant != 1 && sim->fast_ok)
-        launch_apply_fast(sim->d, sim->Dm, sim->Ep(), u, nullptr, nullptr, variant == 0 ? 0 : 3, out, S(stream));
+    if (variant != 1 && sim->fast_ok) {
+        bool done = false;
+        if (variant == 0 && g_apply_impl == 0)
+            done = launch_apply_dma(sim->d, sim->Dm, sim->Ep(), sim->E.p + sim->n_store(), u, out, S(stream));
+        if (!done) launch_apply_fast(sim->d, sim->Dm, sim->Ep(), u, nullptr, nullptr, 0, out, S(stream));
+    }
     else launch_apply_gather(sim->d, OP_MF0, sim->dK0.p, sim->Ep(), u, nullptr, nullptr, 0, out, S(stream));
     VFEM_CATCH
 }

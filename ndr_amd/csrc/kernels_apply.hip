@@ -27,18 +27,18 @@ namespace vfem {
 constexpr int TY = 8;          // element rows per tile = waves per block (2 per SIMD, one block per CU)
 constexpr int TZ = 64;         // element columns per tile (lanes)
 constexpr int ROW_D = 196;     // doubles per staged node row (65 nodes x 3 = 195 used)
-constexpr int PD = 2;          // planes of u kept in flight in registers
 constexpr int NLD = 4;         // staged doubles per thread and plane: (TY+1)*195 = 1755 <= 4 * 512
 constexpr int SU_SIZE = (TY + 1) * ROW_D;               // element 195 of every row is the dump slot of unused staging slots
 
 struct DmArgs { double v[36]; };
 
-template <int MODE, int WPS>   // MODE 0: out = K u   1: out = zeroDirichlet(b - K u)   2: out = zeroDirichlet(K u)
-__global__ void __launch_bounds__(TY * TZ, WPS) k_apply_fast(Dims d, DmArgs dm, const double *__restrict__ E,
+template <int MODE, int WPS, int PD>   // MODE 0: out = K u   1: out = zeroDirichlet(b - K u)   2: out = zeroDirichlet(K u); PD = planes in flight
+__global__ void __launch_bounds__(TY * TZ, WPS == 1 ? 2 : WPS) k_apply_fast(Dims d, DmArgs dm, const double *__restrict__ E,
                                                         const double *__restrict__ u, const double *__restrict__ b,
                                                         const uint8_t *__restrict__ mask, double *__restrict__ out,
-                                                        int planes_per_chunk) {
-    __shared__ double su2[2 * SU_SIZE];          // staged node planes, double-buffered
+                                                        int planes_per_chunk, int store_mode) {
+    __shared__ double su2[2 * SU_SIZE];
+    __shared__ double so[TY * 192];               // per-wave output row staging (store_mode 2)          // staged node planes, double-buffered
     __shared__ double sS[2 * 9 * TY * TZ];        // face -> node scatter slots (B, C, D shares), double-buffered
 
     const int tz = threadIdx.x, ty = threadIdx.y;
@@ -124,6 +124,30 @@ __global__ void __launch_bounds__(TY * TZ, WPS) k_apply_fast(Dims d, DmArgs dm, 
     };
 
     auto emit_plane = [&](int i, const double wa[3], int buf) {
+        if (MODE == 0 && store_mode == 2) {
+            // transpose through a per-wave LDS row so that every store instruction writes 512 contiguous bytes
+            const double *sB = sS + buf * (9 * TY * TZ), *sC = sB + 3 * TY * TZ, *sD = sC + 3 * TY * TZ;
+            double *row = so + ty * 192;
+            if (ty >= 1 && tz >= 1) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    row[3 * (tz - 1) + c] = wa[c] + sB[(c * TY + ty) * TZ + tz - 1] + sC[(c * TY + ty - 1) * TZ + tz] +
+                                            sD[(c * TY + ty - 1) * TZ + tz - 1];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (ty >= 1 && ej < d.NY) {
+                const int kfirst = k0 + 1;                       // node column of row[0]
+                int nvalid = d.NZ - kfirst; if (nvalid > TZ - 1) nvalid = TZ - 1;
+                double *dst = out + 3 * ((long long) i * plane + (long long) ej * d.NZ + kfirst);
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3) {
+                    const int q = tz + 64 * s3;
+                    if (q < 3 * nvalid) dst[q] = row[q];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
         if (!out_ok) return;
         const double *sB = sS + buf * (9 * TY * TZ), *sC = sB + 3 * TY * TZ, *sD = sC + 3 * TY * TZ;
         const long long n = (long long) i * plane + (long long) ej * d.NZ + ek;
@@ -133,7 +157,8 @@ __global__ void __launch_bounds__(TY * TZ, WPS) k_apply_fast(Dims d, DmArgs dm, 
             w[c] = wa[c] + sB[(c * TY + ty) * TZ + tz - 1] + sC[(c * TY + ty - 1) * TZ + tz] +
                    sD[(c * TY + ty - 1) * TZ + tz - 1];
         if (MODE == 0) {
-            out[3 * n] = w[0]; out[3 * n + 1] = w[1]; out[3 * n + 2] = w[2];
+            if (store_mode == 0) { out[3 * n] = w[0]; out[3 * n + 1] = w[1]; out[3 * n + 2] = w[2]; }
+            else if (store_mode == 1) { if (p0 < -5) out[3 * n] = w[0] + w[1] + w[2]; }
         } else {
             const uint8_t m = mask ? mask[n] : 0;
 #pragma unroll
@@ -157,6 +182,16 @@ __global__ void __launch_bounds__(TY * TZ, WPS) k_apply_fast(Dims d, DmArgs dm, 
     // face sums of plane i-1 in the scatter slots sS[buf] and returns this thread's own share in wa
     auto process = [&](double Ee, int buf, double wa[3]) {
         if (!elem_ok) Ee = 0.0;
+        if (WPS == 1) {   // diagnostic build: memory/LDS skeleton only (no transform arithmetic)
+            const double *su = su2 + buf * SU_SIZE;
+            double acc[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[q][c] = Ee + su[ty * ROW_D + 3 * tz + c] + su[(ty + 1) * ROW_D + 3 * (tz + 1) + c];
+            scatter_face(acc, wa, buf);
+            return;
+        }
         double fnew[4][3];
         face_modes(fnew, buf);
         double m[8][3];
@@ -255,6 +290,13 @@ __global__ void __launch_bounds__(TY * TZ, WPS) k_apply_fast(Dims d, DmArgs dm, 
     }
 }
 
+bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, const double *E_alloc_end, const double *u,
+                      double *out, hipStream_t s);
+int g_apply_impl = 0;        // 0: LDS-DMA kernel (falls back to the register-staged one when it cannot run), 1: register-staged
+int g_apply_pd = 2;          // tuning knobs (vfem_debug_set): planes in flight, memory-skeleton diagnostic
+int g_apply_skeleton = 0;
+int g_apply_store = 0;
+
 void launch_apply_fast(const Dims &d, const double *Dm_host, const double *E, const double *u, const double *b,
                        const uint8_t *mask, int mode, double *out, hipStream_t s) {
     DmArgs dm;
@@ -263,10 +305,17 @@ void launch_apply_fast(const Dims &d, const double *Dm_host, const double *E, co
     if (d.NX >= 1024) nchunks = 16;
     const int ppc = (d.NX + nchunks - 1) / nchunks;
     dim3 blk(TZ, TY, 1), grd((d.NX + ppc - 1) / ppc, (d.NZ + TZ - 2) / (TZ - 1), (d.NY + TY - 2) / (TY - 1));
-    if (mode == 0)      k_apply_fast<0, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc);
-    else if (mode == 1) k_apply_fast<1, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc);
-    else if (mode == 2) k_apply_fast<2, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc);
-    else                k_apply_fast<0, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc);   // tuning variant
+    if (g_apply_skeleton) {
+        if (g_apply_pd == 2)      k_apply_fast<0, 1, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, g_apply_store);
+        else if (g_apply_pd == 3) k_apply_fast<0, 1, 3><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, g_apply_store);
+        else                      k_apply_fast<0, 1, 4><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, g_apply_store);
+    } else if (mode == 0) {
+        if (g_apply_pd == 2)      k_apply_fast<0, 2, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, g_apply_store);
+        else if (g_apply_pd == 3) k_apply_fast<0, 2, 3><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, g_apply_store);
+        else                      k_apply_fast<0, 2, 4><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, g_apply_store);
+    }
+    else if (mode == 1) k_apply_fast<1, 2, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, g_apply_store);
+    else                k_apply_fast<2, 2, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, g_apply_store);
     VFEM_HIP(hipGetLastError());
 }
 

@@ -1,0 +1,377 @@
+// k_apply_dma: the production stiffness apply with LDS-DMA staging.
+//
+// Same algorithm and tiling as k_apply_fast (kernels_apply.hip: mode-space element matrix, lanes = z, 8 waves = 8
+// element rows, block marches along x, one barrier per plane), but the node planes and the element moduli are
+// brought in by `global_load_lds_dwordx4` straight into a 4-deep LDS ring instead of through registers:
+//   * no VGPRs and no ds_write instructions are spent on staging,
+//   * three planes stay in flight behind a *counted* `s_waitcnt vmcnt(N)` + raw `s_barrier` (hipcc drains every
+//     ordinary load to vmcnt(0) once per plane in the register-staged version, which is what bounded it:
+//     its memory skeleton alone ran at 3 TB/s whatever the prefetch depth),
+//   * a plane is read one phase after the wait+barrier that retires it (MI355X_MICROARCH.md, two-waves item 7).
+// A DMA piece is 16 bytes on the absolute 16-byte grid of memory: a tile row (65 nodes = 1560 B) starts on an 8-byte
+// boundary, so its image starts at the aligned address at or 8 bytes below it and the consumer adds that one-double
+// shift (a parity that depends on the row and, when a plane holds an odd number of doubles, on the plane).  Aligned
+// pieces never straddle the 16-byte-aligned end of an allocation, so nothing outside the caller's buffers is read;
+// a row image starts at node max(k0, 0) so that no address precedes the array.
+#include "vfem_internal.h"
+
+namespace vfem {
+
+namespace dma {
+constexpr int TY = 8, TZ = 64;
+constexpr int ROW_D = 196;                  // doubles per staged node row (98 pieces)
+constexpr int U_PIECES = (TY + 1) * 98;     // 882
+constexpr int U_INSTR = 14;                 // 896 pieces of 16 B
+constexpr int E_INSTR = 5;                  // 8 rows x 33 pieces (32 + 1 for the alignment shift) = 264 <= 320
+constexpr int SLOT_BYTES = U_INSTR * 1024 + E_INSTR * 1024;   // 18432
+constexpr int RING = 4;
+constexpr int SS_DOUBLES = 9 * TY * TZ;     // one scatter buffer
+constexpr size_t LDS_BYTES = (size_t) RING * SLOT_BYTES + 2 * SS_DOUBLES * sizeof(double);
+}  // namespace dma
+
+struct DmArgs2 { double v[36]; };
+
+__device__ __forceinline__ void glds16(const void *g, void *l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) g,
+                                     (__attribute__((address_space(3))) void *) l, 16, 0, 0);
+}
+
+template <int CNT>   // CNT = LDS-DMA instructions this wave issues per plane (2 or 3)
+__device__ __forceinline__ void wait_plane(bool has_stores, bool steady) {
+    // retire the DMA of the oldest plane in flight; two newer planes (2 CNT instructions) and, in the steady
+    // state, the four output stores of the last two phases were issued after it
+    if (!steady) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+    if (has_stores) {
+        if (CNT == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    } else {
+        if (CNT == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
+}
+
+__global__ void __launch_bounds__(512, 2) k_apply_dma(Dims d, DmArgs2 dm, const double *__restrict__ E,
+                                                      const double *__restrict__ u, double *__restrict__ out,
+                                                      int planes_per_chunk, const char *u_last, const char *e_last) {
+    using namespace dma;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char *ring = smem;
+    double *sS = reinterpret_cast<double *>(smem + (size_t) RING * SLOT_BYTES);
+
+    const int tz = threadIdx.x, ty = threadIdx.y;      // ty is wave-uniform (64 x 8 block)
+    const int wave = ty;
+    const int k0 = blockIdx.y * (TZ - 1) - 1;
+    const int j0 = blockIdx.z * (TY - 1) - 1;
+    const int p0 = blockIdx.x * planes_per_chunk;
+    int p1 = p0 + planes_per_chunk - 1;
+    if (p1 > d.NX - 1) p1 = d.NX - 1;
+    if (p0 > d.NX - 1) return;
+    const int k0u = k0 < 0 ? 0 : k0;                   // first node column held by a staged row image
+    const int cshift = k0u - k0;                       // 0, or 1 in the first z tile
+
+    const int ej = j0 + ty, ek = k0 + tz;
+    const bool elem_ok = ej >= 0 && ej < d.ny && ek >= 0 && ek < d.nz;
+    const bool out_ok = ty >= 1 && tz >= 1 && ej < d.NY && ek < d.NZ;
+    const long long plane = (long long) d.NY * d.NZ;
+    const long long elayer = (long long) d.ny * d.nz;
+
+    // ---- DMA descriptors of this wave -----------------------------------------------------------
+    // addresses in units of doubles from address 0, so that parities are those of the absolute 16-byte grid
+    const long long ubase8 = (long long) (reinterpret_cast<uintptr_t>(u) >> 3);
+    const long long ebase8 = (long long) (reinterpret_cast<uintptr_t>(E) >> 3);
+    const int ppar = (int) ((3 * plane) & 1), epar = (int) (elayer & 1);       // parity added per plane / element layer
+    // u: instruction j moves pieces [64 j, 64 j + 64) of the (TY+1) x 98 piece image; this wave owns j = wave, wave + 8
+    long long ugo[2];          // double offset (from plane start) of this lane's row start + 2 q
+    int upar[2];               // parity of (ubase8 + row start) at plane 0
+    bool uhas[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int j = wave + 8 * s;
+        uhas[s] = j < U_INSTR;
+        const int P = 64 * j + tz;
+        int r = P / 98, q = P - r * 98;
+        if (r > TY) { r = TY; q = 97; }
+        int jj = j0 + r;
+        jj = jj < 0 ? 0 : (jj > d.NY - 1 ? d.NY - 1 : jj);
+        const long long rs = 3LL * ((long long) jj * d.NZ + k0u);
+        ugo[s] = rs + 2LL * q;
+        upar[s] = (int) ((ubase8 + rs) & 1);
+    }
+    // E: instruction e moves pieces [64 e, 64 e + 64) of the TY x 33 piece image (32 + 1 for the shift);
+    // e = 0,1 -> waves 6,7 (which own a single u instruction), e = 2,3,4 -> waves 3,4,5
+    const int eidx = wave == 6 ? 0 : (wave == 7 ? 1 : ((wave >= 3 && wave <= 5) ? wave - 1 : -1));
+    const bool ehas = eidx >= 0;
+    long long ego = 0;
+    int epar0 = 0;
+    const int k0e = k0u;                               // element columns start at max(k0, 0) as well
+    {
+        const int P = 64 * (eidx < 0 ? 0 : eidx) + tz;
+        int r = P / 33, q = P - r * 33;
+        if (r > TY - 1) { r = TY - 1; q = 32; }
+        int jj = j0 + r;
+        jj = jj < 0 ? 0 : (jj > d.ny - 1 ? d.ny - 1 : jj);
+        const long long rs = (long long) jj * d.nz + k0e;
+        ego = rs + 2LL * q;
+        epar0 = (int) ((ebase8 + rs) & 1);
+    }
+    const int cnt = (uhas[1] ? 2 : 1) + (ehas ? 1 : 0);          // 2,2,2,3,3,3,2,2
+    // parities of the rows this thread consumes (node rows ty, ty+1; element row ty)
+    int rpar[2], erpar;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        int jj = j0 + ty + s;
+        jj = jj < 0 ? 0 : (jj > d.NY - 1 ? d.NY - 1 : jj);
+        rpar[s] = (int) ((ubase8 + 3LL * ((long long) jj * d.NZ + k0u)) & 1);
+    }
+    {
+        int jj = ej < 0 ? 0 : (ej > d.ny - 1 ? d.ny - 1 : ej);
+        erpar = (int) ((ebase8 + (long long) jj * d.nz + k0e) & 1);
+    }
+
+    auto issue_plane = [&](int i) {                    // node plane i + element layer min(i, nx-1) -> ring slot i & 3
+        unsigned char *slot = ring + (size_t) (i & (RING - 1)) * SLOT_BYTES;
+        const int ip = i & ppar;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (uhas[s]) {
+                // aligned piece: one double below the row start when (row start + plane offset) is odd
+                const long long off = 3LL * i * plane + ugo[s] - ((upar[s] + ip) & 1);
+                const char *g = reinterpret_cast<const char *>(u + off);
+                g = g > u_last ? u_last : g;
+                glds16(g, slot + 1024 * (wave + 8 * s));
+            }
+        }
+        if (ehas) {
+            const int il = i < d.nx ? i : d.nx - 1;
+            const long long off = (long long) il * elayer + ego - ((epar0 + (il & epar)) & 1);
+            const char *g = reinterpret_cast<const char *>(E + off);
+            g = g > e_last ? e_last : g;
+            glds16(g, slot + U_INSTR * 1024 + 1024 * eidx);
+        }
+    };
+
+    // steady-state issue: per instruction slot two running pointers (planes of even / odd step parity), each advanced
+    // by two plane strides per use; the alignment shift alternates with the plane only when a plane holds an odd number
+    // of doubles, so it is folded into the two pointers once.  Only the last plane of the grid needs the end clamp.
+    const char *up_run[2][2];
+    const char *ep_run[2];
+    auto init_running = [&](int i_first) {            // i_first = plane issued by the first loop phase (step parity 0)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = i_first + k;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                up_run[k][s2] = reinterpret_cast<const char *>(u + (3LL * i * plane + ugo[s2] - ((upar[s2] + (i & ppar)) & 1)));
+            ep_run[k] = reinterpret_cast<const char *>(E + ((long long) i * elayer + ego - ((epar0 + (i & epar)) & 1)));
+        }
+    };
+    auto issue_running = [&](int i, int k) {           // k = step parity (compile-time after unrolling)
+        unsigned char *slot = ring + (size_t) (i & (RING - 1)) * SLOT_BYTES;
+        const bool last = (i >= d.NX - 1);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (uhas[s2]) {
+                const char *g = up_run[k][s2];
+                if (last) g = g > u_last ? u_last : g;
+                glds16(g, slot + 1024 * (wave + 8 * s2));
+                up_run[k][s2] += 48LL * plane;         // two planes of 24 * plane bytes
+            }
+        }
+        if (ehas) {
+            const char *g = ep_run[k];
+            if (i >= d.nx - 1) {                       // last layers: clamp the layer index and the address
+                const long long off = (long long) (d.nx - 1) * elayer + ego - ((epar0 + ((d.nx - 1) & epar)) & 1);
+                g = reinterpret_cast<const char *>(E + off);
+                g = g > e_last ? e_last : g;
+            }
+            glds16(g, slot + U_INSTR * 1024 + 1024 * eidx);
+            ep_run[k] += 16LL * elayer;
+        }
+    };
+
+    // ---- per-thread read offsets into a slot (doubles) ----------------------------------------
+    int c0 = tz - cshift, c1 = tz + 1 - cshift;
+    c0 = c0 < 0 ? 0 : c0; c1 = c1 < 0 ? 0 : c1;
+    const int o00 = ty * ROW_D + 3 * c0, o01 = ty * ROW_D + 3 * c1;
+    const int o10 = (ty + 1) * ROW_D + 3 * c0, o11 = (ty + 1) * ROW_D + 3 * c1;
+    int ce = tz - cshift; ce = ce < 0 ? 0 : ce;
+    const int oE0 = (U_INSTR * 1024) / 8 + ty * 66 + ce;       // element rows hold 33 pieces = 66 doubles
+
+    auto face_modes_at = [&](double f[4][3], const double *su, int q00, int q01, int q10, int q11) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double a = su[q00 + c], bb = su[q01 + c], cc = su[q10 + c], dd = su[q11 + c];
+            const double s0 = a + bb, d0 = bb - a, s1 = cc + dd, d1 = dd - cc;
+            f[0][c] = s0 + s1; f[1][c] = d0 + d1; f[2][c] = s1 - s0; f[3][c] = d1 - d0;
+        }
+    };
+    auto scatter_face = [&](const double acc[4][3], double wa[3], int buf) {
+        double *sB = sS + buf * SS_DOUBLES, *sC = sB + 3 * TY * TZ, *sD = sC + 3 * TY * TZ;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double p = acc[0][c] - acc[2][c], q = acc[1][c] - acc[3][c];
+            const double r = acc[0][c] + acc[2][c], t = acc[1][c] + acc[3][c];
+            wa[c] = p - q;
+            sB[(c * TY + ty) * TZ + tz] = p + q;
+            sC[(c * TY + ty) * TZ + tz] = r - t;
+            sD[(c * TY + ty) * TZ + tz] = r + t;
+        }
+    };
+    auto emit_plane = [&](int i, const double wa[3], int buf) {
+        if (!out_ok) return;
+        const double *sB = sS + buf * SS_DOUBLES, *sC = sB + 3 * TY * TZ, *sD = sC + 3 * TY * TZ;
+        const long long n = (long long) i * plane + (long long) ej * d.NZ + ek;
+        double w[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            w[c] = wa[c] + sB[(c * TY + ty) * TZ + tz - 1] + sC[(c * TY + ty - 1) * TZ + tz] + sD[(c * TY + ty - 1) * TZ + tz - 1];
+        out[3 * n] = w[0]; out[3 * n + 1] = w[1]; out[3 * n + 2] = w[2];
+    };
+
+    double fold[4][3], carry[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) carry[q][c] = 0.0;
+
+    auto face_modes = [&](double f[4][3], const double *su, int i) {
+        const int ip = i & ppar;
+        const int s0r = (rpar[0] + ip) & 1, s1r = (rpar[1] + ip) & 1;   // one-double shift of the aligned row images
+        face_modes_at(f, su, o00 + s0r, o01 + s0r, o10 + s1r, o11 + s1r);
+    };
+    auto process = [&](double Ee, const double *su, const int q[4], int buf, double wa[3]) {
+        if (!elem_ok) Ee = 0.0;
+        double fnew[4][3];
+        face_modes_at(fnew, su, q[0], q[1], q[2], q[3]);
+        double m[8][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                m[q][c] = fold[q][c] + fnew[q][c];
+                m[4 + q][c] = fnew[q][c] - fold[q][c];
+                fold[q][c] = fnew[q][c];
+            }
+        double qv[8][3];
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) qv[p][c] = (p == 0) ? 0.0 : dm.v[3 * p + c] * m[p][c];
+        {
+            int idx = 24;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int bb = a + 1; bb < 3; ++bb) {
+                    const int t = 3 - a - bb;
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                        for (int type = 0; type < 2; ++type) {
+                            const int ba = 1 << (2 - a), bbit = 1 << (2 - bb), bt = 1 << (2 - t);
+                            const int pa = (type == 0 ? ba : bbit) | (pt ? bt : 0);
+                            const int pb = (type == 0 ? bbit : ba) | (pt ? bt : 0);
+                            const double v = dm.v[idx++];
+                            qv[pa][a] = fma(v, m[pb][bb], qv[pa][a]);
+                            qv[pb][bb] = fma(v, m[pa][a], qv[pb][bb]);
+                        }
+                }
+        }
+        double acc[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                acc[q][c] = fma(Ee, qv[q][c] - qv[4 + q][c], carry[q][c]);
+                carry[q][c] = Ee * (qv[q][c] + qv[4 + q][c]);
+            }
+        scatter_face(acc, wa, buf);
+    };
+
+    const int i_start = p0 > 0 ? p0 - 1 : 0;
+    const int i_end = p1 + 1 < d.NX - 1 ? p1 + 1 : d.NX - 1;
+
+    // ---- prologue: planes i_start .. i_start+3 issued, all retired once ---------------------------
+    issue_plane(i_start);
+    if (i_start + 1 <= i_end) issue_plane(i_start + 1);
+    if (i_start + 2 <= i_end) issue_plane(i_start + 2);
+    if (i_start + 3 <= i_end) issue_plane(i_start + 3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+        const double *su = reinterpret_cast<const double *>(ring + (size_t) (i_start & (RING - 1)) * SLOT_BYTES);
+        face_modes(fold, su, i_start);
+    }
+    auto e_offset = [&](int i) { return oE0 + ((erpar + (i & epar)) & 1); };
+    double Eprev = reinterpret_cast<const double *>(ring + (size_t) (i_start & (RING - 1)) * SLOT_BYTES)[e_offset(i_start)];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // slot i_start may now be overwritten (plane i_start+4)
+
+    // read offsets for the two step parities (the alignment shift alternates with the plane when 3*plane is odd)
+    int qoff[2][4], eoff2[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = i_start + 1 + k, ip = i & ppar;
+        const int s0r = (rpar[0] + ip) & 1, s1r = (rpar[1] + ip) & 1;
+        qoff[k][0] = o00 + s0r; qoff[k][1] = o01 + s0r; qoff[k][2] = o10 + s1r; qoff[k][3] = o11 + s1r;
+        eoff2[k] = oE0 + ((erpar + (i & epar)) & 1);
+    }
+    init_running(i_start + 4);
+    const bool has_stores = ty >= 1 && ej < d.NY;
+
+    int buf = 0, phase = 0;
+    auto run_phase = [&](int ii, int k) {
+        if (ii + 3 <= i_end) issue_running(ii + 3, k); // slot (ii+3)&3 held plane ii-1: every wave passed a barrier after reading it
+        const double *su = reinterpret_cast<const double *>(ring + (size_t) (ii & (RING - 1)) * SLOT_BYTES);
+        double wa[3];
+        const double Enext = su[eoff2[k]];             // modulus of layer ii, used in the next phase
+        process(Eprev, su, qoff[k], buf, wa);
+        Eprev = Enext;
+        if (ii + 1 <= i_end) {
+            // counted wait: after plane ii+1's DMA this wave issued the stores of phases ii-2 and ii-1 and the DMA of
+            // planes ii+2 and ii+3; outside that steady state (start / end of the chunk) drain everything
+            const bool steady = (phase >= 2) && (ii + 3 <= i_end) && (ii - 3 >= p0);
+            if (cnt == 2) wait_plane<2>(has_stores, steady); else wait_plane<3>(has_stores, steady);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ii - 1 >= p0) emit_plane(ii - 1, wa, buf);
+        buf ^= 1;
+        ++phase;
+    };
+    for (int ii = i_start + 1; ii <= i_end; ii += 2) {
+        run_phase(ii, 0);
+        if (ii + 1 <= i_end) run_phase(ii + 1, 1);
+    }
+    if (p1 == d.NX - 1) {
+        double wa[3];
+        scatter_face(carry, wa, buf);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        emit_plane(d.NX - 1, wa, buf);
+    }
+}
+
+bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, const double *E_alloc_end, const double *u,
+                      double *out, hipStream_t s) {
+    using namespace dma;
+    const char *u_end = reinterpret_cast<const char *>(u + 3 * d.nn);
+    const char *e_end = reinterpret_cast<const char *>(E_alloc_end);
+    if ((reinterpret_cast<uintptr_t>(u) & 7u) || (reinterpret_cast<uintptr_t>(E) & 7u)) return false;
+    DmArgs2 dm;
+    for (int q = 0; q < 36; ++q) dm.v[q] = Dm_host[q];
+    int nchunks = d.NX >= 64 ? 8 : (d.NX >= 16 ? 4 : 1);
+    if (d.NX >= 1024) nchunks = 16;
+    const int ppc = (d.NX + nchunks - 1) / nchunks;
+    dim3 blk(TZ, TY, 1), grd((d.NX + ppc - 1) / ppc, (d.NZ + TZ - 2) / (TZ - 1), (d.NY + TY - 2) / (TY - 1));
+    static bool attr = false;
+    if (!attr) {
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
+        attr = true;
+    }
+    // last admissible (aligned) piece: the one holding the last byte of each array
+    auto last_piece = [](const char *end) { return reinterpret_cast<const char *>((reinterpret_cast<uintptr_t>(end) - 1) & ~(uintptr_t) 15); };
+    k_apply_dma<<<grd, blk, LDS_BYTES, s>>>(d, dm, E, u, out, ppc, last_piece(u_end), last_piece(e_end));
+    VFEM_HIP(hipGetLastError());
+    return true;
+}
+
+}  // namespace vfem

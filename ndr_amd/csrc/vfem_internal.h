@@ -75,6 +75,10 @@ void launch_apply_stencil(const Dims &d, const double *S, const double *u, const
 // production level-0 apply (symmetry-reduced, x-marching)
 void launch_apply_fast(const Dims &d, const double *Dm_host, const double *E, const double *u, const double *b,
                        const uint8_t *mask, int mode, double *out, hipStream_t s);
+// LDS-DMA version of the plain apply (mode 0); returns false when it must not be used for these buffers
+bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, const double *E_alloc_end, const double *u,
+                      double *out, hipStream_t s);
+extern int g_apply_impl;
 
 // colours are processed in the reference order (global parity); `xparity` = global x-parity of local plane 0,
 // [first, first+count) selects a sub-range of the 8 colours (half sweeps between halo exchanges)
