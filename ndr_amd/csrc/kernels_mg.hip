@@ -379,20 +379,38 @@ void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const doubl
 // Replaces the block-CSC matrix of TPS::updateBlockK (TPS.hh:649-720): on a regular grid the
 // column indices are implicit.
 // ------------------------------------------------------------------------------------------
+// Colour-major stencil storage: the nodes of one Gauss-Seidel colour (parity class) are contiguous, so the
+// colour sweeps (lanes = every other node in z) read full cache lines.  Entry (nb, q) of node (i,j,k) lives at
+//   St[ 243 * nodes_in_earlier_colours + (nb*9 + q) * nodes_of_this_colour + colour_local_index ].
+__device__ __forceinline__ void cm_index(const Dims &d, int i, int j, int k, long long &base, long long &cnt) {
+    const int ci = i & 1, cj = j & 1, ck = k & 1;
+    const long long nx[2] = {(d.NX + 1) >> 1, d.NX >> 1}, ny[2] = {(d.NY + 1) >> 1, d.NY >> 1}, nz[2] = {(d.NZ + 1) >> 1, d.NZ >> 1};
+    cnt = nx[ci] * ny[cj] * nz[ck];
+    long long before = 0;
+    const int c = ci * 4 + cj * 2 + ck;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (q < c) before += nx[(q >> 2) & 1] * ny[(q >> 1) & 1] * nz[q & 1];
+    base = 243 * before + ((long long) (i >> 1) * ny[cj] + (j >> 1)) * nz[ck] + (k >> 1);
+}
+
 template <bool WITH_M>
 __device__ __forceinline__ void stencil_node(const Dims &d, const double *__restrict__ St, const double *__restrict__ u,
                                              int i, int j, int k, long long n, double S[3], double M[9]) {
     S[0] = S[1] = S[2] = 0.0;
+    long long sbase, scnt;
+    cm_index(d, i, j, k, sbase, scnt);
+    (void) n;
     for (int nb = 0; nb < 27; ++nb) {
         const int di = nb / 9 - 1, dj = (nb / 3) % 3 - 1, dk = nb % 3 - 1;
         const int ii = i + di, jj = j + dj, kk = k + dk;
         if (ii < 0 || ii >= d.NX || jj < 0 || jj >= d.NY || kk < 0 || kk >= d.NZ) continue;
         const long long m = nidx(d, ii, jj, kk);
         const double u0 = u[3 * m], u1 = u[3 * m + 1], u2 = u[3 * m + 2];
-        const double *a = St + (long long) nb * 9 * d.nn + n;
+        const double *a = St + sbase + (long long) nb * 9 * scnt;
         double A[9];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) A[q] = a[(long long) q * d.nn];
+        for (int q = 0; q < 9; ++q) A[q] = a[(long long) q * scnt];
 #pragma unroll
         for (int r = 0; r < 3; ++r) S[r] += A[3 * r] * u0 + A[3 * r + 1] * u1 + A[3 * r + 2] * u2;
         if (WITH_M && nb == 13) {
@@ -660,8 +678,10 @@ __global__ void __launch_bounds__(256) k_stencil_build(Dims d, const double *__r
             }
         }
     }
+    long long sbase, scnt;
+    cm_index(d, i, j, k, sbase, scnt);
 #pragma unroll
-    for (int q = 0; q < 9; ++q) St[((long long) nb * 9 + q) * d.nn + n] = A[q];
+    for (int q = 0; q < 9; ++q) St[sbase + ((long long) nb * 9 + q) * scnt] = A[q];
 }
 
 void launch_stencil_from_ke(const Dims &d, const double *Ke, double *S, hipStream_t s) {
@@ -692,10 +712,12 @@ __global__ void __launch_bounds__(256) k_dense_from_stencil(Dims d, const double
     if (ii < 0 || ii >= d.NX || jj < 0 || jj >= d.NY || kk < 0 || kk >= d.NZ) return;
     const long long m = nidx(d, ii, jj, kk);
     const long long N3 = 3 * d.nn;
+    long long sbase, scnt;
+    cm_index(d, i, j, k, sbase, scnt);
     const uint8_t mn = mask[n], mm = mask[m];
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) {
-            double v = St[((long long) nb * 9 + 3 * r + c) * d.nn + n];
+            double v = St[sbase + ((long long) nb * 9 + 3 * r + c) * scnt];
             const bool fr = (mn >> r) & 1, fc = (mm >> c) & 1;
             if (fr || fc) v = (n == m && r == c) ? 1.0 : 0.0;
             A[(3 * n + r) * N3 + 3 * m + c] = v;
