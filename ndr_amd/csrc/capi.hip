@@ -141,9 +141,9 @@ void vfem_sim::update_k0() {
         if (!used[q] && std::fabs(Dfull[q]) > 1e-13 * maxabs) fast_ok = false;
     dK0.alloc(576);
     VFEM_HIP(hipMemcpy(dK0.p, K0, sizeof(K0), hipMemcpyHostToDevice));
-    double tab[36 * 24];
+    double tab[72 * 12];
     vfem::build_gs_table(K0, tab);
-    dGsTab.alloc(36 * 24);
+    dGsTab.alloc(72 * 12);
     VFEM_HIP(hipMemcpy(dGsTab.p, tab, sizeof(tab), hipMemcpyHostToDevice));
 }
 

@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(256) k_gs_color_mf(Dims d, const double *__res
 // K0[rows of n] . u_e; the element moduli enter once at the end (S = sum_e E_e T_e, M = sum_e E_e K0_nn).
 // The next row's loads are in flight while the current row is consumed.
 // ------------------------------------------------------------------------------------------
-constexpr int GS_ROWBUF = 392;   // 129 nodes x 3 doubles (+ pad)
+constexpr int GS_ROWBUF = 448;   // 129 nodes x 3 doubles = 387, padded to 7 x 64 so that every staging store is unconditional
 
 typedef double d8_t __attribute__((ext_vector_type(8)));
 
@@ -195,11 +195,21 @@ __device__ __forceinline__ void swait3(d8_t &a, d8_t &b, d8_t &c) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c));
 }
 
+typedef double d4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ d4_t sload4(const double *p, int byte_off) {
+    d4_t r;
+    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(r) : "s"(p), "s"(byte_off));
+    return r;
+}
+__device__ __forceinline__ void swait2(d8_t &a, d4_t &b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b));
+}
+
 // Host-side layout of the coefficient table consumed by k_gs_rows_mf0 (same loop nest as the kernel):
-// 32 half-groups of 24 doubles: [mz][r][c] = K0[(3 ln + r)*24 + 3 lm + c] for the two nodes mz of the element
-// pair, padded to 24; then 4 groups of 24 doubles with the diagonal blocks of local nodes 2g, 2g+1.
-void build_gs_table(const double *K0, double *tab /* 36*24 */) {
-    int hg = 0;
+// 64 groups of 12 doubles: [r][c] = K0[(3 ln + r)*24 + 3 lm + c] for one (incident element, element node) pair,
+// padded to 12; then 8 groups of 12 doubles with the diagonal block of local node ln = group index.
+void build_gs_table(const double *K0, double *tab /* 72*12 */) {
+    int g = 0;
     for (int r9 = 0; r9 < 9; ++r9) {
         const int dx = r9 / 3 - 1, dy = r9 % 3 - 1;
         for (int di = 0; di < 2; ++di)
@@ -213,22 +223,18 @@ void build_gs_table(const double *K0, double *tab /* 36*24 */) {
                             for (int mz = 0; mz < 2; ++mz) {
                                 const int lm = mx * 4 + my * 2 + mz;
                                 for (int r = 0; r < 3; ++r)
-                                    for (int c = 0; c < 3; ++c)
-                                        tab[hg * 24 + mz * 9 + r * 3 + c] = K0[(3 * ln + r) * 24 + 3 * lm + c];
+                                    for (int c = 0; c < 3; ++c) tab[g * 12 + r * 3 + c] = K0[(3 * ln + r) * 24 + 3 * lm + c];
+                                for (int q = 9; q < 12; ++q) tab[g * 12 + q] = 0.0;
+                                ++g;
                             }
-                            for (int q = 18; q < 24; ++q) tab[hg * 24 + q] = 0.0;
-                            ++hg;
                         }
                     }
             }
     }
-    for (int g = 0; g < 4; ++g) {
-        for (int h = 0; h < 2; ++h) {
-            const int ln = 2 * g + h;
-            for (int r = 0; r < 3; ++r)
-                for (int c = 0; c < 3; ++c) tab[(32 + g) * 24 + h * 9 + r * 3 + c] = K0[(3 * ln + r) * 24 + 3 * ln + c];
-        }
-        for (int q = 18; q < 24; ++q) tab[(32 + g) * 24 + q] = 0.0;
+    for (int ln = 0; ln < 8; ++ln) {
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) tab[(64 + ln) * 12 + r * 3 + c] = K0[(3 * ln + r) * 24 + 3 * ln + c];
+        for (int q = 9; q < 12; ++q) tab[(64 + ln) * 12 + q] = 0.0;
     }
 }
 
@@ -266,7 +272,11 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
         int gx = x + r9 / 3 - 1, gy = y + r9 % 3 - 1;
         gx = gx < 0 ? 0 : (gx > d.NX - 1 ? d.NX - 1 : gx);
         gy = gy < 0 ? 0 : (gy > d.NY - 1 ? d.NY - 1 : gy);
-        const double *rowp = u + 3 * (((long long) gx * d.NY + gy) * d.NZ + zlo);
+        // the row is the same for the whole wave: keep its base in SGPRs so that the loads use scalar base + 32-bit lane offset
+        const long long ro = 3 * (((long long) gx * d.NY + gy) * d.NZ + zlo);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) (ro & 0xffffffffLL));
+        const int hi = __builtin_amdgcn_readfirstlane((int) (ro >> 32));
+        const double *rowp = u + (((long long) hi << 32) | (long long) lo);
 #pragma unroll
         for (int s7 = 0; s7 < 7; ++s7) pre[s7] = rowp[qc[s7]];
     };
@@ -276,10 +286,7 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
     for (int r9 = 0; r9 < 9; ++r9) {
         const int dx = r9 / 3 - 1, dy = r9 % 3 - 1;
 #pragma unroll
-        for (int s7 = 0; s7 < 7; ++s7) {
-            const int q = lane + 64 * s7;
-            if (q < GS_ROWBUF) buf[q] = pre[s7];
-        }
+        for (int s7 = 0; s7 < 7; ++s7) buf[lane + 64 * s7] = pre[s7];
         if (r9 + 1 < 9) issue(r9 + 1);
         __builtin_amdgcn_wave_barrier();
         double u3[3][3];
@@ -301,23 +308,24 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
                         if (dj - 1 + my != dy) continue;
 #pragma unroll
                         for (int dk = 0; dk < 2; ++dk) {
-                            d8_t k0 = sload8(tab, hg * 192), k1 = sload8(tab, hg * 192 + 64), k2 = sload8(tab, hg * 192 + 128);
-                            ++hg;
-                            swait3(k0, k1, k2);
-                            double kk[24];
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) { kk[q] = k0[q]; kk[8 + q] = k1[q]; kk[16 + q] = k2[q]; }
                             const int sl = di * 4 + dj * 2 + dk;
 #pragma unroll
                             for (int mz = 0; mz < 2; ++mz) {
+                                d8_t k0 = sload8(tab, hg * 96);
+                                d4_t k1 = sload4(tab, hg * 96 + 64);
+                                ++hg;
+                                swait2(k0, k1);
                                 const int n3 = dk + mz;            // dz + 1
 #pragma unroll
                                 for (int r = 0; r < 3; ++r)
 #pragma unroll
-                                    for (int c = 0; c < 3; ++c) T[sl][r] = fma(kk[mz * 9 + r * 3 + c], u3[n3][c], T[sl][r]);
+                                    for (int c = 0; c < 3; ++c) {
+                                        const int q = r * 3 + c;
+                                        T[sl][r] = fma(q < 8 ? k0[q < 8 ? q : 0] : k1[0], u3[n3][c], T[sl][r]);
+                                    }
+                                // pin: these FMAs retire before the next coefficient load is issued
+                                asm volatile("" : "+v"(T[sl][0]), "+v"(T[sl][1]), "+v"(T[sl][2]));
                             }
-                            // pin: the FMAs of this half-group retire before the next coefficient load is issued
-                            asm volatile("" : "+v"(T[sl][0]), "+v"(T[sl][1]), "+v"(T[sl][2]));
                         }
                     }
             }
@@ -327,20 +335,25 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
 #pragma unroll
     for (int q = 0; q < 9; ++q) M[q] = 0.0;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        d8_t k0 = sload8(tab, (32 + g) * 192), k1 = sload8(tab, (32 + g) * 192 + 64), k2 = sload8(tab, (32 + g) * 192 + 128);
-        swait3(k0, k1, k2);
-        double kk[24];
+    for (int g = 0; g < 8; ++g) {
+        d8_t k0 = sload8(tab, (64 + g) * 96);
+        d4_t k1 = sload4(tab, (64 + g) * 96 + 64);
+        swait2(k0, k1);
+        double kk[9];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { kk[q] = k0[q]; kk[8 + q] = k1[q]; kk[16 + q] = k2[q]; }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ln = 2 * g + h;                    // local index of the node in its element
+        for (int q = 0; q < 8; ++q) kk[q] = k0[q];
+        kk[8] = k1[0];
+        {
+            const int h = 0;
+            const int ln = g;                            // local index of the node in its element
             const int sl = 7 - ln;                       // slot (di,dj,dk) = complement of ln
             const int di = (sl >> 2) & 1, dj = (sl >> 1) & 1, dk = sl & 1;
             const int ex = x - 1 + di, ey = y - 1 + dj, ez = z - 1 + dk;
             const bool ok = ex >= 0 && ex < d.nx && ey >= 0 && ey < d.ny && ez >= 0 && ez < d.nz;
-            const double Ee = ok ? E[eidx(d, ex < 0 ? 0 : ex, ey < 0 ? 0 : ey, ez < 0 ? 0 : ez)] : 0.0;
+            const int exc = ex < 0 ? 0 : (ex > d.nx - 1 ? d.nx - 1 : ex), eyc = ey < 0 ? 0 : (ey > d.ny - 1 ? d.ny - 1 : ey);
+            const int ezc = ez < 0 ? 0 : (ez > d.nz - 1 ? d.nz - 1 : ez);
+            const double Ev = E[eidx(d, exc, eyc, ezc)];          // unconditional load, masked afterwards
+            const double Ee = ok ? Ev : 0.0;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 S[r] = fma(Ee, T[sl][r], S[r]);

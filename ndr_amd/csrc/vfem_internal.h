@@ -84,7 +84,7 @@ extern int g_apply_impl;
 // [first, first+count) selects a sub-range of the 8 colours (half sweeps between halo exchanges)
 void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *gs_tab, const double *E, double *u,
                         const double *b, const uint8_t *mask, int forward, int xparity, int first, int count, hipStream_t s);
-void build_gs_table(const double *K0, double *tab /* 36*24 doubles */);
+void build_gs_table(const double *K0, double *tab /* 72*12 doubles */);
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
                              int forward, int xparity, int first, int count, hipStream_t s);
 
