@@ -1,0 +1,107 @@
+"""Driver-level mirror of the reference's ``fem.py`` for the accelerated path: the ground-truth OC loop
+(``fem.ground_truth_topopt``, fem.py:20-106) and the autograd bridge used by train_xdg
+(``fem.VoxelFEMFunction``, fem.py:109-134), on top of ``ndr_amd.pyVoxelFEM``.  Plotting / .vtr export of the
+reference drivers is out of scope; everything numerical keeps the reference's call sequence and its
+hard-coded settings (E0 = 1, Emin = 1e-4, tol 1e-4, one FMG cycle per CG iteration, 2+2 sweeps)."""
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.autograd as autograd
+
+from . import pyVoxelFEM
+
+
+class _History:
+    def __init__(self):
+        self.objective = []
+
+
+class _ProblemObj:
+    def __init__(self, top):
+        self.problem = top
+        self.history = _History()
+        self.beta_interval = self.beta_scaler = self.radius_interval = self.radius_scaler = None
+
+
+def initializeTensorProductSimulator(orderFEM, domainCorners, numberElements, uniformDensity, E0, Emin, SIMPExp,
+                                     materialPath, bcsPath):
+    """VoxelFEM/python/helpers/ipopt_helpers.py:7-15"""
+    tps = pyVoxelFEM.TensorProductSimulator(orderFEM, domainCorners, numberElements)
+    tps.readMaterial(materialPath)
+    tps.setUniformDensities(uniformDensity)
+    tps.applyDisplacementsAndLoadsFromFile(bcsPath)
+    tps.E_0 = E0
+    tps.E_min = Emin
+    tps.gamma = SIMPExp
+    return tps
+
+
+def ground_truth_topopt(MATERIAL_PATH, BC_PATH, orderFEM, domainCorners, gridDimensions, SIMPExponent, maxVolume,
+                        optimizer, multigrid_levels, use_multigrid=True, adaptive_filtering=[1, 1, 1, 1],
+                        max_iter=100, init=None, obj_history=False, verbose=True, **kwargs):
+    """fem.ground_truth_topopt (fem.py:20-106), optimizer 'OC' only (the L-BFGS branch needs cyipopt)."""
+    E0, Emin = 1, 1e-4                                             # fem.py:31-32 (the JSON values are ignored)
+    constraints = [pyVoxelFEM.TotalVolumeConstraint(maxVolume)]
+    filters = [pyVoxelFEM.SmoothingFilter(), pyVoxelFEM.ProjectionFilter()]
+    domain = [np.asarray(domainCorners[0], dtype=np.float64), np.asarray(domainCorners[1], dtype=np.float64)]
+    tps = initializeTensorProductSimulator(orderFEM, domain, gridDimensions, maxVolume, E0, Emin, SIMPExponent,
+                                           MATERIAL_PATH, BC_PATH)
+    if use_multigrid:
+        objective = pyVoxelFEM.MultigridComplianceObjective(tps.multigridSolver(multigrid_levels))
+    else:
+        objective = pyVoxelFEM.ComplianceObjective(tps)
+    top = pyVoxelFEM.TopologyOptimizationProblem(tps, objective, constraints, filters)
+    problemObj = _ProblemObj(top)
+    if adaptive_filtering is not None:
+        (problemObj.beta_interval, problemObj.beta_scaler, problemObj.radius_interval,
+         problemObj.radius_scaler) = adaptive_filtering
+    if init is not None:
+        init = np.asarray(init.detach().cpu().numpy() if isinstance(init, torch.Tensor) else init, dtype=np.float64)
+        top.setVars(init.flatten())
+    if use_multigrid:
+        objective.tol = 1e-4                                       # fem.py:64-70
+        objective.mgIterations = 1
+        objective.fullMultigrid = True
+        objective.zeroInit = False
+        objective.mgSmoothingIterations = 2
+    if optimizer != 'OC':
+        raise ValueError('Optimizer {} is unknown or not implemented.'.format(optimizer))
+    oco = pyVoxelFEM.OCOptimizer(top)
+    top.setVars(tps.getDensities())
+    iter_start_time = 0
+    for idx in range(max_iter):
+        iter_time = time.perf_counter() - iter_start_time
+        objective_value = 2.0 * top.evaluateObjective()
+        problemObj.history.objective.append(objective_value)
+        if verbose:
+            sys.stderr.write('Total Steps: {:d}, Runtime: {:.1f}, Compliance loss {:.6f}\n'.format(idx, iter_time, objective_value))
+        iter_start_time = time.perf_counter()
+        oco.step()
+    x0 = tps.getDensities()
+    density_binary = (x0 > 0.5) * 1.0                              # utils.compute_binary_compliance_loss
+    top.setVars(density_binary.astype(np.float64))
+    binary_objective = 2.0 * top.evaluateObjective()
+    top.setVars(x0)
+    out = (tps if len(orderFEM) == 3 else tps.getDensities(), 2.0 * top.evaluateObjective(), binary_objective)
+    return out + (problemObj.history.objective,) if obj_history else out
+
+
+class VoxelFEMFunction(autograd.Function):
+    """fem.VoxelFEMFunction (fem.py:109-134): compliance of the predicted densities as an autograd node.  Densities
+    may live on the GPU; the sensitivity is returned in float32 on the input's device, as the reference does."""
+
+    @staticmethod
+    def forward(ctx, densities, top):
+        dev = densities.device
+        top.setVars(densities.detach().to(torch.float64).cpu().numpy())
+        output_objective = 2.0 * top.evaluateObjective()
+        grad = torch.from_numpy(top.evaluateObjectiveGradient().astype(np.float32)).to(dev)
+        ctx.save_for_backward(grad)
+        return torch.tensor(output_objective, device=dev).float()
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (grad,) = ctx.saved_tensors
+        return grad * grad_output, None
