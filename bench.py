@@ -177,7 +177,7 @@ def main():
             traffic = t.get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "achieved": ab / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ab / kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "vfem::k_apply_fast", "algorithmic_bytes_per_launch": ab, "kernel_ms": kernel_s * 1e3}
+                "kernel": "vfem::k_apply_dma", "algorithmic_bytes_per_launch": ab, "kernel_ms": kernel_s * 1e3}
     del out
 
     result = {
