@@ -150,6 +150,17 @@ int vfem_mg_pcg(vfem_mg *mg, double *x, const double *b, int max_iter, double to
                 vfem_residual_cb residual_cb, void *cb_user,
                 int *iterations_out_host, double *relres_out_host, void *stream);
 
+/* ---- design-update path, element-grid arrays [n0][n1][n2] fp64 (2-D grids: n2 = 1) ----
+ * SmoothingFilter apply / backprop (TopologyOptimizationFilter.hh:105-162; transpose != 0 => A^T), ProjectionFilter apply /
+ * backprop (:55-79), mean for TotalVolumeConstraint (TopologyOptimizationConstraint.hh:21-34), and the OC candidate step
+ * clip(x0 sqrt(dJ/(dc lambda)), max(x0-m,0), min(x0+m,1)) of OCOptimizer::step (OptimalityCriterion.hh:47-50). */
+int vfem_box_filter(const int64_t n_host[3], int radius, const double *in, double *out, int transpose, void *stream);
+int vfem_projection(int64_t n, double beta, const double *x, double *out, void *stream);
+int vfem_projection_backprop(int64_t n, double beta, const double *g, const double *vars, double *out, void *stream);
+int vfem_oc_candidate(int64_t n, const double *x0, const double *dJ, const double *dc, double lambda, double move, double *out,
+                      void *stream);
+int vfem_mean(int64_t n, const double *x, double *mean_host, void *stream);
+
 /* ---- Fourier-feature MLP density field: networks.MLP (networks.py:128-185), out_features = 1 ----
  * n_layers counts Linear layers as the reference does: Linear(2 es, nn), (n_layers - 2) x Linear(nn, nn), Linear(nn, 1).
  * Weights are handed over as fp32 HOST arrays in torch layout ([out][in] row-major) and converted once:

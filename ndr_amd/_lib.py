@@ -69,6 +69,11 @@ SIGNATURES = {
     "vfem_mg_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vfem_mg_pcg": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_int, c_int,
                             RESIDUAL_CB, c_void_p, POINTER(c_int), POINTER(c_double), c_void_p]),
+    "vfem_box_filter": (c_int, [POINTER(c_int64), c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "vfem_projection": (c_int, [c_int64, c_double, c_void_p, c_void_p, c_void_p]),
+    "vfem_projection_backprop": (c_int, [c_int64, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vfem_oc_candidate": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_double, c_double, c_void_p, c_void_p]),
+    "vfem_mean": (c_int, [c_int64, c_void_p, POINTER(c_double), c_void_p]),
     "vfem_mlp_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int]),
     "vfem_mlp_destroy": (c_int, [c_void_p]),
     "vfem_mlp_load_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float]),

@@ -769,6 +769,37 @@ int vfem_mg_pcg(vfem_mg *mg, double *x, const double *b, int max_iter, double to
     VFEM_CATCH
 }
 
+// ---- design-update path ----
+int vfem_box_filter(const int64_t n[3], int radius, const double *in, double *out, int transpose, void *stream) {
+    VFEM_TRY
+    if (radius < 0) throw Error("negative filter radius");
+    launch_box_filter((int) n[0], (int) n[1], (int) n[2], radius, in, out, transpose, S(stream));
+    VFEM_CATCH
+}
+int vfem_projection(int64_t n, double beta, const double *x, double *out, void *stream) {
+    VFEM_TRY
+    if (!(beta > 0)) throw Error("Beta parameter has to be positive (received beta = " + std::to_string(beta) + ")");
+    launch_projection(n, beta, x, nullptr, out, 0, S(stream));
+    VFEM_CATCH
+}
+int vfem_projection_backprop(int64_t n, double beta, const double *g, const double *vars, double *out, void *stream) {
+    VFEM_TRY launch_projection(n, beta, vars, g, out, 1, S(stream)); VFEM_CATCH
+}
+int vfem_oc_candidate(int64_t n, const double *x0, const double *dJ, const double *dc, double lambda, double move, double *out,
+                      void *stream) {
+    VFEM_TRY launch_oc_candidate(n, x0, dJ, dc, lambda, move, out, S(stream)); VFEM_CATCH
+}
+int vfem_mean(int64_t n, const double *x, double *mean_host, void *stream) {
+    VFEM_TRY
+    DevBuf<double> tmp; tmp.alloc(2048 + 8);
+    launch_sum(n, x, tmp.p + 8, tmp.p, S(stream));
+    double v = 0.0;
+    VFEM_HIP(hipMemcpyAsync(&v, tmp.p, sizeof(double), hipMemcpyDeviceToHost, S(stream)));
+    VFEM_HIP(hipStreamSynchronize(S(stream)));
+    *mean_host = n > 0 ? v / (double) n : 0.0;
+    VFEM_CATCH
+}
+
 // ---- MLP ----
 int vfem_mlp_create(vfem_mlp **out, int es, int nn, int n_layers, int sigmoid) {
     VFEM_TRY

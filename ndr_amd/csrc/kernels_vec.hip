@@ -186,3 +186,87 @@ void launch_compliance_gradient(const Dims &d, const double *K0, const double *r
 }
 
 }  // namespace vfem
+
+// ------------------------------------------------------------------------------------------
+// design-update path: SmoothingFilter / ProjectionFilter (TopologyOptimizationFilter.hh:55-79,
+// 105-162), TotalVolumeConstraint (TopologyOptimizationConstraint.hh:21-34) and the OC candidate step
+// (OptimalityCriterion.hh:47-50) as elementwise / small-stencil kernels on the element grid.
+// ------------------------------------------------------------------------------------------
+namespace vfem {
+
+// box filter of radius r clipped to the grid; every output row is normalised by its in-bounds neighbour count.
+// transpose = 0:  out_i = (1/c_i) sum_{k in N(i)} in_k        (A x)
+// transpose = 1:  out_k = sum_{i in N(k)} in_i / c_i          (A^T g; the neighbourhood relation is symmetric)
+__global__ void __launch_bounds__(256) k_box_filter(int nx, int ny, int nz, int r, const double *__restrict__ in,
+                                                    double *__restrict__ out, int transpose) {
+    const long long n = (long long) nx * ny * nz;
+    for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long) gridDim.x * blockDim.x) {
+        const int k = (int) (e % nz), j = (int) ((e / nz) % ny), i = (int) (e / ((long long) nz * ny));
+        const int i0 = max(i - r, 0), i1 = min(i + r, nx - 1), j0 = max(j - r, 0), j1 = min(j + r, ny - 1);
+        const int k0 = max(k - r, 0), k1 = min(k + r, nz - 1);
+        double acc = 0.0;
+        for (int a = i0; a <= i1; ++a)
+            for (int b = j0; b <= j1; ++b)
+                for (int c = k0; c <= k1; ++c) {
+                    double v = in[((long long) a * ny + b) * nz + c];
+                    if (transpose) {
+                        const int ca = min(a + r, nx - 1) - max(a - r, 0) + 1, cb = min(b + r, ny - 1) - max(b - r, 0) + 1;
+                        const int cc = min(c + r, nz - 1) - max(c - r, 0) + 1;
+                        v /= (double) (ca * cb * cc);
+                    }
+                    acc += v;
+                }
+        if (!transpose) acc /= (double) ((i1 - i0 + 1) * (j1 - j0 + 1) * (k1 - k0 + 1));
+        out[e] = acc;
+    }
+}
+void launch_box_filter(int nx, int ny, int nz, int r, const double *in, double *out, int transpose, hipStream_t s) {
+    k_box_filter<<<grid_for((long long) nx * ny * nz, 256), 256, 0, s>>>(nx, ny, nz, r, in, out, transpose);
+    VFEM_HIP(hipGetLastError());
+}
+
+// mode 0: out = 0.5 (tanh(b/2) + tanh(b (x - 1/2))) / tanh(b/2);  mode 1: out = g * 0.5 b (1 - tanh^2(b (x - 1/2))) / tanh(b/2)
+__global__ void __launch_bounds__(256) k_projection(long long n, double beta, const double *__restrict__ x,
+                                                    const double *__restrict__ g, double *__restrict__ out, int mode) {
+    const double th = tanh(0.5 * beta);
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+        const double t = tanh(beta * (x[i] - 0.5));
+        out[i] = mode == 0 ? 0.5 * (th + t) / th : g[i] * 0.5 * beta * (1.0 - t * t) / th;
+    }
+}
+void launch_projection(long long n, double beta, const double *x, const double *g, double *out, int mode, hipStream_t s) {
+    k_projection<<<grid_for(n, 256), 256, 0, s>>>(n, beta, x, g, out, mode);
+    VFEM_HIP(hipGetLastError());
+}
+
+// OC candidate: clip(x0 sqrt(dJ / (dc lambda)), max(x0 - m, 0), min(x0 + m, 1))
+__global__ void __launch_bounds__(256) k_oc_candidate(long long n, const double *__restrict__ x0, const double *__restrict__ dJ,
+                                                      const double *__restrict__ dc, double lambda, double m, double *__restrict__ out) {
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+        const double x = x0[i];
+        double v = x * sqrt(dJ[i] / (dc[i] * lambda));
+        v = fmax(fmax(v, x - m), 0.0);
+        v = fmin(fmin(v, x + m), 1.0);
+        out[i] = v;
+    }
+}
+void launch_oc_candidate(long long n, const double *x0, const double *dJ, const double *dc, double lambda, double m, double *out,
+                         hipStream_t s) {
+    k_oc_candidate<<<grid_for(n, 256), 256, 0, s>>>(n, x0, dJ, dc, lambda, m, out);
+    VFEM_HIP(hipGetLastError());
+}
+
+__global__ void __launch_bounds__(256) k_sum_partial(long long n, const double *__restrict__ a, double *__restrict__ partial) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) acc += a[i];
+    const double t = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+void launch_sum(long long n, const double *a, double *scratch, double *out, hipStream_t s) {
+    k_sum_partial<<<DOT_BLOCKS, 256, 0, s>>>(n, a, scratch);
+    k_dot_final<<<1, 256, 0, s>>>(DOT_BLOCKS, scratch, out);
+    VFEM_HIP(hipGetLastError());
+}
+
+}  // namespace vfem

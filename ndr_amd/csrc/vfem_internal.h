@@ -116,6 +116,11 @@ void launch_pcg_step(long long n, double *x, double *r, const double *dv, const 
                      hipStream_t s);
 void launch_shift_scalar(double *sc, hipStream_t s);   // sc[1] = sc[0]
 
+void launch_box_filter(int nx, int ny, int nz, int r, const double *in, double *out, int transpose, hipStream_t s);
+void launch_projection(long long n, double beta, const double *x, const double *g, double *out, int mode, hipStream_t s);
+void launch_oc_candidate(long long n, const double *x0, const double *dJ, const double *dc, double lambda, double m, double *out, hipStream_t s);
+void launch_sum(long long n, const double *a, double *scratch, double *out, hipStream_t s);
+
 struct MlpArgs;
 void launch_mlp_forward(const MlpArgs &a, hipStream_t s);
 void launch_f32_to_f16(long long n, const float *in, void *out, hipStream_t s);

@@ -665,7 +665,9 @@ class MultigridComplianceObjective1_1_1(ComplianceObjective1_1_1):
 
 
 # ----------------------------------------------------------------------------------------------
-# filters / constraint (TopologyOptimizationFilter.hh, TopologyOptimizationConstraint.hh)
+# filters / constraint (TopologyOptimizationFilter.hh, TopologyOptimizationConstraint.hh) -- device kernels
+# (vfem_box_filter, vfem_projection*, vfem_mean); the public methods take/return numpy like the bound C++ classes,
+# the *_dev variants work on float64 CUDA tensors.
 # ----------------------------------------------------------------------------------------------
 
 class _Filter:
@@ -682,6 +684,16 @@ class _Filter:
 
     def getGridDimensions(self):
         return np.array(self._grid)
+
+    def _n3(self):
+        g = list(self._grid) + [1] * (3 - len(self._grid))
+        return (ctypes.c_int64 * 3)(*g)
+
+    def apply(self, x):
+        return _to_np(self.apply_dev(_to_dev(x).reshape(-1)))
+
+    def backprop(self, g, x):
+        return _to_np(self.backprop_dev(_to_dev(g).reshape(-1), _to_dev(x).reshape(-1)))
 
 
 class ProjectionFilter(_Filter):
@@ -701,89 +713,76 @@ class ProjectionFilter(_Filter):
 
     beta = property(_get_beta, _set_beta)
 
-    def apply(self, x):
-        b = self._beta
-        return 0.5 * (np.tanh(0.5 * b) + np.tanh(b * (x - 0.5))) / np.tanh(0.5 * b)
+    def apply_dev(self, x):
+        out = torch.empty_like(x)
+        _lib.check(_lib.load().vfem_projection(x.numel(), self._beta, _ptr(x), _ptr(out), _stream()))
+        return out
 
-    def backprop(self, g, x):
-        b = self._beta
-        t = np.tanh(b * (x - 0.5))
-        return g * 0.5 * b * (1.0 - t * t) / np.tanh(0.5 * b)
+    def backprop_dev(self, g, x):
+        out = torch.empty_like(g)
+        _lib.check(_lib.load().vfem_projection_backprop(g.numel(), self._beta, _ptr(g), _ptr(x), _ptr(out), _stream()))
+        return out
 
 
 class SmoothingFilter(_Filter):
-    """Box filter, each row normalised by its in-bounds neighbour count (TopologyOptimizationFilter.hh:105-162),
-    evaluated with separable running sums instead of an explicit sparse matrix."""
+    """Box filter, each row normalised by its in-bounds neighbour count (TopologyOptimizationFilter.hh:105-162);
+    the sparse matrix of the reference is replaced by a direct stencil kernel."""
 
     def __init__(self):
         super().__init__()
         self._radius = 1
-        self._count = None
 
     def _get_radius(self):
         return self._radius
 
     def _set_radius(self, r):
         self._radius = int(r)
-        if self._grid is not None:
-            self._update()
 
     radius = property(_get_radius, _set_radius)
 
-    def _set_grid(self, dims):
-        super()._set_grid(dims)
-        self._update()
-
-    def _box(self, a):
-        r = self._radius
-        for ax, n in enumerate(self._grid):
-            c = np.cumsum(a, axis=ax)
-            c = np.concatenate([np.zeros_like(np.take(c, [0], axis=ax)), c], axis=ax)
-            hi = np.minimum(np.arange(n) + r + 1, n)
-            lo = np.maximum(np.arange(n) - r, 0)
-            a = np.take(c, hi, axis=ax) - np.take(c, lo, axis=ax)
-        return a
-
-    def _update(self):
-        self._count = self._box(np.ones(self._grid))
-
-    def apply(self, x):
+    def _run(self, x, transpose):
         self._check()
-        return (self._box(np.asarray(x, dtype=np.float64).reshape(self._grid)) / self._count).reshape(-1)
+        out = torch.empty_like(x)
+        _lib.check(_lib.load().vfem_box_filter(self._n3(), self._radius, _ptr(x), _ptr(out), int(transpose), _stream()))
+        return out
 
-    def backprop(self, g, x):
-        self._check()
-        return self._box(np.asarray(g, dtype=np.float64).reshape(self._grid) / self._count).reshape(-1)
+    def apply_dev(self, x):
+        return self._run(x, 0)
+
+    def backprop_dev(self, g, x):
+        return self._run(g, 1)
 
 
 class PythonFilter(_Filter):
-    """Callback filter (TopologyOptimizationFilter.hh:81-103): apply_cb(in, out), backprop_cb(in, vars, out)."""
+    """Callback filter (TopologyOptimizationFilter.hh:81-103): apply_cb(in, out), backprop_cb(in, vars, out) on numpy."""
 
     def __init__(self):
         super().__init__()
         self.apply_cb = None
         self.backprop_cb = None
 
-    def apply(self, x):
+    def apply_dev(self, x):
         if self.apply_cb is None:
             raise RuntimeError("Apply callback must be configured")
-        out = np.zeros_like(x)
-        self.apply_cb(x, out)
-        return out
+        xin = _to_np(x)
+        out = np.zeros_like(xin)
+        self.apply_cb(xin, out)
+        return _to_dev(out)
 
-    def backprop(self, g, x):
+    def backprop_dev(self, g, x):
         if self.backprop_cb is None:
             raise RuntimeError("Backprop callback must be configured")
-        out = np.zeros_like(g)
-        self.backprop_cb(g, x, out)
-        return out
+        gin = _to_np(g)
+        out = np.zeros_like(gin)
+        self.backprop_cb(gin, _to_np(x), out)
+        return _to_dev(out)
 
 
 class LangelaarFilter(_Filter):
-    def apply(self, x):
+    def apply_dev(self, x):
         raise RuntimeError("LangelaarFilter is not part of the accelerated path (never used by the drivers)")
 
-    backprop = apply
+    backprop_dev = apply_dev
 
 
 def applyFilter(filter, x):
@@ -797,15 +796,24 @@ class TotalVolumeConstraint:
     def __init__(self, volumeFraction):
         self.volumeFraction = float(volumeFraction)
 
+    def evaluate_dev(self, x):
+        m = ctypes.c_double(0.0)
+        _lib.check(_lib.load().vfem_mean(x.numel(), _ptr(x), ctypes.byref(m), _stream()))
+        return 1.0 - m.value / self.volumeFraction
+
     def evaluate(self, x):
-        return 1.0 - float(np.mean(x)) / self.volumeFraction
+        return self.evaluate_dev(_to_dev(x).reshape(-1))
+
+    def backprop_dev(self, x):
+        return torch.full((x.numel(),), -1.0 / (self.volumeFraction * x.numel()), dtype=torch.float64, device=_dev())
 
     def backprop(self, x):
-        return np.full(x.size, -1.0 / (self.volumeFraction * x.size))
+        return np.full(np.size(x), -1.0 / (self.volumeFraction * np.size(x)))
 
 
 # ----------------------------------------------------------------------------------------------
-# problem + optimality criterion (TopologyOptimizationProblem.hh, OptimalityCriterion.hh)
+# problem + optimality criterion (TopologyOptimizationProblem.hh, OptimalityCriterion.hh); the design variables,
+# every filtered stage and the sensitivities stay on the device between calls
 # ----------------------------------------------------------------------------------------------
 
 class TopologyOptimizationProblem1_1_1:
@@ -817,22 +825,26 @@ class TopologyOptimizationProblem1_1_1:
         self._nvars = simulator.numElements()
         for f in self._filters:
             f._set_grid(simulator.NbElementsPerDimension())
-        self._cached = [np.zeros(self._nvars) for _ in range(len(self._filters) + 1)]
+        z = lambda: torch.zeros(self._nvars, dtype=torch.float64, device=_dev())
+        self._cached = [z() for _ in range(len(self._filters) + 1)]
         self._vars_set = False
 
     def numVars(self):
         return self._nvars
 
     def getVars(self):
-        return self._cached[0].copy()
+        return _to_np(self._cached[0])
+
+    def getVars_device(self):
+        return self._cached[0]
 
     def setVars(self, x, forceUpdate=False):
-        x = np.asarray(x, dtype=np.float64).reshape(-1)
-        if (not forceUpdate) and self._vars_set and np.linalg.norm(x - self._cached[0]) < 1e-16:
+        x = _to_dev(x, (self._nvars,))
+        if (not forceUpdate) and self._vars_set and float((x - self._cached[0]).norm()) < 1e-16:
             return False                                             # Problem.hh:50-51
-        self._cached[0] = x.copy()
+        self._cached[0] = x.clone()
         for i, f in enumerate(self._filters):
-            self._cached[i + 1] = f.apply(self._cached[i])
+            self._cached[i + 1] = f.apply_dev(self._cached[i])
         self._objective.updateCache(self._cached[-1])
         self._vars_set = True
         return True
@@ -841,39 +853,48 @@ class TopologyOptimizationProblem1_1_1:
         if not self._vars_set:
             raise RuntimeError("Must call setVars first!")
 
-    def evaluateOCConstraintAtVars(self, x):
+    def evaluateOCConstraintAtVars_dev(self, x):
         if len(self._constraints) != 1 or not isinstance(self._constraints[0], TotalVolumeConstraint):
             raise RuntimeError("Applicable only for a topology optimization with a single (volume) constraint")
         for f in self._filters:
-            x = f.apply(x)
-        return self._constraints[0].evaluate(x)
+            x = f.apply_dev(x)
+        return self._constraints[0].evaluate_dev(x)
+
+    def evaluateOCConstraintAtVars(self, x):
+        return self.evaluateOCConstraintAtVars_dev(_to_dev(x, (self._nvars,)))
 
     def evaluateObjective(self):
         self._need_vars()
-        return self._objective.evaluate(self._cached[-1])
+        return self._objective.evaluate(None)
 
-    def evaluateObjectiveGradient(self):
+    def evaluateObjectiveGradient_device(self):
         self._need_vars()
-        g = self._objective.gradient()
+        g = self._objective.gradient_device()
         nf = len(self._filters)
         for i in range(nf):
-            g = self._filters[nf - 1 - i].backprop(g, self._cached[nf - 1 - i])
+            g = self._filters[nf - 1 - i].backprop_dev(g, self._cached[nf - 1 - i])
         return g
+
+    def evaluateObjectiveGradient(self):
+        return _to_np(self.evaluateObjectiveGradient_device())
 
     def evaluateConstraints(self):
         self._need_vars()
-        return np.array([c.evaluate(self._cached[-1]) for c in self._constraints])
+        return np.array([c.evaluate_dev(self._cached[-1]) for c in self._constraints])
 
-    def evaluateConstraintsJacobian(self):
+    def evaluateConstraintsJacobian_device(self):
         self._need_vars()
         nf = len(self._filters)
         rows = []
         for c in self._constraints:
-            d = c.backprop(self._cached[-1])
+            d = c.backprop_dev(self._cached[-1])
             for i in range(nf):
-                d = self._filters[nf - 1 - i].backprop(d, self._cached[nf - 1 - i])
+                d = self._filters[nf - 1 - i].backprop_dev(d, self._cached[nf - 1 - i])
             rows.append(d)
-        return np.array(rows).reshape(len(self._constraints), self._nvars)
+        return rows
+
+    def evaluateConstraintsJacobian(self):
+        return np.stack([_to_np(r) for r in self.evaluateConstraintsJacobian_device()]).reshape(len(self._constraints), self._nvars)
 
     def getDensities(self):
         return self._sim.getDensities()
@@ -888,13 +909,14 @@ class TopologyOptimizationProblem1_1_1:
         self._filters = list(filters)
         for f in self._filters:
             f._set_grid(self._sim.NbElementsPerDimension())
-        self._cached = [self._cached[0]] + [np.zeros(self._nvars) for _ in self._filters]
+        self._cached = [self._cached[0]] + [torch.zeros(self._nvars, dtype=torch.float64, device=_dev()) for _ in self._filters]
 
     filters = property(lambda s: list(s._filters), _set_filters)
 
 
 class OCOptimizer1_1_1:
-    """OCOptimizer (OptimalityCriterion.hh:30-81); the multiplier bracket persists across steps."""
+    """OCOptimizer (OptimalityCriterion.hh:30-81); the multiplier bracket persists across steps.  Each bisection
+    probe is three small kernels (candidate step, filters, mean) and one scalar read-back."""
 
     def __init__(self, problem):
         self._p = problem
@@ -902,16 +924,18 @@ class OCOptimizer1_1_1:
 
     def step(self, m=0.2, ctol=1e-6):
         p = self._p
-        dJ = p.evaluateObjectiveGradient()
-        dc = p.evaluateConstraintsJacobian()[0]
-        x0 = p.getVars()
+        lib = _lib.load()
+        dJ = p.evaluateObjectiveGradient_device()
+        dc = p.evaluateConstraintsJacobian_device()[0]
+        x0 = p.getVars_device().clone()
+        cand = torch.empty_like(x0)
 
         def stepped(lam):
-            return np.minimum(np.minimum(np.maximum(np.maximum(x0 * np.sqrt(dJ / (dc * lam)), x0 - m), 0.0),
-                                         x0 + m), 1.0)
+            _lib.check(lib.vfem_oc_candidate(x0.numel(), _ptr(x0), _ptr(dJ), _ptr(dc), float(lam), float(m), _ptr(cand), _stream()))
+            return cand
 
         def ceval(lam):
-            return p.evaluateOCConstraintAtVars(stepped(lam))
+            return p.evaluateOCConstraintAtVars_dev(stepped(lam))
 
         while ceval(self._lmin) > 0:
             self._lmax = self._lmin
@@ -928,7 +952,7 @@ class OCOptimizer1_1_1:
                 self._lmax = mid
             mid = 0.5 * (self._lmin + self._lmax)
             vol = ceval(mid)
-        p.setVars(stepped(mid))
+        p.setVars(stepped(mid).clone())
         print("objective, constraint, lambda estimate: %g\t%g\t%g" % (p.evaluateObjective(),
                                                                       p.evaluateConstraints()[0], mid))
 
