@@ -121,6 +121,10 @@ void launch_projection(long long n, double beta, const double *x, const double *
 void launch_oc_candidate(long long n, const double *x0, const double *dJ, const double *dc, double lambda, double m, double *out, hipStream_t s);
 void launch_sum(long long n, const double *a, double *scratch, double *out, hipStream_t s);
 
+void launch_apply_q2(int nx, int ny, int nz, const double *K0, const double *E, const double *u, double *out, hipStream_t s);
+void launch_gradient_q2(int nx, int ny, int nz, const double *K0, const double *rho, double E0, double Emin, double gamma,
+                        const double *u, double *g, hipStream_t s);
+
 struct MlpArgs;
 void launch_mlp_forward(const MlpArgs &a, hipStream_t s);
 void launch_f32_to_f16(long long n, const float *in, void *out, hipStream_t s);
@@ -188,4 +192,16 @@ struct vfem_mlp {
     vfem::DevBuf<uint16_t> W1, Wh;               // fp16 bit patterns
     float bout = 0.f;
     bool loaded = false;
+};
+
+struct vfem_simq2 {                              // TensorProductSimulator<2,2,2>: grid, K0 (81x81), SIMP, applyK, sensitivity
+    int nx = 0, ny = 0, nz = 0;
+    double h[3];
+    double lambda = 0.0, mu = 0.5;
+    double E0 = 1.0, Emin = 1e-9, gamma = 3.0;
+    std::vector<double> K0;                      // 81 x 81 row-major
+    vfem::DevBuf<double> dK0, rho, E;
+    long long nn() const { return (long long) (2 * nx + 1) * (2 * ny + 1) * (2 * nz + 1); }
+    long long ne() const { return (long long) nx * ny * nz; }
+    void update_k0();
 };

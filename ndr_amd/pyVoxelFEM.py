@@ -961,11 +961,103 @@ class OCOptimizer1_1_1:
 # module-level factories (VoxelFEM.cc:136-216, 234-240)
 # ----------------------------------------------------------------------------------------------
 
+class TensorProductSimulator2_2_2:
+    """Degree-2 simulator (27-node hexahedra): grid, material, SIMP, ``applyK``, sensitivity.  The reference
+    templates support it (TPS.hh:97-110) but leave it unbound (VoxelFEM.cc:226-229); the multigrid hierarchy for
+    degree 2 is not built yet, so ``multigridSolver`` raises."""
+
+    N = 3
+
+    def __init__(self, domainBoundingBox, numElemg):
+        _lib.require_gpu()
+        self._lib = _lib.load()
+        lo = np.asarray(domainBoundingBox[0], dtype=np.float64).reshape(-1)
+        hi = np.asarray(domainBoundingBox[1], dtype=np.float64).reshape(-1)
+        self._ne = np.array([int(v) for v in numElemg], dtype=np.int64)
+        if self._ne.size != 3:
+            raise RuntimeError("Dimension mismatch: %d vs 3" % self._ne.size)
+        self._nn = 2 * self._ne + 1
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.vfem_simq2_create(ctypes.byref(h), lo.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                               hi.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                               self._ne.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
+        self._h = h
+        self._E0, self._Emin, self._gamma = 1.0, 1e-9, 3.0
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                self._lib.vfem_simq2_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def numNodes(self):
+        return int(np.prod(self._nn))
+
+    def numElements(self):
+        return int(np.prod(self._ne))
+
+    def NbElementsPerDimension(self):
+        return self._ne.copy()
+
+    def readMaterial(self, materialPath):
+        young, poisson = _read_isotropic_material(materialPath)
+        _lib.check(self._lib.vfem_simq2_set_isotropic(self._h, young, poisson))
+
+    def _push_simp(self):
+        _lib.check(self._lib.vfem_simq2_set_simp(self._h, self._E0, self._Emin, self._gamma))
+
+    E_0 = property(lambda s: s._E0, lambda s, v: (setattr(s, "_E0", float(v)), s._push_simp())[0])
+    E_min = property(lambda s: s._Emin, lambda s, v: (setattr(s, "_Emin", float(v)), s._push_simp())[0])
+    gamma = property(lambda s: s._gamma, lambda s, v: (setattr(s, "_gamma", float(v)), s._push_simp())[0])
+
+    def fullDensityElementStiffnessMatrix(self):
+        K0 = np.empty((81, 81))
+        _lib.check(self._lib.vfem_simq2_k0(self._h, K0.ctypes.data_as(ctypes.c_void_p)))
+        return K0
+
+    def setElementDensities(self, rho):
+        t = _to_dev(rho, (self.numElements(),))
+        _lib.check(self._lib.vfem_simq2_set_densities(self._h, _ptr(t), _stream()))
+
+    def setUniformDensities(self, density):
+        if density > 1.0 or density < 0:
+            raise RuntimeError("Density value (%f) has to be in between 0 and 1" % density)
+        self.setElementDensities(torch.full((self.numElements(),), float(density), dtype=torch.float64, device=_dev()))
+
+    def getDensities(self):
+        t = torch.empty(self.numElements(), dtype=torch.float64, device=_dev())
+        _lib.check(self._lib.vfem_simq2_get_densities(self._h, _ptr(t), _stream()))
+        return _to_np(t)
+
+    def applyK_device(self, u):
+        u = _to_dev(u, (self.numNodes(), 3))
+        out = torch.empty_like(u)
+        _lib.check(self._lib.vfem_simq2_apply_k(self._h, _ptr(u), _ptr(out), _stream()))
+        return out
+
+    def applyK(self, u):
+        return _to_np(self.applyK_device(u))
+
+    def complianceGradient_device(self, u):
+        u = _to_dev(u, (self.numNodes(), 3))
+        g = torch.empty(self.numElements(), dtype=torch.float64, device=_dev())
+        _lib.check(self._lib.vfem_simq2_compliance_gradient(self._h, _ptr(u), _ptr(g), _stream()))
+        return g
+
+    def multigridSolver(self, numCoarseningLevels):
+        raise RuntimeError("the degree-2 multigrid hierarchy is not built yet")
+
+
 def TensorProductSimulator(degreesPerDimension, domainBBox, elementsPerDimension):
     degs = [int(d) for d in degreesPerDimension]
-    if degs != [1, 1, 1]:
-        raise RuntimeError("No template instantiation matching degreesPerDimension!")
-    return TensorProductSimulator1_1_1(domainBBox, elementsPerDimension)
+    if degs == [1, 1, 1]:
+        return TensorProductSimulator1_1_1(domainBBox, elementsPerDimension)
+    if degs == [2, 2, 2]:
+        return TensorProductSimulator2_2_2(domainBBox, elementsPerDimension)
+    raise RuntimeError("No template instantiation matching degreesPerDimension!")
 
 
 def TopologyOptimizationProblem(simulator, objective, constraints, filters):
@@ -1033,6 +1125,7 @@ def benchmark_report(include_messages=False):
 
 detail = types.ModuleType(__name__ + ".detail")
 detail.TensorProductSimulator1_1_1 = TensorProductSimulator1_1_1
+detail.TensorProductSimulator2_2_2 = TensorProductSimulator2_2_2
 detail.MultigridSolver1_1_1 = MultigridSolver1_1_1
 detail.TopologyOptimizationProblem1_1_1 = TopologyOptimizationProblem1_1_1
 detail.ComplianceObjective1_1_1 = ComplianceObjective1_1_1

@@ -814,3 +814,86 @@ def get_mgrid(sidelen, domain=None):
     axes = [np.linspace(domain[d][0], domain[d][1], sidelen[d], dtype=np.float32) for d in range(N)]
     g = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1)
     return g[None].astype(np.float32)
+
+
+# ======================================================================================================
+# Degree-2 elements: TensorProductSimulator<2,2,2> (TPS.hh:97-110 with Degrees = 2,2,2).  The reference's python
+# bindings leave this instantiation out (VoxelFEM.cc:226-229), so it holds no golden numbers for it; this restatement
+# is pinned by the analytic properties of the element (rigid-body null space, linear patch test, constant-strain
+# energy) in tests/test_oracle_kats.py.
+# ======================================================================================================
+def _lagrange2(x):
+    """values and derivatives of the three degree-2 Lagrange polynomials on nodes 0, 1/2, 1 (TensorProductPolynomialInterpolant.hh)."""
+    x = np.asarray(x, dtype=np.float64)
+    N = np.stack([2 * (x - 0.5) * (x - 1), -4 * x * (x - 1), 2 * x * (x - 0.5)])
+    dN = np.stack([4 * x - 3, -8 * x + 4, 4 * x - 1])
+    return N, dN
+
+
+def q2_reference_stiffness(h, lam, mu):
+    """81 x 81 full-density element stiffness of the 27-node hexahedron with edge lengths h, isotropic (lam, mu);
+    local node 9a+3b+c, dof 3*node+component; Gauss-Legendre 3 points per axis (exact for the degree-4 integrand)."""
+    xg, wg = np.polynomial.legendre.leggauss(3)
+    xg, wg = 0.5 * (xg + 1.0), 0.5 * wg
+    N, dN = _lagrange2(xg)                                  # [3 basis, 3 points]
+    K = np.zeros((81, 81))
+    vol = float(np.prod(h))
+    for qa in range(3):
+        for qb in range(3):
+            for qc in range(3):
+                w = wg[qa] * wg[qb] * wg[qc] * vol
+                G = np.zeros((27, 3))
+                for a in range(3):
+                    for b in range(3):
+                        for c in range(3):
+                            n = 9 * a + 3 * b + c
+                            G[n, 0] = dN[a, qa] * N[b, qb] * N[c, qc] / h[0]
+                            G[n, 1] = N[a, qa] * dN[b, qb] * N[c, qc] / h[1]
+                            G[n, 2] = N[a, qa] * N[b, qb] * dN[c, qc] / h[2]
+                # strain-displacement in Voigt-free form: K[(n,i),(m,j)] = lam G[n,i] G[m,j] + mu G[n,j] G[m,i] + mu delta_ij G[n].G[m]
+                GG = G @ G.T
+                blk = lam * np.einsum("ni,mj->nimj", G, G) + mu * np.einsum("nj,mi->nimj", G, G) \
+                    + mu * np.einsum("nm,ij->nimj", GG, np.eye(3))
+                K += w * blk.reshape(81, 81)
+    return K
+
+
+class OracleSimQ2:
+    """applyK / complianceGradient of the degree-2 simulator (TPS.hh:905-952, 730-751), numpy element loop."""
+
+    def __init__(self, ne, domain=([0, 0, 0], [1, 1, 1]), young=1.0, poisson=0.0):
+        self.ne = np.asarray(ne, dtype=np.int64)
+        self.nn = 2 * self.ne + 1
+        lo, hi = np.asarray(domain[0], float), np.asarray(domain[1], float)
+        self.h = (hi - lo) / self.ne
+        self.E0, self.Emin, self.gamma = 1.0, 1e-9, 3.0
+        self.set_isotropic(young, poisson)
+        self.num_elems = int(np.prod(self.ne))
+        self.num_nodes = int(np.prod(self.nn))
+        self.rho = np.zeros(self.num_elems)
+        ei = np.stack(np.meshgrid(*[np.arange(n) for n in self.ne], indexing="ij"), axis=-1).reshape(-1, 3)
+        loc = np.stack(np.meshgrid(np.arange(3), np.arange(3), np.arange(3), indexing="ij"), axis=-1).reshape(-1, 3)
+        nd = 2 * ei[:, None, :] + loc[None, :, :]                                    # [ne, 27, 3]
+        self.enodes = (nd[..., 0] * self.nn[1] + nd[..., 1]) * self.nn[2] + nd[..., 2]
+
+    def set_isotropic(self, young, poisson):
+        self.lam = poisson * young / ((1 + poisson) * (1 - 2 * poisson))
+        self.mu = young / (2 + 2 * poisson)
+        self.K0 = q2_reference_stiffness(self.h, self.lam, self.mu)
+
+    def young(self):
+        return self.Emin + self.rho ** self.gamma * (self.E0 - self.Emin)
+
+    def apply_k(self, u):
+        u = np.asarray(u, dtype=np.float64).reshape(self.num_nodes, 3)
+        ue = u[self.enodes].reshape(self.num_elems, 81)
+        fe = (ue @ self.K0.T) * self.young()[:, None]
+        out = np.zeros((self.num_nodes, 3))
+        np.add.at(out, self.enodes.reshape(-1), fe.reshape(-1, 3))
+        return out
+
+    def compliance_gradient(self, u):
+        u = np.asarray(u, dtype=np.float64).reshape(self.num_nodes, 3)
+        ue = u[self.enodes].reshape(self.num_elems, 81)
+        en = np.einsum("ei,ij,ej->e", ue, self.K0, ue)
+        return -0.5 * self.gamma * self.rho ** (self.gamma - 1) * (self.E0 - self.Emin) * en

@@ -133,3 +133,37 @@ def test_3d_cantilever_log_kat_full_size():
     f = o.build_load_vector()
     u = mg.pcg(np.zeros_like(f), f, 100, 1e-6, 1, 2, True)
     assert abs(np.sum(f * u) - k["compliance"][0]) < 1e-5 * k["compliance"][0]
+
+
+def test_degree2_element_analytic_properties():
+    """The reference binds no degree-2 simulator, so its tests hold no numbers for it; pin the restatement on what
+    the element must satisfy analytically: symmetry, rigid-body null space of dimension 6, and the exact strain
+    energy of linear displacement fields (patch test)."""
+    from oracle import vfem_oracle as vo
+    h = np.array([0.5, 0.25, 0.4])
+    E, nu = 3.0, 0.3
+    lam, mu = nu * E / ((1 + nu) * (1 - 2 * nu)), E / (2 + 2 * nu)
+    K = vo.q2_reference_stiffness(h, lam, mu)
+    assert np.abs(K - K.T).max() < 1e-13
+    w = np.linalg.eigvalsh(K)
+    assert (np.abs(w) < 1e-10).sum() == 6 and w.min() > -1e-10
+    loc = np.stack(np.meshgrid(np.arange(3), np.arange(3), np.arange(3), indexing="ij"), axis=-1).reshape(-1, 3)
+    X = loc * 0.5 * h
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((3, 3))
+    u = (X @ A.T).reshape(-1)                        # u(x) = A x: constant strain eps = sym(A)
+    eps = 0.5 * (A + A.T)
+    energy = np.prod(h) * (lam * np.trace(eps) ** 2 + 2 * mu * (eps * eps).sum())
+    assert abs(u @ K @ u - energy) < 1e-12 * abs(energy)
+    # translations and infinitesimal rotations
+    for c in range(3):
+        t = np.zeros((27, 3)); t[:, c] = 1.0
+        assert np.abs(K @ t.reshape(-1)).max() < 1e-12
+    W = A - A.T
+    assert np.abs(K @ (X @ W.T).reshape(-1)).max() < 1e-11
+    # interior nodes of a 2x2x2 patch carry no force under a linear field
+    o = vo.OracleSimQ2((2, 2, 2), ([0, 0, 0], [1.0, 0.5, 0.8]), E, nu)
+    o.rho[:] = 1.0
+    g = np.stack(np.meshgrid(*[np.arange(5)] * 3, indexing="ij"), axis=-1).reshape(-1, 3) * 0.5 * o.h
+    f = o.apply_k(g @ A.T).reshape(5, 5, 5, 3)
+    assert np.abs(f[1:4, 1:4, 1:4]).max() < 1e-12
