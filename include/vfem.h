@@ -79,6 +79,9 @@ int vfem_sim_get_densities(const vfem_sim *sim, double *rho, void *stream);
 /* applyK (TPS.hh:905-952): out = K(rho) u, Dirichlet conditions ignored.
  * variant 0 = production kernel, 1 = plain gather kernel (cross-check). */
 int vfem_sim_apply_k(const vfem_sim *sim, const double *u, double *out, int variant, void *stream);
+/* the same operator for the output node planes plane_lo..plane_hi (x index, inclusive) only; other planes of `out` are left
+ * untouched.  Used by the slab-decomposed apply to overlap the halo exchange with the interior planes. */
+int vfem_sim_apply_k_planes(const vfem_sim *sim, const double *u, double *out, int64_t plane_lo, int64_t plane_hi, void *stream);
 /* complianceGradient (TPS.hh:730-751): g_e = -1/2 gamma rho^(gamma-1) (E0-Emin) u_e^T K0 u_e */
 int vfem_sim_compliance_gradient(const vfem_sim *sim, const double *u, double *g, void *stream);
 /* ComplianceObjective::compliance (TopologyOptimizationObjective.hh:39-41): 1/2 sum f.u, to host */

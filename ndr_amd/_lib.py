@@ -42,6 +42,7 @@ SIGNATURES = {
     "vfem_sim_set_uniform_density": (c_int, [c_void_p, c_double, c_void_p]),
     "vfem_sim_get_densities": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vfem_sim_apply_k": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "vfem_sim_apply_k_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "vfem_sim_compliance_gradient": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "vfem_compliance": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double), c_void_p]),
     "vfem_mg_create": (c_int, [POINTER(c_void_p), c_void_p, c_int]),

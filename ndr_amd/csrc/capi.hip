@@ -453,6 +453,15 @@ int vfem_sim_apply_k(const vfem_sim *sim, const double *u, double *out, int vari
     else launch_apply_gather(sim->d, OP_MF0, sim->dK0.p, sim->Ep(), u, nullptr, nullptr, 0, out, S(stream));
     VFEM_CATCH
 }
+int vfem_sim_apply_k_planes(const vfem_sim *sim, const double *u, double *out, int64_t plane_lo, int64_t plane_hi, void *stream) {
+    VFEM_TRY
+    if (plane_lo < 0 || plane_hi > sim->d.NX - 1) throw Error("plane range outside the node grid");
+    if (plane_lo > plane_hi) return 0;
+    if (!sim->fast_ok) throw Error("plane-range apply needs the mode-space kernel (box voxels, isotropic tensor)");
+    if (!launch_apply_dma(sim->d, sim->Dm, sim->Ep(), sim->E.p + sim->n_store(), u, out, S(stream), (int) plane_lo, (int) plane_hi))
+        throw Error("plane-range apply needs 8-byte aligned device buffers");
+    VFEM_CATCH
+}
 int vfem_sim_compliance_gradient(const vfem_sim *sim, const double *u, double *g, void *stream) {
     VFEM_TRY
     launch_compliance_gradient(sim->d, sim->dK0.p, sim->rhop(), sim->E0, sim->Emin, sim->gamma, u, g, S(stream));

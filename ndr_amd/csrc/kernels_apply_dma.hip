@@ -50,7 +50,8 @@ __device__ __forceinline__ void wait_plane(bool has_stores, bool steady) {
 
 __global__ void __launch_bounds__(512, 2) k_apply_dma(Dims d, DmArgs2 dm, const double *__restrict__ E,
                                                       const double *__restrict__ u, double *__restrict__ out,
-                                                      int planes_per_chunk, const char *u_last, const char *e_last) {
+                                                      int planes_per_chunk, const char *u_last, const char *e_last,
+                                                      int plane_lo, int plane_hi) {
     using namespace dma;
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char *ring = smem;
@@ -60,10 +61,10 @@ __global__ void __launch_bounds__(512, 2) k_apply_dma(Dims d, DmArgs2 dm, const 
     const int wave = ty;
     const int k0 = blockIdx.y * (TZ - 1) - 1;
     const int j0 = blockIdx.z * (TY - 1) - 1;
-    const int p0 = blockIdx.x * planes_per_chunk;
+    const int p0 = plane_lo + blockIdx.x * planes_per_chunk;      // output planes [p0, p1] of [plane_lo, plane_hi]
     int p1 = p0 + planes_per_chunk - 1;
-    if (p1 > d.NX - 1) p1 = d.NX - 1;
-    if (p0 > d.NX - 1) return;
+    if (p1 > plane_hi) p1 = plane_hi;
+    if (p0 > plane_hi) return;
     const int k0u = k0 < 0 ? 0 : k0;                   // first node column held by a staged row image
     const int cshift = k0u - k0;                       // 0, or 1 in the first z tile
 
@@ -351,17 +352,21 @@ __global__ void __launch_bounds__(512, 2) k_apply_dma(Dims d, DmArgs2 dm, const 
 }
 
 bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, const double *E_alloc_end, const double *u,
-                      double *out, hipStream_t s) {
+                      double *out, hipStream_t s, int plane_lo, int plane_hi) {
     using namespace dma;
+    if (plane_hi < 0 || plane_hi > d.NX - 1) plane_hi = d.NX - 1;
+    if (plane_lo < 0) plane_lo = 0;
+    if (plane_lo > plane_hi) return true;
+    const int np = plane_hi - plane_lo + 1;
     const char *u_end = reinterpret_cast<const char *>(u + 3 * d.nn);
     const char *e_end = reinterpret_cast<const char *>(E_alloc_end);
     if ((reinterpret_cast<uintptr_t>(u) & 7u) || (reinterpret_cast<uintptr_t>(E) & 7u)) return false;
     DmArgs2 dm;
     for (int q = 0; q < 36; ++q) dm.v[q] = Dm_host[q];
-    int nchunks = d.NX >= 64 ? 8 : (d.NX >= 16 ? 4 : 1);
-    if (d.NX >= 1024) nchunks = 16;
-    const int ppc = (d.NX + nchunks - 1) / nchunks;
-    dim3 blk(TZ, TY, 1), grd((d.NX + ppc - 1) / ppc, (d.NZ + TZ - 2) / (TZ - 1), (d.NY + TY - 2) / (TY - 1));
+    int nchunks = np >= 64 ? 8 : (np >= 16 ? 4 : 1);
+    if (np >= 1024) nchunks = 16;
+    const int ppc = (np + nchunks - 1) / nchunks;
+    dim3 blk(TZ, TY, 1), grd((np + ppc - 1) / ppc, (d.NZ + TZ - 2) / (TZ - 1), (d.NY + TY - 2) / (TY - 1));
     static bool attr = false;
     if (!attr) {
         VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
@@ -369,7 +374,7 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
     }
     // last admissible (aligned) piece: the one holding the last byte of each array
     auto last_piece = [](const char *end) { return reinterpret_cast<const char *>((reinterpret_cast<uintptr_t>(end) - 1) & ~(uintptr_t) 15); };
-    k_apply_dma<<<grd, blk, LDS_BYTES, s>>>(d, dm, E, u, out, ppc, last_piece(u_end), last_piece(e_end));
+    k_apply_dma<<<grd, blk, LDS_BYTES, s>>>(d, dm, E, u, out, ppc, last_piece(u_end), last_piece(e_end), plane_lo, plane_hi);
     VFEM_HIP(hipGetLastError());
     return true;
 }

@@ -77,7 +77,7 @@ void launch_apply_fast(const Dims &d, const double *Dm_host, const double *E, co
                        const uint8_t *mask, int mode, double *out, hipStream_t s);
 // LDS-DMA version of the plain apply (mode 0); returns false when it must not be used for these buffers
 bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, const double *E_alloc_end, const double *u,
-                      double *out, hipStream_t s);
+                      double *out, hipStream_t s, int plane_lo = 0, int plane_hi = -1);
 extern int g_apply_impl;
 
 // colours are processed in the reference order (global parity); `xparity` = global x-parity of local plane 0,

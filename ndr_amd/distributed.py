@@ -76,6 +76,30 @@ class HaloExchanger:
         self.p = part
         self.group = group
 
+    def start(self, field):
+        """begin the exchange; under nccl the transfers run on RCCL's stream while the caller launches work that
+        does not touch the ghost planes, `finish` makes the current stream wait for them.  Under gloo (CPU tests,
+        one-GPU rehearsal) the exchange completes here."""
+        p = self.p
+        if p.world == 1:
+            return []
+        if dist.get_backend(self.group) == "gloo":
+            self.exchange(field)
+            return []
+        v = field.view(p.n_planes, -1)
+        ops = []
+        if p.gl:
+            ops.append(dist.P2POp(dist.isend, v[p.first_owned + 1], p.rank - 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, v[0], p.rank - 1, self.group))
+        if p.gr:
+            ops.append(dist.P2POp(dist.isend, v[p.last_owned - 1], p.rank + 1, self.group))
+            ops.append(dist.P2POp(dist.irecv, v[p.last_owned + 1], p.rank + 1, self.group))
+        return dist.batch_isend_irecv(ops)
+
+    def finish(self, works):
+        for w in works:
+            w.wait()
+
     def exchange(self, field):
         p = self.p
         if p.world == 1:
@@ -138,6 +162,12 @@ class HipLocalOps:
     def apply(self, u):
         return self.tps.applyK_device(u)
 
+    def apply_planes(self, u, out, lo, hi):
+        """output node planes lo..hi (inclusive) only"""
+        from . import _lib
+        from .pyVoxelFEM import _ptr, _stream
+        _lib.check(self.tps._lib.vfem_sim_apply_k_planes(self.tps._h, _ptr(u), _ptr(out), int(lo), int(hi), _stream()))
+
 
 class DistributedStiffness:
     """K(rho) u on the decomposed grid: halo exchange of u, then the local matrix-free apply."""
@@ -147,9 +177,27 @@ class DistributedStiffness:
         self.halo = HaloExchanger(part, group)
 
     def apply(self, u, exchange=True):
-        if exchange:
+        p = self.part
+        if not exchange or p.world == 1:
+            return self.ops.apply(u)
+        if not hasattr(self.ops, "apply_planes"):
             self.halo.exchange(u)
-        return self.ops.apply(u)
+            return self.ops.apply(u)
+        # overlap: only the first and last owned output planes see the ghost planes of u
+        out = torch.empty_like(u)
+        ov = out.view(p.n_planes, -1)
+        works = self.halo.start(u)
+        self.ops.apply_planes(u, out, p.first_owned + (1 if p.gl else 0), p.last_owned - (1 if p.gr else 0))
+        if p.gl:
+            ov[:p.first_owned].zero_()
+        if p.gr:
+            ov[p.last_owned + 1:].zero_()
+        self.halo.finish(works)
+        if p.gl:
+            self.ops.apply_planes(u, out, p.first_owned, p.first_owned)
+        if p.gr:
+            self.ops.apply_planes(u, out, p.last_owned, p.last_owned)
+        return out
 
 
 def init_process_group_from_env():

@@ -90,11 +90,12 @@ def _pcg_worker(rank, world, port, ne, levels, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,ne,levels", [(2, (32, 16, 16), 3), (2, (48, 8, 16), 2)])
+@pytest.mark.parametrize("world,ne,levels", [(2, (32, 16, 16), 3), (2, (48, 8, 16), 2),
+                                             (4, (64, 16, 16), 3), (4, (64, 16, 16), 4)])
 def test_distributed_pcg_matches_single_process(world, ne, levels):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29800 + (os.getpid() % 1000) + levels
+    port = 29800 + (os.getpid() % 1000) + levels + 10 * world
     procs = [ctx.Process(target=_pcg_worker, args=(r, world, port, ne, levels, q)) for r in range(world)]
     for p in procs:
         p.start()

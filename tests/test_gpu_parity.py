@@ -3,6 +3,7 @@ oracle on the same seeded inputs.  fp64 stencil-class operators must agree to 1e
 summation order only); the converged solve to 1e-8 on compliance (north_star asks 1e-5)."""
 import numpy as np
 import pytest
+import torch
 
 from helpers import BC_BRIDGE, BC_CANTILEVER, make_hip, make_oracle, relerr, seeded_density
 
@@ -184,3 +185,23 @@ def test_objective_and_problem_api():
         oco.step()
         ooc.step()
     assert relerr(top.getVars(), otop.cached[0]) < 1e-4
+
+
+def test_apply_plane_range_equals_full_apply():
+    """vfem_sim_apply_k_planes writes exactly the requested output planes, bit-identical to the whole-grid launch"""
+    import ctypes
+    from ndr_amd import _lib
+    from ndr_amd.pyVoxelFEM import _ptr, _stream
+    ne = (37, 20, 70)
+    t = make_hip(ne, ([0, 0, 0], [1, 1, 1]), None, seeded_density(ne, 4))
+    g = torch.Generator(device="cuda").manual_seed(1)
+    u = torch.randn((t.numNodes(), 3), dtype=torch.float64, device="cuda", generator=g)
+    full = t.applyK_device(u).view(ne[0] + 1, -1)
+    for lo, hi in [(0, 0), (ne[0], ne[0]), (1, ne[0] - 1), (5, 5), (3, 20), (0, ne[0])]:
+        out = torch.full_like(u, float("nan"))
+        _lib.check(t._lib.vfem_sim_apply_k_planes(t._h, _ptr(u), _ptr(out), lo, hi, _stream()))
+        ov = out.view(ne[0] + 1, -1)
+        assert torch.equal(ov[lo:hi + 1], full[lo:hi + 1]), (lo, hi)
+        assert bool(torch.isnan(ov[:lo]).all()) and bool(torch.isnan(ov[hi + 1:]).all()), (lo, hi)
+    with pytest.raises(RuntimeError):
+        _lib.check(t._lib.vfem_sim_apply_k_planes(t._h, _ptr(u), _ptr(out), 0, ne[0] + 1, _stream()))
