@@ -33,7 +33,9 @@ extern "C" {
 typedef struct vfem_sim vfem_sim;   /* TensorProductSimulator<1,1,1>              (TPS.hh:219) */
 typedef struct vfem_mg  vfem_mg;    /* MultigridSolver<1,1,1>                      (MG.hh:11)   */
 typedef struct vfem_mlp vfem_mlp;
-typedef struct vfem_simq2 vfem_simq2; /* TensorProductSimulator<2,2,2> (27-node hexahedra; unbound in the reference, VoxelFEM.cc:226-229) */   /* networks.MLP (Fourier features + ReLU MLP)  (networks.py:128) */
+typedef struct vfem_simq2 vfem_simq2;
+typedef struct vfem_gsim vfem_gsim;   /* TensorProductSimulator<p,..,p>, N = 2 or 3, p = 1 or 2 (generic path) */
+typedef struct vfem_gmg vfem_gmg;     /* MultigridSolver<p,..,p> of the generic path */ /* TensorProductSimulator<2,2,2> (27-node hexahedra; unbound in the reference, VoxelFEM.cc:226-229) */   /* networks.MLP (Fourier features + ReLU MLP)  (networks.py:128) */
 
 const char *vfem_last_error(void);
 int  vfem_device_count(void);                 /* number of visible HIP devices (0 => no GPU) */
@@ -168,6 +170,46 @@ int vfem_simq2_set_densities(vfem_simq2 *sim, const double *rho, void *stream);
 int vfem_simq2_get_densities(const vfem_simq2 *sim, double *rho, void *stream);
 int vfem_simq2_apply_k(const vfem_simq2 *sim, const double *u, double *out, void *stream);
 int vfem_simq2_compliance_gradient(const vfem_simq2 *sim, const double *u, double *g, void *stream);
+
+/* ---- generic path: every instantiation other than the tuned <1,1,1> one.  TensorProductSimulator<1,1> / <2,2> (2-D, plane
+ * stress, ElasticityTensor.hh:100-133; the reference binds <1,1>, VoxelFEM.cc:226) and <2,2,2>; MultigridSolver of the same
+ * degrees (MG.hh, templates generic in Degrees...).  Nodal fields [numNodes][N], node grid (p*ne+1) per axis, last axis
+ * fastest; Dirichlet mask 1 byte per node (bit c = component c).  Same semantics as the vfem_sim_ / vfem_mg_ entry points of the
+ * same name. */
+int vfem_gsim_create(vfem_gsim **out, int dim, int degree, const double *bbox_min_host, const double *bbox_max_host,
+                     const int64_t *nelems_host);
+int vfem_gsim_destroy(vfem_gsim *sim);
+int64_t vfem_gsim_num_nodes(const vfem_gsim *sim);
+int64_t vfem_gsim_num_elements(const vfem_gsim *sim);
+int vfem_gsim_ke_size(const vfem_gsim *sim);                       /* N * (p+1)^N */
+int vfem_gsim_set_isotropic(vfem_gsim *sim, double young, double poisson);
+int vfem_gsim_set_simp(vfem_gsim *sim, double E0, double Emin, double gamma);
+int vfem_gsim_k0(const vfem_gsim *sim, double *K0_host);           /* ke x ke row-major */
+int vfem_gsim_set_dirichlet(vfem_gsim *sim, const uint8_t *mask_host, const double *values_host);
+int vfem_gsim_set_densities(vfem_gsim *sim, const double *rho, void *stream);
+int vfem_gsim_get_densities(const vfem_gsim *sim, double *rho, void *stream);
+int vfem_gsim_apply_k(const vfem_gsim *sim, const double *u, double *out, void *stream);              /* TPS.hh:905-952 */
+int vfem_gsim_compliance_gradient(const vfem_gsim *sim, const double *u, double *g, void *stream);    /* TPS.hh:730-751 */
+int vfem_gsim_compliance(const vfem_gsim *sim, const double *f, const double *u, double *value_host, void *stream);  /* 1/2 f.u */
+int vfem_gmg_create(vfem_gmg **out, vfem_gsim *fine, int num_coarsening_levels);                      /* MG.hh:22-90 */
+int vfem_gmg_destroy(vfem_gmg *mg);
+int vfem_gmg_num_levels(const vfem_gmg *mg);
+int vfem_gmg_level_dims(const vfem_gmg *mg, int level, int64_t nelems_host[3]);
+int64_t vfem_gmg_level_num_nodes(const vfem_gmg *mg, int level);
+int vfem_gmg_level_dirichlet_mask(const vfem_gmg *mg, int level, uint8_t *mask_host);
+int vfem_gmg_set_symmetric_gauss_seidel(vfem_gmg *mg, int symmetric);
+int vfem_gmg_update_operators(vfem_gmg *mg, void *stream);                                            /* MG.hh:415-425 */
+int vfem_gmg_apply_k(vfem_gmg *mg, int level, const double *u, double *out, void *stream);
+int vfem_gmg_residual(vfem_gmg *mg, int level, const double *u, const double *b, double *r, void *stream);
+int vfem_gmg_smooth(vfem_gmg *mg, int level, double *u, const double *b, int forward, void *stream);  /* MG.hh:285-340 */
+int vfem_gmg_zero_dirichlet(vfem_gmg *mg, int level, double *u, void *stream);
+int vfem_gmg_restrict(vfem_gmg *mg, int fine_level, const double *fine, double *coarse, void *stream);
+int vfem_gmg_interpolate(vfem_gmg *mg, int fine_level, const double *coarse, double *fine, int accumulate, void *stream);
+int vfem_gmg_solve(vfem_gmg *mg, double *x, const double *f, int num_steps, int num_smoothing_steps, int stiffness_updated,
+                   int zero_dirichlet, int full_multigrid, void *stream);                             /* MG.hh:447-472 */
+int vfem_gmg_pcg(vfem_gmg *mg, double *x, const double *b, int max_iter, double tol, int mg_iterations, int mg_smoothing_iterations,
+                 int full_multigrid, vfem_residual_cb residual_cb, void *cb_user, int *iterations_out, double *relres_out,
+                 void *stream);                                                                       /* MG.hh:679-732 */
 
 /* ---- design-update path, element-grid arrays [n0][n1][n2] fp64 (2-D grids: n2 = 1) ----
  * SmoothingFilter apply / backprop (TopologyOptimizationFilter.hh:105-162; transpose != 0 => A^T), ProjectionFilter apply /

@@ -81,6 +81,37 @@ SIGNATURES = {
     "vfem_simq2_get_densities": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vfem_simq2_apply_k": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "vfem_simq2_compliance_gradient": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vfem_gsim_create": (c_int, [POINTER(c_void_p), c_int, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
+    "vfem_gsim_destroy": (c_int, [c_void_p]),
+    "vfem_gsim_num_nodes": (c_int64, [c_void_p]),
+    "vfem_gsim_num_elements": (c_int64, [c_void_p]),
+    "vfem_gsim_ke_size": (c_int, [c_void_p]),
+    "vfem_gsim_set_isotropic": (c_int, [c_void_p, c_double, c_double]),
+    "vfem_gsim_set_simp": (c_int, [c_void_p, c_double, c_double, c_double]),
+    "vfem_gsim_k0": (c_int, [c_void_p, c_void_p]),
+    "vfem_gsim_set_dirichlet": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "vfem_gsim_set_densities": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "vfem_gsim_get_densities": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "vfem_gsim_apply_k": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vfem_gsim_compliance_gradient": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vfem_gsim_compliance": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double), c_void_p]),
+    "vfem_gmg_create": (c_int, [POINTER(c_void_p), c_void_p, c_int]),
+    "vfem_gmg_destroy": (c_int, [c_void_p]),
+    "vfem_gmg_num_levels": (c_int, [c_void_p]),
+    "vfem_gmg_level_dims": (c_int, [c_void_p, c_int, POINTER(c_int64)]),
+    "vfem_gmg_level_num_nodes": (c_int64, [c_void_p, c_int]),
+    "vfem_gmg_level_dirichlet_mask": (c_int, [c_void_p, c_int, c_void_p]),
+    "vfem_gmg_set_symmetric_gauss_seidel": (c_int, [c_void_p, c_int]),
+    "vfem_gmg_update_operators": (c_int, [c_void_p, c_void_p]),
+    "vfem_gmg_apply_k": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "vfem_gmg_residual": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vfem_gmg_smooth": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "vfem_gmg_zero_dirichlet": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "vfem_gmg_restrict": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "vfem_gmg_interpolate": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "vfem_gmg_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vfem_gmg_pcg": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_int, c_int, RESIDUAL_CB, c_void_p,
+                             POINTER(c_int), POINTER(c_double), c_void_p]),
     "vfem_box_filter": (c_int, [POINTER(c_int64), c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "vfem_projection": (c_int, [c_int64, c_double, c_void_p, c_void_p, c_void_p]),
     "vfem_projection_backprop": (c_int, [c_int64, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),

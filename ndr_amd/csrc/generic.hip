@@ -1,0 +1,911 @@
+// Dimension- and degree-generic voxel FEM path: TensorProductSimulator<p,..,p> / MultigridSolver<p,..,p> for
+// N in {2,3}, p in {1,2} (reference templates: VoxelFEM/TensorProductSimulator.hh, VoxelFEM/MultigridSolver.hh).
+// It serves every instantiation other than the tuned <1,1,1> path: the 2-D simulators of the reference's own
+// CPU-runnable configuration (<1,1>, plane stress) and the degree-2 elements (<2,2>, <2,2,2>).
+//
+// One kernel family, "one wave per node": the wave gathers the node's incident elements (1..2^N), each lane owns
+// dofs of the element vector, and the N rows of the element matrix that belong to the node are read as contiguous
+// runs (K is symmetric, so rows are columns).  Level 0 uses E_e * K0, coarser levels the stored Galerkin element
+// matrices Ke_e (MG.hh:604-669).  The same gather yields S = sum_e (K_e u_e)[node rows] and the diagonal block M, so
+// the operator apply, the residual and the multicoloured block Gauss-Seidel (MG.hh:193-340) share it.  Deterministic:
+// fixed lane ownership and a fixed xor-shuffle reduction tree.
+#include "vfem_internal.h"
+
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+namespace vfem {
+
+struct GDims {
+    int N, p;
+    int ne[3], nn[3];
+    int npe, ke;                     // nodes per element (p+1)^N, element matrix size N * npe
+    long long nnodes, nelems;
+};
+
+static GDims make_gdims(int N, int p, const long long *ne) {
+    GDims d{};
+    d.N = N; d.p = p; d.npe = 1; d.nnodes = 1; d.nelems = 1;
+    for (int a = 0; a < 3; ++a) {
+        d.ne[a] = a < N ? (int) ne[a] : 1;
+        d.nn[a] = a < N ? p * d.ne[a] + 1 : 1;
+        if (a < N) { d.npe *= p + 1; d.nnodes *= d.nn[a]; d.nelems *= d.ne[a]; }
+    }
+    d.ke = N * d.npe;
+    return d;
+}
+
+struct GWeights { double w[5][3]; };     // w[t][a]: coarse Lagrange basis a at fine offset t/(2p), t = 0..2p
+
+// ------------------------------------------------------------------------------------------
+// node gather
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long g_node_flat(const GDims &d, const int idx[3]) {
+    long long n = idx[0];
+    for (int a = 1; a < d.N; ++a) n = n * d.nn[a] + idx[a];
+    return n;
+}
+
+// S[r] = sum over incident elements e, element dofs q of scale_e * K_e[N*ln + r][q] * u_e[q]   (complete in every lane)
+// M[r][c] = sum_e scale_e * K_e[N*ln + r][N*ln + c]
+__device__ __forceinline__ void g_gather(const GDims &d, const double *__restrict__ K, long long kstride,
+                                         const double *__restrict__ scale, const double *__restrict__ u, const int idx[3],
+                                         int lane, double S[3], double M[9]) {
+    const int N = d.N, p = d.p, q1 = p + 1, ke = d.ke;
+    int cnt[3] = {1, 1, 1}, el[3][2], lo[3][2];
+    for (int a = 0; a < N; ++a) {
+        const int r = idx[a] % p, e = idx[a] / p;
+        if (r != 0) { cnt[a] = 1; el[a][0] = e; lo[a][0] = r; }
+        else {
+            int c = 0;
+            if (e - 1 >= 0) { el[a][c] = e - 1; lo[a][c] = p; ++c; }
+            if (e < d.ne[a]) { el[a][c] = e; lo[a][c] = 0; ++c; }
+            cnt[a] = c;
+        }
+    }
+    double sp[3] = {0.0, 0.0, 0.0};
+    for (int q = 0; q < 9; ++q) M[q] = 0.0;
+    // dof -> (local node offsets, component) of this lane's (up to two) element dofs
+    int qn[2], qc[2], qoff[2][3];
+    for (int t = 0; t < 2; ++t) {
+        const int q = lane + 64 * t;
+        qn[t] = q < ke ? q / N : -1; qc[t] = q % N;
+        int m = qn[t] < 0 ? 0 : qn[t];
+        for (int a = N - 1; a >= 0; --a) { qoff[t][a] = m % q1; m /= q1; }
+    }
+    for (int i0 = 0; i0 < cnt[0]; ++i0)
+        for (int i1 = 0; i1 < cnt[1]; ++i1)
+            for (int i2 = 0; i2 < (N == 3 ? cnt[2] : 1); ++i2) {
+                const int sel[3] = {i0, i1, i2};
+                long long e = 0; int ln = 0; int ebase[3] = {0, 0, 0};
+                for (int a = 0; a < N; ++a) {
+                    e = e * d.ne[a] + el[a][sel[a]];
+                    ln = ln * q1 + lo[a][sel[a]];
+                    ebase[a] = p * el[a][sel[a]];
+                }
+                const double sc = scale ? scale[e] : 1.0;
+                const double *Kp = K + e * kstride + (long long) (N * ln) * ke;
+                for (int t = 0; t < 2; ++t) {
+                    if (qn[t] < 0) continue;
+                    int g[3];
+                    for (int a = 0; a < N; ++a) g[a] = ebase[a] + qoff[t][a];
+                    const double uv = sc * u[N * g_node_flat(d, g) + qc[t]];
+                    const int q = lane + 64 * t;
+                    for (int r = 0; r < N; ++r) sp[r] = fma(Kp[r * ke + q], uv, sp[r]);
+                }
+                for (int r = 0; r < N; ++r)
+                    for (int c = 0; c < N; ++c) M[3 * r + c] = fma(sc, Kp[r * ke + N * ln + c], M[3 * r + c]);
+            }
+    for (int r = 0; r < 3; ++r) {
+        double v = r < N ? sp[r] : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        S[r] = v;
+    }
+}
+
+// mode 0: out = K u;  1: out = zeroDirichlet(b - K u);  2: out = zeroDirichlet(K u)
+__global__ void __launch_bounds__(256) kg_apply(GDims d, const double *__restrict__ K, long long kstride,
+                                                const double *__restrict__ scale, const double *__restrict__ u,
+                                                const double *__restrict__ b, const uint8_t *__restrict__ mask, int mode,
+                                                double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long n = (long long) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= d.nnodes) return;
+    int idx[3] = {0, 0, 0};
+    { long long m = n; for (int a = d.N - 1; a >= 0; --a) { idx[a] = (int) (m % d.nn[a]); m /= d.nn[a]; } }
+    double S[3], M[9];
+    g_gather(d, K, kstride, scale, u, idx, lane, S, M);
+    if (lane < d.N) {
+        double v = S[lane];
+        if (mode == 1) v = b[d.N * n + lane] - v;
+        if (mode != 0 && mask && ((mask[n] >> lane) & 1)) v = 0.0;
+        out[d.N * n + lane] = v;
+    }
+}
+
+struct GColor { int start[3], inc[3], cnt[3]; long long total; };
+
+// one colour of smoothingMulticoloredGS (MG.hh:285-340) with m_smoothNode's component-sequential solve (MG.hh:254-264)
+__global__ void __launch_bounds__(256) kg_gs_color(GDims d, GColor col, const double *__restrict__ K, long long kstride,
+                                                   const double *__restrict__ scale, double *__restrict__ u,
+                                                   const double *__restrict__ b, const uint8_t *__restrict__ mask, int forward) {
+    const int lane = threadIdx.x & 63;
+    const long long w = (long long) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= col.total) return;
+    int idx[3] = {0, 0, 0};
+    { long long m = w; for (int a = d.N - 1; a >= 0; --a) { idx[a] = col.start[a] + (int) (m % col.cnt[a]) * col.inc[a]; m /= col.cnt[a]; } }
+    double S[3], M[9];
+    g_gather(d, K, kstride, scale, u, idx, lane, S, M);
+    if (lane == 0) {
+        const long long n = g_node_flat(d, idx);
+        const int N = d.N;
+        const uint8_t dc = mask ? mask[n] : 0;
+        double bms[3], diff[3] = {0.0, 0.0, 0.0};
+        for (int r = 0; r < N; ++r) bms[r] = b[N * n + r] - S[r];
+        for (int s = 0; s < N; ++s) {
+            const int i = forward ? s : N - 1 - s;
+            double acc = 0.0;
+            for (int c = 0; c < N; ++c) acc += M[3 * i + c] * diff[c];
+            const double fac = (double) (((dc >> i) & 1) == 0) / M[3 * i + i];
+            diff[i] = (bms[i] - acc) * fac;
+        }
+        for (int r = 0; r < N; ++r) u[N * n + r] += diff[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// grid transfers (MG.hh:116-161): thread per node of the level written
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) kg_prolong(GDims f, GDims c, GWeights W, const double *__restrict__ cv,
+                                                  double *__restrict__ fv, int accumulate) {
+    const long long n = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= f.nnodes) return;
+    const int N = f.N, p = f.p;
+    int e[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+    { long long m = n; for (int a = N - 1; a >= 0; --a) { const int i = (int) (m % f.nn[a]); m /= f.nn[a];
+        int ee = i / (2 * p); if (ee > c.ne[a] - 1) ee = c.ne[a] - 1; e[a] = ee; t[a] = i - 2 * p * ee; } }
+    double acc[3] = {0.0, 0.0, 0.0};
+    const int q1 = p + 1;
+    const int n2 = N == 3 ? q1 : 1;
+    for (int a0 = 0; a0 < q1; ++a0) {
+        const double w0 = W.w[t[0]][a0];
+        if (w0 == 0.0) continue;
+        for (int a1 = 0; a1 < q1; ++a1) {
+            const double w1 = w0 * W.w[t[1]][a1];
+            if (w1 == 0.0) continue;
+            for (int a2 = 0; a2 < n2; ++a2) {
+                const double w2 = N == 3 ? w1 * W.w[t[2]][a2] : w1;
+                if (w2 == 0.0) continue;
+                int g[3] = {p * e[0] + a0, p * e[1] + a1, p * e[2] + a2};
+                const long long cn = g_node_flat(c, g);
+                for (int r = 0; r < N; ++r) acc[r] = fma(w2, cv[N * cn + r], acc[r]);
+            }
+        }
+    }
+    for (int r = 0; r < N; ++r) fv[N * n + r] = accumulate ? fv[N * n + r] + acc[r] : acc[r];
+}
+
+__device__ __forceinline__ double g_restrict_weight(const GWeights &W, int p, int nce, int I, int i_f) {
+    int e = i_f / (2 * p); if (e > nce - 1) e = nce - 1;
+    const int t = i_f - 2 * p * e, a = I - p * e;
+    return (a < 0 || a > p) ? 0.0 : W.w[t][a];
+}
+
+__global__ void __launch_bounds__(256) kg_restrict(GDims f, GDims c, GWeights W, const double *__restrict__ fv,
+                                                   double *__restrict__ cv) {
+    const long long n = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= c.nnodes) return;
+    const int N = f.N, p = f.p, R = 2 * p - 1;
+    int I[3] = {0, 0, 0};
+    { long long m = n; for (int a = N - 1; a >= 0; --a) { I[a] = (int) (m % c.nn[a]); m /= c.nn[a]; } }
+    int lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = a < N ? max(0, 2 * I[a] - R) : 0;
+        hi[a] = a < N ? min(f.nn[a] - 1, 2 * I[a] + R) : 0;
+    }
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int i0 = lo[0]; i0 <= hi[0]; ++i0) {
+        const double w0 = g_restrict_weight(W, p, c.ne[0], I[0], i0);
+        if (w0 == 0.0) continue;
+        for (int i1 = lo[1]; i1 <= hi[1]; ++i1) {
+            const double w1 = w0 * g_restrict_weight(W, p, c.ne[1], I[1], i1);
+            if (w1 == 0.0) continue;
+            for (int i2 = lo[2]; i2 <= hi[2]; ++i2) {
+                const double w2 = N == 3 ? w1 * g_restrict_weight(W, p, c.ne[2], I[2], i2) : w1;
+                if (w2 == 0.0) continue;
+                const int g[3] = {i0, i1, i2};
+                const long long fn = g_node_flat(f, g);
+                for (int r = 0; r < N; ++r) acc[r] = fma(w2, fv[N * fn + r], acc[r]);
+            }
+        }
+    }
+    for (int r = 0; r < N; ++r) cv[N * n + r] = acc[r];
+}
+
+// ------------------------------------------------------------------------------------------
+// Galerkin element matrices (buildPESCoarse, MG.hh:604-669)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long g_child(const GDims &f, const GDims &c, long long ec, int fi) {
+    int idx[3] = {0, 0, 0};
+    { long long m = ec; for (int a = c.N - 1; a >= 0; --a) { idx[a] = (int) (m % c.ne[a]); m /= c.ne[a]; } }
+    long long e = 0;
+    for (int a = 0; a < c.N; ++a) e = e * f.ne[a] + 2 * idx[a] + ((fi >> a) & 1);
+    return e;
+}
+
+// level 1: Ke_c = sum_f E_f * cK0[f]
+__global__ void __launch_bounds__(256) kg_coarsen_first(GDims f, GDims c, const double *__restrict__ cK0,
+                                                        const double *__restrict__ Ef, double *__restrict__ Kec) {
+    const long long ec = blockIdx.x;
+    const int kk = c.ke * c.ke, nch = 1 << c.N;
+    double E[8];
+    for (int fi = 0; fi < nch; ++fi) E[fi] = Ef[g_child(f, c, ec, fi)];
+    for (int q = threadIdx.x; q < kk; q += blockDim.x) {
+        double v = 0.0;
+        for (int fi = 0; fi < nch; ++fi) v = fma(E[fi], cK0[(long long) fi * kk + q], v);
+        Kec[ec * kk + q] = v;
+    }
+}
+
+// deeper levels: Ke_c = sum_f I_f^T Ke_f I_f with I_f = phi_f (x) Id_N; one block per coarse element
+__global__ void __launch_bounds__(256) kg_coarsen_next(GDims f, GDims c, const double *__restrict__ phi,
+                                                       const double *__restrict__ Kef, double *__restrict__ Kec) {
+    extern __shared__ double g_sm[];
+    const int N = c.N, ke = c.ke, npe = c.npe, kk = ke * ke, nch = 1 << N;
+    double *A = g_sm, *T = g_sm + kk;
+    const long long ec = blockIdx.x;
+    for (int q = threadIdx.x; q < kk; q += blockDim.x) Kec[ec * kk + q] = 0.0;
+    for (int fi = 0; fi < nch; ++fi) {
+        const double *Kf = Kef + g_child(f, c, ec, fi) * kk;
+        const double *ph = phi + (long long) fi * npe * npe;          // ph[fine_n * npe + coarse_n]
+        __syncthreads();
+        for (int q = threadIdx.x; q < kk; q += blockDim.x) A[q] = Kf[q];
+        __syncthreads();
+        // T[i][(m,b)] = sum_qn A[i][(qn,b)] ph[qn][m]
+        for (int q = threadIdx.x; q < kk; q += blockDim.x) {
+            const int i = q / ke, j = q % ke, m = j / N, bcomp = j % N;
+            double v = 0.0;
+            for (int qn = 0; qn < npe; ++qn) v = fma(A[i * ke + N * qn + bcomp], ph[qn * npe + m], v);
+            T[q] = v;
+        }
+        __syncthreads();
+        // out[(n,a)][j] += sum_pn ph[pn][n] T[(pn,a)][j]
+        for (int q = threadIdx.x; q < kk; q += blockDim.x) {
+            const int i = q / ke, j = q % ke, n = i / N, a = i % N;
+            double v = 0.0;
+            for (int pn = 0; pn < npe; ++pn) v = fma(ph[pn * npe + n], T[(N * pn + a) * ke + j], v);
+            Kec[ec * kk + q] += v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// small vector kernels with N components per node
+// ------------------------------------------------------------------------------------------
+__global__ void kg_dirichlet(long long nn, int N, const uint8_t *__restrict__ mask, const double *__restrict__ vals,
+                             double *__restrict__ u) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nn * N) return;
+    if ((mask[i / N] >> (i % N)) & 1) u[i] = vals ? vals[i] : 0.0;
+}
+
+__global__ void kg_dense_finish(long long n, int N, const uint8_t *__restrict__ mask, double *__restrict__ A) {
+    const long long gid = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * n) return;
+    const long long r = gid / n, c = gid % n;
+    const bool fr = (mask[r / N] >> (r % N)) & 1, fc = (mask[c / N] >> (c % N)) & 1;
+    if (fr || fc) { A[gid] = 0.0; return; }
+    if (c < r) A[gid] = A[c * n + r];      // rocSOLVER "lower" (column-major) = row-major upper triangle
+}
+
+__global__ void __launch_bounds__(256) kg_gradient(GDims d, const double *__restrict__ K0, const double *__restrict__ rho,
+                                                   double E0, double Emin, double gamma, const double *__restrict__ u,
+                                                   double *__restrict__ g) {
+    __shared__ double ue[4][81];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long e = (long long) blockIdx.x * 4 + w;
+    if (e >= d.nelems) return;
+    const int N = d.N, q1 = d.p + 1, ke = d.ke;
+    int eb[3] = {0, 0, 0};
+    { long long m = e; for (int a = N - 1; a >= 0; --a) { eb[a] = d.p * (int) (m % d.ne[a]); m /= d.ne[a]; } }
+    for (int q = lane; q < ke; q += 64) {
+        int m = q / N, gg[3] = {0, 0, 0};
+        for (int a = N - 1; a >= 0; --a) { gg[a] = eb[a] + m % q1; m /= q1; }
+        ue[w][q] = u[N * g_node_flat(d, gg) + q % N];
+    }
+    __builtin_amdgcn_wave_barrier();
+    double acc = 0.0;
+    for (int r = lane; r < ke; r += 64) {
+        double t = 0.0;
+        for (int c = 0; c < ke; ++c) t = fma(K0[r * ke + c], ue[w][c], t);
+        acc = fma(ue[w][r], t, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) g[e] = -0.5 * gamma * pow(rho[e], gamma - 1.0) * (E0 - Emin) * acc;
+}
+
+}  // namespace vfem
+
+using namespace vfem;
+
+// ------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------
+struct vfem_gsim {
+    GDims d;
+    double h[3] = {1, 1, 1};
+    double lambda = 0.0, mu = 0.5;                 // ETensor(1, 0), TPS.hh:1379
+    double E0 = 1.0, Emin = 1e-9, gamma = 3.0;     // TPS.hh:1392-1394
+    std::vector<double> K0;
+    DevBuf<double> dK0, rho, E, dvals;
+    DevBuf<uint8_t> dmask;
+    std::vector<uint8_t> hmask;
+    void update_k0();
+    void update_E(hipStream_t s) { launch_simp(d.nelems, rho.p, E0, Emin, gamma, E.p, s); }
+};
+
+struct GLevel {
+    GDims d;
+    std::vector<uint8_t> hmask;
+    DevBuf<uint8_t> mask;
+    DevBuf<double> Ke, x, b, r;
+};
+
+struct vfem_gmg {
+    vfem_gsim *fine = nullptr;
+    int L = 0;
+    bool symmetric_gs = true, operators_valid = false;
+    std::vector<GLevel> lv;
+    GWeights W;
+    DevBuf<double> cK0, phi, Ainv, pr, pd, pAd, ps, scal, scratch;
+    DevBuf<int> info;
+    void *rocblas = nullptr;
+};
+
+static double lagrange1d(int p, int a, double x) {            // LagrangePolynomial.hh:9,42-56
+    double v = 1.0;
+    for (int j = 0; j <= p; ++j) if (j != a) v *= (x - (double) j / p) / ((double) a / p - (double) j / p);
+    return v;
+}
+static double dlagrange1d(int p, int a, double x) {
+    double s = 0.0;
+    for (int k = 0; k <= p; ++k) {
+        if (k == a) continue;
+        double t = 1.0 / ((double) a / p - (double) k / p);
+        for (int j = 0; j <= p; ++j) if (j != a && j != k) t *= (x - (double) j / p) / ((double) a / p - (double) j / p);
+        s += t;
+    }
+    return s;
+}
+
+// Element_T::Stiffness (TPS.hh:127-140) by (p+1)-point Gauss quadrature per axis (TensorProductQuadrature<2p,...>)
+void vfem_gsim::update_k0() {
+    static const double g2[2] = {0.21132486540518711775, 0.78867513459481288225}, w2[2] = {0.5, 0.5};
+    static const double g3[3] = {0.11270166537925831148, 0.5, 0.88729833462074168852}, w3[3] = {5.0 / 18.0, 8.0 / 18.0, 5.0 / 18.0};
+    const int N = d.N, p = d.p, q1 = p + 1, npe = d.npe, ke = d.ke;
+    const double *gp = p == 1 ? g2 : g3, *gw = p == 1 ? w2 : w3;
+    K0.assign((size_t) ke * ke, 0.0);
+    double vol = 1.0;
+    for (int a = 0; a < N; ++a) vol *= h[a];
+    int nq = 1;
+    for (int a = 0; a < N; ++a) nq *= q1;
+    std::vector<double> G((size_t) npe * 3);
+    for (int qi = 0; qi < nq; ++qi) {
+        int qa[3] = {0, 0, 0};
+        { int m = qi; for (int a = N - 1; a >= 0; --a) { qa[a] = m % q1; m /= q1; } }
+        double w = vol;
+        for (int a = 0; a < N; ++a) w *= gw[qa[a]];
+        for (int n = 0; n < npe; ++n) {
+            int l[3] = {0, 0, 0};
+            { int m = n; for (int a = N - 1; a >= 0; --a) { l[a] = m % q1; m /= q1; } }
+            for (int dd = 0; dd < N; ++dd) {
+                double v = 1.0;
+                for (int e = 0; e < N; ++e) v *= e == dd ? dlagrange1d(p, l[e], gp[qa[e]]) : lagrange1d(p, l[e], gp[qa[e]]);
+                G[3 * n + dd] = v / h[dd];
+            }
+        }
+        for (int n = 0; n < npe; ++n)
+            for (int m = 0; m < npe; ++m) {
+                double dot = 0.0;
+                for (int dd = 0; dd < N; ++dd) dot += G[3 * n + dd] * G[3 * m + dd];
+                for (int a = 0; a < N; ++a)
+                    for (int b = 0; b < N; ++b)
+                        K0[(size_t) (N * n + a) * ke + N * m + b] +=
+                            w * (lambda * G[3 * n + a] * G[3 * m + b] + mu * G[3 * n + b] * G[3 * m + a] + (a == b ? mu * dot : 0.0));
+            }
+    }
+    dK0.alloc(K0.size());
+    VFEM_HIP(hipMemcpy(dK0.p, K0.data(), K0.size() * sizeof(double), hipMemcpyHostToDevice));
+}
+
+static inline hipStream_t GS(void *s) { return (hipStream_t) s; }
+#define G_TRY try {
+#define G_CATCH } catch (const std::exception &e) { vfem::set_error(e.what()); return 1; } return 0;
+
+static void g_apply(const GDims &d, const double *K, long long kstride, const double *scale, const double *u,
+                    const double *b, const uint8_t *mask, int mode, double *out, hipStream_t s) {
+    kg_apply<<<dim3((unsigned) ((d.nnodes + 3) / 4)), dim3(256), 0, s>>>(d, K, kstride, scale, u, b, mask, mode, out);
+    VFEM_HIP(hipGetLastError());
+}
+
+static void level_op(const vfem_gmg *mg, int l, const double *&K, long long &kstride, const double *&scale) {
+    if (l == 0) { K = mg->fine->dK0.p; kstride = 0; scale = mg->fine->E.p; }
+    else { K = mg->lv[l].Ke.p; kstride = (long long) mg->lv[l].d.ke * mg->lv[l].d.ke; scale = nullptr; }
+}
+
+static void gmg_apply(vfem_gmg *mg, int l, const double *u, const double *b, int mode, double *out, hipStream_t s) {
+    const double *K, *scale; long long ks;
+    level_op(mg, l, K, ks, scale);
+    g_apply(mg->lv[l].d, K, ks, scale, u, b, mg->lv[l].mask.p, mode, out, s);
+}
+
+static void gmg_smooth(vfem_gmg *mg, int l, double *u, const double *b, int forward, hipStream_t s) {
+    const GDims &d = mg->lv[l].d;
+    const double *K, *scale; long long ks;
+    level_op(mg, l, K, ks, scale);
+    int ncol = 1;
+    for (int a = 0; a < d.N; ++a) ncol *= d.p + 1;
+    for (int i = 0; i < ncol; ++i) {
+        const int lni = forward ? i : ncol - 1 - i;                   // MG.hh:293-295
+        GColor col{};
+        col.total = 1;
+        int m = lni;
+        for (int a = d.N - 1; a >= 0; --a) {
+            const int la = m % (d.p + 1); m /= d.p + 1;
+            const bool boundary = la == 0 || la == d.p;
+            col.start[a] = la;
+            col.inc[a] = (1 + (boundary ? 1 : 0)) * d.p;              // MG.hh:301-305
+            col.cnt[a] = la > d.nn[a] - 1 ? 0 : (d.nn[a] - 1 - la) / col.inc[a] + 1;
+            col.total *= col.cnt[a];
+        }
+        for (int a = d.N; a < 3; ++a) { col.start[a] = 0; col.inc[a] = 1; col.cnt[a] = 1; }
+        if (col.total == 0) continue;
+        kg_gs_color<<<dim3((unsigned) ((col.total + 3) / 4)), dim3(256), 0, s>>>(d, col, K, ks, scale, u, b, mg->lv[l].mask.p, forward);
+    }
+    VFEM_HIP(hipGetLastError());
+}
+
+static void gmg_restrict(vfem_gmg *mg, int l, const double *fine, double *coarse, hipStream_t s) {
+    const GDims &f = mg->lv[l].d, &c = mg->lv[l + 1].d;
+    kg_restrict<<<dim3((unsigned) ((c.nnodes + 255) / 256)), dim3(256), 0, s>>>(f, c, mg->W, fine, coarse);
+    VFEM_HIP(hipGetLastError());
+}
+static void gmg_prolong(vfem_gmg *mg, int l, const double *coarse, double *fine, int accumulate, hipStream_t s) {
+    const GDims &f = mg->lv[l].d, &c = mg->lv[l + 1].d;
+    kg_prolong<<<dim3((unsigned) ((f.nnodes + 255) / 256)), dim3(256), 0, s>>>(f, c, mg->W, coarse, fine, accumulate);
+    VFEM_HIP(hipGetLastError());
+}
+static void g_dirichlet(const GDims &d, const uint8_t *mask, const double *vals, double *u, hipStream_t s) {
+    kg_dirichlet<<<dim3((unsigned) ((d.nnodes * d.N + 255) / 256)), dim3(256), 0, s>>>(d.nnodes, d.N, mask, vals, u);
+    VFEM_HIP(hipGetLastError());
+}
+static void gmg_coarsest(vfem_gmg *mg, const double *b, double *x, hipStream_t s) {
+    if (!mg->Ainv.p) throw Error("coarsest grid too large for the dense coarsest-level solve; use more coarsening levels");
+    launch_gemv_sym((long long) mg->lv[mg->L].d.N * mg->lv[mg->L].d.nnodes, mg->Ainv.p, b, x, s);
+}
+
+static void gmg_update(vfem_gmg *mg, hipStream_t s) {
+    vfem_gsim *sim = mg->fine;
+    const int N = sim->d.N;
+    for (int l = 1; l <= mg->L; ++l) {
+        GLevel &lv = mg->lv[l];
+        const size_t kk = (size_t) lv.d.ke * lv.d.ke;
+        lv.Ke.alloc((size_t) lv.d.nelems * kk);
+        if (l == 1) kg_coarsen_first<<<dim3((unsigned) lv.d.nelems), dim3(256), 0, s>>>(mg->lv[0].d, lv.d, mg->cK0.p, sim->E.p, lv.Ke.p);
+        else {
+            const size_t lds = 2 * kk * sizeof(double);
+            static bool attr = false;
+            if (!attr) { VFEM_HIP(hipFuncSetAttribute((const void *) kg_coarsen_next, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 81 * 81 * 8)); attr = true; }
+            kg_coarsen_next<<<dim3((unsigned) lv.d.nelems), dim3(256), lds, s>>>(mg->lv[l - 1].d, lv.d, mg->phi.p, mg->lv[l - 1].Ke.p, lv.Ke.p);
+        }
+        VFEM_HIP(hipGetLastError());
+    }
+    // coarsest level: assemble the dense matrix on the host (a few elements), invert with rocSOLVER
+    GLevel &cl = mg->lv[mg->L];
+    const GDims &d = cl.d;
+    const long long n = (long long) N * d.nnodes;
+    if (n > 40000) {
+        // a grid that cannot be coarsened (odd element counts) and is too large for the dense factorisation can still be
+        // solved by the unpreconditioned CG (mgSmoothingIterations = 0, MG.hh:476-479); any cycle on it throws
+        if (mg->L > 0) throw Error("coarsest grid too large for the dense coarsest-level solve (" + std::to_string(n) + " dofs); use more coarsening levels");
+        mg->Ainv.release();
+        mg->operators_valid = true;
+        return;
+    }
+    const size_t kk = (size_t) d.ke * d.ke;
+    std::vector<double> Ke((size_t) d.nelems * kk);
+    if (mg->L == 0) {
+        std::vector<double> E((size_t) d.nelems);
+        VFEM_HIP(hipMemcpyAsync(E.data(), sim->E.p, E.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        VFEM_HIP(hipStreamSynchronize(s));
+        for (long long e = 0; e < d.nelems; ++e)
+            for (size_t q = 0; q < kk; ++q) Ke[e * kk + q] = E[e] * sim->K0[q];
+    } else {
+        VFEM_HIP(hipMemcpyAsync(Ke.data(), cl.Ke.p, Ke.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        VFEM_HIP(hipStreamSynchronize(s));
+    }
+    std::vector<double> A((size_t) n * n, 0.0);
+    const int q1 = d.p + 1;
+    std::vector<long long> dofs(d.ke);
+    for (long long e = 0; e < d.nelems; ++e) {
+        int eb[3] = {0, 0, 0};
+        { long long m = e; for (int a = N - 1; a >= 0; --a) { eb[a] = d.p * (int) (m % d.ne[a]); m /= d.ne[a]; } }
+        for (int ln = 0; ln < d.npe; ++ln) {
+            int m = ln, g[3] = {0, 0, 0};
+            for (int a = N - 1; a >= 0; --a) { g[a] = eb[a] + m % q1; m /= q1; }
+            long long node = g[0];
+            for (int a = 1; a < N; ++a) node = node * d.nn[a] + g[a];
+            for (int c = 0; c < N; ++c) dofs[N * ln + c] = N * node + c;
+        }
+        for (int i = 0; i < d.ke; ++i)
+            for (int j = 0; j < d.ke; ++j) A[(size_t) dofs[i] * n + dofs[j]] += Ke[e * kk + (size_t) i * d.ke + j];
+    }
+    for (long long r = 0; r < n; ++r)
+        if ((cl.hmask[r / N] >> (r % N)) & 1) {
+            for (long long c = 0; c < n; ++c) { A[(size_t) r * n + c] = 0.0; A[(size_t) c * n + r] = 0.0; }
+            A[(size_t) r * n + r] = 1.0;
+        }
+    mg->Ainv.alloc((size_t) n * n);
+    VFEM_HIP(hipMemcpyAsync(mg->Ainv.p, A.data(), A.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    if (!mg->rocblas) {
+        rocblas_handle hnd;
+        if (rocblas_create_handle(&hnd) != rocblas_status_success) throw Error("rocblas_create_handle failed");
+        mg->rocblas = hnd;
+        mg->info.alloc(1);
+    }
+    rocblas_handle hnd = (rocblas_handle) mg->rocblas;
+    rocblas_set_stream(hnd, s);
+    if (rocsolver_dpotrf(hnd, rocblas_fill_lower, (rocblas_int) n, mg->Ainv.p, (rocblas_int) n, mg->info.p) != rocblas_status_success)
+        throw Error("rocsolver_dpotrf failed");
+    int info = 0;
+    VFEM_HIP(hipMemcpyAsync(&info, mg->info.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    VFEM_HIP(hipStreamSynchronize(s));
+    if (info != 0) throw Error("coarsest-level stiffness matrix is not positive definite (potrf info = " + std::to_string(info) + ")");
+    if (rocsolver_dpotri(hnd, rocblas_fill_lower, (rocblas_int) n, mg->Ainv.p, (rocblas_int) n, mg->info.p) != rocblas_status_success)
+        throw Error("rocsolver_dpotri failed");
+    kg_dense_finish<<<dim3((unsigned) ((n * n + 255) / 256)), dim3(256), 0, s>>>(n, N, cl.mask.p, mg->Ainv.p);
+    VFEM_HIP(hipGetLastError());
+    VFEM_HIP(hipStreamSynchronize(s));
+    mg->operators_valid = true;
+}
+
+// MG.hh:516-553
+static void gmg_vcycle(vfem_gmg *mg, int l, int nsmooth, bool residual_system, hipStream_t s) {
+    GLevel &L = mg->lv[l];
+    if (l == mg->L) { gmg_coarsest(mg, L.b.p, L.x.p, s); return; }
+    GLevel &C = mg->lv[l + 1];
+    g_dirichlet(L.d, L.mask.p, (l == 0 && !residual_system) ? mg->fine->dvals.p : nullptr, L.x.p, s);
+    for (int i = 0; i < nsmooth; ++i) gmg_smooth(mg, l, L.x.p, L.b.p, 1, s);
+    gmg_apply(mg, l, L.x.p, L.b.p, 1, L.r.p, s);
+    gmg_restrict(mg, l, L.r.p, C.b.p, s);
+    C.x.zero(s);
+    gmg_vcycle(mg, l + 1, nsmooth, true, s);
+    gmg_prolong(mg, l, C.x.p, L.x.p, 1, s);
+    for (int i = 0; i < nsmooth; ++i) gmg_smooth(mg, l, L.x.p, L.b.p, mg->symmetric_gs ? 0 : 1, s);
+}
+// MG.hh:486-508
+static void gmg_fmg(vfem_gmg *mg, int l, int nsmooth, bool residual_system, hipStream_t s) {
+    GLevel &L = mg->lv[l];
+    if (l == mg->L) { gmg_coarsest(mg, L.b.p, L.x.p, s); return; }
+    GLevel &C = mg->lv[l + 1];
+    gmg_restrict(mg, l, L.b.p, C.b.p, s);
+    gmg_fmg(mg, l + 1, nsmooth, residual_system, s);
+    gmg_prolong(mg, l, C.x.p, L.x.p, 0, s);
+    gmg_vcycle(mg, l, nsmooth, residual_system, s);
+}
+static void gmg_cycles(vfem_gmg *mg, int num_steps, int nsmooth, bool zero_dirichlet, bool fmg, hipStream_t s) {
+    if (fmg) {
+        gmg_fmg(mg, 0, nsmooth, zero_dirichlet, s);
+        for (int i = 1; i < num_steps; ++i) gmg_vcycle(mg, 0, nsmooth, zero_dirichlet, s);
+    } else
+        for (int i = 0; i < num_steps; ++i) gmg_vcycle(mg, 0, nsmooth, zero_dirichlet, s);
+}
+
+static void coarsen_mask(const GDims &f, const std::vector<uint8_t> &fm, const GDims &c, std::vector<uint8_t> &cm) {
+    // MG.hh:57-84 in integer arithmetic
+    const int N = f.N, p = f.p;
+    cm.assign((size_t) c.nnodes, 0);
+    for (long long nf = 0; nf < f.nnodes; ++nf) {
+        const uint8_t m = fm[nf];
+        if (!m) continue;
+        int g[3] = {0, 0, 0};
+        { long long q = nf; for (int a = N - 1; a >= 0; --a) { g[a] = (int) (q % f.nn[a]); q /= f.nn[a]; } }
+        int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        bool any = false;
+        for (int a = 0; a < N; ++a) {
+            const int e = std::min(g[a] / (2 * p), c.ne[a] - 1), t = g[a] - 2 * p * e;
+            if (t == 0) { lo[a] = hi[a] = p * e; any = true; }
+            else if (t == 2 * p) { lo[a] = hi[a] = p * e + p; any = true; }
+            else { lo[a] = p * e; hi[a] = p * e + p; }
+        }
+        if (!any) throw Error("Dirichlet constraints on internal nodes are not supported");
+        for (int a0 = lo[0]; a0 <= hi[0]; ++a0)
+            for (int a1 = lo[1]; a1 <= hi[1]; ++a1)
+                for (int a2 = lo[2]; a2 <= hi[2]; ++a2) {
+                    const int gg[3] = {a0, a1, a2};
+                    long long node = gg[0];
+                    for (int a = 1; a < N; ++a) node = node * c.nn[a] + gg[a];
+                    cm[node] |= m;
+                }
+    }
+}
+
+extern "C" {
+
+int vfem_gsim_create(vfem_gsim **out, int dim, int degree, const double *bbmin, const double *bbmax, const int64_t *ne) {
+    G_TRY
+    if (dim != 2 && dim != 3) throw Error("dimension must be 2 or 3");
+    if (degree != 1 && degree != 2) throw Error("No template instantiation matching degreesPerDimension!");
+    long long n[3] = {1, 1, 1};
+    for (int a = 0; a < dim; ++a) {
+        if (ne[a] < 1 || ne[a] > 4096) throw Error("elements per dimension must be in [1, 4096]");
+        n[a] = ne[a];
+    }
+    std::unique_ptr<vfem_gsim> sim(new vfem_gsim);
+    sim->d = make_gdims(dim, degree, n);
+    for (int a = 0; a < dim; ++a) {
+        sim->h[a] = (bbmax[a] - bbmin[a]) / (double) ne[a];
+        if (!(sim->h[a] > 0)) throw Error("empty domain bounding box");
+    }
+    sim->update_k0();
+    sim->rho.alloc((size_t) sim->d.nelems); sim->rho.zero(nullptr);
+    sim->E.alloc((size_t) sim->d.nelems);
+    sim->update_E(nullptr);
+    sim->hmask.assign((size_t) sim->d.nnodes, 0);
+    sim->dmask.alloc((size_t) sim->d.nnodes); sim->dmask.zero(nullptr);
+    sim->dvals.alloc((size_t) sim->d.nnodes * dim); sim->dvals.zero(nullptr);
+    VFEM_HIP(hipDeviceSynchronize());
+    *out = sim.release();
+    G_CATCH
+}
+int vfem_gsim_destroy(vfem_gsim *sim) { G_TRY delete sim; G_CATCH }
+int64_t vfem_gsim_num_nodes(const vfem_gsim *sim) { return sim->d.nnodes; }
+int64_t vfem_gsim_num_elements(const vfem_gsim *sim) { return sim->d.nelems; }
+int vfem_gsim_ke_size(const vfem_gsim *sim) { return sim->d.ke; }
+int vfem_gsim_set_isotropic(vfem_gsim *sim, double young, double poisson) {
+    G_TRY
+    // ElasticityTensor::setIsotropic (ElasticityTensor.hh:100-133): 3-D Lame parameters; 2-D = plane stress
+    sim->lambda = sim->d.N == 2 ? poisson * young / (1.0 - poisson * poisson)
+                                : poisson * young / ((1.0 + poisson) * (1.0 - 2.0 * poisson));
+    sim->mu = young / (2.0 + 2.0 * poisson);
+    sim->update_k0();
+    G_CATCH
+}
+int vfem_gsim_set_simp(vfem_gsim *sim, double E0, double Emin, double gamma) {
+    G_TRY
+    sim->E0 = E0; sim->Emin = Emin; sim->gamma = gamma;
+    sim->update_E(nullptr);
+    VFEM_HIP(hipDeviceSynchronize());
+    G_CATCH
+}
+int vfem_gsim_k0(const vfem_gsim *sim, double *K0_host) {
+    G_TRY std::memcpy(K0_host, sim->K0.data(), sim->K0.size() * sizeof(double)); G_CATCH
+}
+int vfem_gsim_set_dirichlet(vfem_gsim *sim, const uint8_t *mask_host, const double *values_host) {
+    G_TRY
+    sim->hmask.assign(mask_host, mask_host + sim->d.nnodes);
+    VFEM_HIP(hipMemcpy(sim->dmask.p, mask_host, (size_t) sim->d.nnodes, hipMemcpyHostToDevice));
+    VFEM_HIP(hipMemcpy(sim->dvals.p, values_host, (size_t) sim->d.nnodes * sim->d.N * sizeof(double), hipMemcpyHostToDevice));
+    G_CATCH
+}
+int vfem_gsim_set_densities(vfem_gsim *sim, const double *rho, void *stream) {
+    G_TRY
+    VFEM_HIP(hipMemcpyAsync(sim->rho.p, rho, (size_t) sim->d.nelems * sizeof(double), hipMemcpyDeviceToDevice, GS(stream)));
+    sim->update_E(GS(stream));
+    G_CATCH
+}
+int vfem_gsim_get_densities(const vfem_gsim *sim, double *rho, void *stream) {
+    G_TRY
+    VFEM_HIP(hipMemcpyAsync(rho, sim->rho.p, (size_t) sim->d.nelems * sizeof(double), hipMemcpyDeviceToDevice, GS(stream)));
+    G_CATCH
+}
+int vfem_gsim_apply_k(const vfem_gsim *sim, const double *u, double *out, void *stream) {
+    G_TRY
+    if (sim->d.N == 3 && sim->d.p == 2)
+        launch_apply_q2(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->dK0.p, sim->E.p, u, out, GS(stream));
+    else
+        g_apply(sim->d, sim->dK0.p, 0, sim->E.p, u, nullptr, nullptr, 0, out, GS(stream));
+    G_CATCH
+}
+int vfem_gsim_compliance_gradient(const vfem_gsim *sim, const double *u, double *g, void *stream) {
+    G_TRY
+    kg_gradient<<<dim3((unsigned) ((sim->d.nelems + 3) / 4)), dim3(256), 0, GS(stream)>>>(sim->d, sim->dK0.p, sim->rho.p, sim->E0, sim->Emin,
+                                                                                       sim->gamma, u, g);
+    VFEM_HIP(hipGetLastError());
+    G_CATCH
+}
+
+int vfem_gsim_compliance(const vfem_gsim *sim, const double *f, const double *u, double *value_host, void *stream) {
+    G_TRY
+    DevBuf<double> tmp;
+    tmp.alloc(4096 + 1);
+    launch_dot((long long) sim->d.N * sim->d.nnodes, f, u, tmp.p, tmp.p + 4096, GS(stream));
+    double v = 0.0;
+    VFEM_HIP(hipMemcpyAsync(&v, tmp.p + 4096, sizeof(double), hipMemcpyDeviceToHost, GS(stream)));
+    VFEM_HIP(hipStreamSynchronize(GS(stream)));
+    *value_host = 0.5 * v;                                            // TopologyOptimizationObjective.hh:39-41
+    G_CATCH
+}
+
+int vfem_gmg_create(vfem_gmg **out, vfem_gsim *fine, int L) {
+    G_TRY
+    if (L < 0 || L > 16) throw Error("invalid number of coarsening levels");
+    std::unique_ptr<vfem_gmg> mg(new vfem_gmg);
+    mg->fine = fine; mg->L = L;
+    mg->lv.resize(L + 1);
+    const int N = fine->d.N, p = fine->d.p;
+    long long ne[3] = {fine->d.ne[0], fine->d.ne[1], fine->d.ne[2]};
+    for (int l = 0; l <= L; ++l) {
+        GLevel &lv = mg->lv[l];
+        if (l > 0) {
+            for (int a = 0; a < N; ++a) {
+                if (ne[a] % 2) throw Error("Grid size currently must be divisible by 2^numCoarseningLevels (nonuniform coarsening not yet implemented)");
+                ne[a] /= 2;
+            }
+        }
+        lv.d = make_gdims(N, p, ne);
+        if (l == 0) lv.hmask = fine->hmask; else coarsen_mask(mg->lv[l - 1].d, mg->lv[l - 1].hmask, lv.d, lv.hmask);
+        lv.mask.alloc((size_t) lv.d.nnodes);
+        VFEM_HIP(hipMemcpy(lv.mask.p, lv.hmask.data(), lv.hmask.size(), hipMemcpyHostToDevice));
+        const size_t n = (size_t) lv.d.nnodes * N;
+        lv.x.alloc(n); lv.b.alloc(n); lv.r.alloc(n);
+        lv.x.zero(nullptr); lv.b.zero(nullptr); lv.r.zero(nullptr);
+    }
+    for (int t = 0; t < 5; ++t) for (int a = 0; a < 3; ++a) mg->W.w[t][a] = 0.0;
+    for (int t = 0; t <= 2 * p; ++t) for (int a = 0; a <= p; ++a) mg->W.w[t][a] = lagrange1d(p, a, (double) t / (2.0 * p));
+    // compressed interpolation operators phi[fi](fine_n, coarse_n) (MG.hh:557-583) and cK0[fi] = I_fi^T K0 I_fi (MG.hh:644-648)
+    const int npe = fine->d.npe, ke = fine->d.ke, q1 = p + 1, nch = 1 << N;
+    std::vector<double> phi((size_t) nch * npe * npe), cK0((size_t) nch * ke * ke, 0.0), T((size_t) ke * ke);
+    for (int fi = 0; fi < nch; ++fi) {
+        double *ph = phi.data() + (size_t) fi * npe * npe;
+        for (int fn = 0; fn < npe; ++fn)
+            for (int cn = 0; cn < npe; ++cn) {
+                int mf = fn, mc = cn;
+                double w = 1.0;
+                for (int a = N - 1; a >= 0; --a) {
+                    const int lf = mf % q1, lc = mc % q1; mf /= q1; mc /= q1;
+                    w *= mg->W.w[lf + p * ((fi >> a) & 1)][lc];
+                }
+                ph[fn * npe + cn] = w;
+            }
+        const std::vector<double> &K0 = fine->K0;
+        for (int i = 0; i < ke; ++i)
+            for (int j = 0; j < ke; ++j) {
+                const int m = j / N, b = j % N;
+                double v = 0.0;
+                for (int qn = 0; qn < npe; ++qn) v += K0[(size_t) i * ke + N * qn + b] * ph[qn * npe + m];
+                T[(size_t) i * ke + j] = v;
+            }
+        double *cK = cK0.data() + (size_t) fi * ke * ke;
+        for (int i = 0; i < ke; ++i)
+            for (int j = 0; j < ke; ++j) {
+                const int n = i / N, a = i % N;
+                double v = 0.0;
+                for (int pn = 0; pn < npe; ++pn) v += ph[pn * npe + n] * T[(size_t) (N * pn + a) * ke + j];
+                cK[(size_t) i * ke + j] = v;
+            }
+    }
+    mg->phi.alloc(phi.size()); mg->cK0.alloc(cK0.size());
+    VFEM_HIP(hipMemcpy(mg->phi.p, phi.data(), phi.size() * sizeof(double), hipMemcpyHostToDevice));
+    VFEM_HIP(hipMemcpy(mg->cK0.p, cK0.data(), cK0.size() * sizeof(double), hipMemcpyHostToDevice));
+    const size_t n0 = (size_t) fine->d.nnodes * N;
+    mg->pr.alloc(n0); mg->pd.alloc(n0); mg->pAd.alloc(n0); mg->ps.alloc(n0);
+    mg->scal.alloc(8); mg->scal.zero(nullptr); mg->scratch.alloc(4096);
+    VFEM_HIP(hipDeviceSynchronize());
+    *out = mg.release();
+    G_CATCH
+}
+int vfem_gmg_destroy(vfem_gmg *mg) {
+    G_TRY
+    if (mg && mg->rocblas) rocblas_destroy_handle((rocblas_handle) mg->rocblas);
+    delete mg;
+    G_CATCH
+}
+int vfem_gmg_num_levels(const vfem_gmg *mg) { return mg->L + 1; }
+int vfem_gmg_level_dims(const vfem_gmg *mg, int level, int64_t ne[3]) {
+    G_TRY
+    if (level < 0 || level > mg->L) throw Error("level out of range");
+    for (int a = 0; a < 3; ++a) ne[a] = mg->lv[level].d.ne[a];
+    G_CATCH
+}
+int64_t vfem_gmg_level_num_nodes(const vfem_gmg *mg, int level) { return (level < 0 || level > mg->L) ? -1 : mg->lv[level].d.nnodes; }
+int vfem_gmg_level_dirichlet_mask(const vfem_gmg *mg, int level, uint8_t *mask_host) {
+    G_TRY
+    if (level < 0 || level > mg->L) throw Error("level out of range");
+    std::memcpy(mask_host, mg->lv[level].hmask.data(), mg->lv[level].hmask.size());
+    G_CATCH
+}
+int vfem_gmg_set_symmetric_gauss_seidel(vfem_gmg *mg, int symmetric) { mg->symmetric_gs = symmetric != 0; return 0; }
+int vfem_gmg_update_operators(vfem_gmg *mg, void *stream) { G_TRY gmg_update(mg, GS(stream)); G_CATCH }
+static void g_check_level(const vfem_gmg *mg, int level, bool need_ops) {
+    if (level < 0 || level > mg->L) throw Error("level out of range");
+    if (need_ops && level > 0 && !mg->operators_valid) throw Error("coarse operators not built: call updateElementStiffnessMatrices first");
+}
+int vfem_gmg_apply_k(vfem_gmg *mg, int level, const double *u, double *out, void *stream) {
+    G_TRY g_check_level(mg, level, true); gmg_apply(mg, level, u, nullptr, 0, out, GS(stream)); G_CATCH
+}
+int vfem_gmg_residual(vfem_gmg *mg, int level, const double *u, const double *b, double *r, void *stream) {
+    G_TRY g_check_level(mg, level, true); gmg_apply(mg, level, u, b, 1, r, GS(stream)); G_CATCH
+}
+int vfem_gmg_smooth(vfem_gmg *mg, int level, double *u, const double *b, int forward, void *stream) {
+    G_TRY g_check_level(mg, level, true); gmg_smooth(mg, level, u, b, forward, GS(stream)); G_CATCH
+}
+int vfem_gmg_zero_dirichlet(vfem_gmg *mg, int level, double *u, void *stream) {
+    G_TRY g_check_level(mg, level, false); g_dirichlet(mg->lv[level].d, mg->lv[level].mask.p, nullptr, u, GS(stream)); G_CATCH
+}
+int vfem_gmg_restrict(vfem_gmg *mg, int fine_level, const double *fine, double *coarse, void *stream) {
+    G_TRY g_check_level(mg, fine_level + 1, false); gmg_restrict(mg, fine_level, fine, coarse, GS(stream)); G_CATCH
+}
+int vfem_gmg_interpolate(vfem_gmg *mg, int fine_level, const double *coarse, double *fine, int accumulate, void *stream) {
+    G_TRY g_check_level(mg, fine_level + 1, false); gmg_prolong(mg, fine_level, coarse, fine, accumulate, GS(stream)); G_CATCH
+}
+int vfem_gmg_solve(vfem_gmg *mg, double *x, const double *f, int num_steps, int nsmooth, int stiffness_updated,
+                   int zero_dirichlet, int fmg, void *stream) {
+    G_TRY
+    hipStream_t s = GS(stream);
+    if (!stiffness_updated) gmg_update(mg, s);                         // MG.hh:455
+    else if (!mg->operators_valid) throw Error("coarse operators not built");
+    if (num_steps == 0) return 0;
+    const size_t bytes = (size_t) mg->fine->d.nnodes * mg->fine->d.N * sizeof(double);
+    VFEM_HIP(hipMemcpyAsync(mg->lv[0].x.p, x, bytes, hipMemcpyDeviceToDevice, s));
+    VFEM_HIP(hipMemcpyAsync(mg->lv[0].b.p, f, bytes, hipMemcpyDeviceToDevice, s));
+    gmg_cycles(mg, num_steps, nsmooth, zero_dirichlet != 0, fmg != 0, s);
+    VFEM_HIP(hipMemcpyAsync(x, mg->lv[0].x.p, bytes, hipMemcpyDeviceToDevice, s));
+    G_CATCH
+}
+int vfem_gmg_pcg(vfem_gmg *mg, double *x, const double *b, int max_iter, double tol, int mg_iterations, int mg_smoothing,
+                 int fmg, vfem_residual_cb residual_cb, void *cb_user, int *iters_out, double *relres_out, void *stream) {
+    G_TRY
+    hipStream_t s = GS(stream);
+    vfem_gsim *sim = mg->fine;
+    const long long nn = sim->d.nnodes, n3 = sim->d.N * nn;
+    const size_t bytes = (size_t) n3 * sizeof(double);
+    double *r = mg->pr.p, *d = mg->pd.p, *Ad = mg->pAd.p, *sv = mg->ps.p, *sc = mg->scal.p;
+    const uint8_t *mask = mg->lv[0].mask.p;
+    g_dirichlet(sim->d, mask, sim->dvals.p, x, s);                       // MG.hh:687-688
+    gmg_update(mg, s);                                                   // MG.hh:690-691
+    double host_sc[4];
+    launch_dot(n3, b, b, mg->scratch.p, sc + 4, s);
+    gmg_apply(mg, 0, x, b, 1, r, s);                                     // MG.hh:696
+    launch_dot(n3, r, r, mg->scratch.p, sc + 3, s);
+    VFEM_HIP(hipMemcpyAsync(host_sc, sc + 3, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    VFEM_HIP(hipStreamSynchronize(s));
+    double rr = host_sc[0];
+    const double bb = host_sc[1];
+    int it = 0;
+    while (it < max_iter && rr > tol * tol * bb) {                       // MG.hh:711 (counter started at 0)
+        ++it;
+        if (mg_smoothing == 0) {
+            VFEM_HIP(hipMemcpyAsync(sv, r, bytes, hipMemcpyDeviceToDevice, s));
+        } else {
+            mg->lv[0].x.zero(s);
+            VFEM_HIP(hipMemcpyAsync(mg->lv[0].b.p, r, bytes, hipMemcpyDeviceToDevice, s));
+            gmg_cycles(mg, mg_iterations, mg_smoothing, true, fmg != 0, s);
+            VFEM_HIP(hipMemcpyAsync(sv, mg->lv[0].x.p, bytes, hipMemcpyDeviceToDevice, s));
+        }
+        g_dirichlet(sim->d, mask, nullptr, sv, s);
+        launch_shift_scalar(sc, s);
+        launch_dot(n3, r, sv, mg->scratch.p, sc + 0, s);
+        launch_pcg_direction(n3, sv, d, sc, it == 1, s);
+        gmg_apply(mg, 0, d, nullptr, 2, Ad, s);                          // zeroDirichlet(K d)
+        launch_dot(n3, d, Ad, mg->scratch.p, sc + 2, s);
+        launch_pcg_step(n3, x, r, d, Ad, sc, s);
+        launch_dot(n3, r, r, mg->scratch.p, sc + 3, s);
+        VFEM_HIP(hipMemcpyAsync(host_sc, sc + 3, sizeof(double), hipMemcpyDeviceToHost, s));
+        VFEM_HIP(hipStreamSynchronize(s));
+        rr = host_sc[0];
+        if (!(rr == rr)) throw Error("PCG produced NaN residual");
+        if (residual_cb) residual_cb(cb_user, it, std::sqrt(rr));
+    }
+    if (iters_out) *iters_out = it;
+    if (relres_out) *relres_out = bb > 0 ? std::sqrt(rr / bb) : 0.0;
+    G_CATCH
+}
+
+}  // extern "C"

@@ -356,6 +356,11 @@ class TensorProductSimulator1_1_1:
         _lib.check(self._lib.vfem_sim_compliance_gradient(self._h, _ptr(u), _ptr(g), _stream()))
         return g
 
+    def _compliance(self, f, u):
+        v = ctypes.c_double(0.0)
+        _lib.check(self._lib.vfem_compliance(self._h, _ptr(f), _ptr(u), ctypes.byref(v), _stream()))
+        return v.value
+
     def multigridSolver(self, numCoarseningLevels):
         return MultigridSolver1_1_1(self, int(numCoarseningLevels))
 
@@ -610,9 +615,7 @@ class ComplianceObjective1_1_1:
             self.updateCache(None)
 
     def compliance(self):
-        v = ctypes.c_double(0.0)
-        _lib.check(self._sim._lib.vfem_compliance(self._sim._h, _ptr(self._f), _ptr(self._u), ctypes.byref(v), _stream()))
-        return v.value
+        return self._sim._compliance(self._f, self._u)
 
     def evaluate(self, xPhys=None):
         return self.compliance()
@@ -961,38 +964,46 @@ class OCOptimizer1_1_1:
 # module-level factories (VoxelFEM.cc:136-216, 234-240)
 # ----------------------------------------------------------------------------------------------
 
-class TensorProductSimulator2_2_2:
-    """Degree-2 simulator (27-node hexahedra): grid, material, SIMP, ``applyK``, sensitivity.  The reference
-    templates support it (TPS.hh:97-110) but leave it unbound (VoxelFEM.cc:226-229); the multigrid hierarchy for
-    degree 2 is not built yet, so ``multigridSolver`` raises."""
+class _GenericSimulator:
+    """Generic path (``libvfem`` ``vfem_gsim_*``): TensorProductSimulator<p,..,p> for N = 2, 3 and p = 1, 2 other than
+    the tuned <1,1,1> instantiation -- the 2-D simulators the reference binds (VoxelFEM.cc:226, plane stress) and
+    the degree-2 elements its templates support (TPS.hh:97-110).  Same surface as ``TensorProductSimulator1_1_1``."""
 
     N = 3
+    P = 1
 
     def __init__(self, domainBoundingBox, numElemg):
         _lib.require_gpu()
         self._lib = _lib.load()
+        N, p = self.N, self.P
         lo = np.asarray(domainBoundingBox[0], dtype=np.float64).reshape(-1)
         hi = np.asarray(domainBoundingBox[1], dtype=np.float64).reshape(-1)
-        self._ne = np.array([int(v) for v in numElemg], dtype=np.int64)
-        if self._ne.size != 3:
-            raise RuntimeError("Dimension mismatch: %d vs 3" % self._ne.size)
-        self._nn = 2 * self._ne + 1
+        ne = [int(v) for v in numElemg]
+        if len(ne) != N or lo.size != N or hi.size != N:
+            raise RuntimeError("Dimension mismatch: %d vs %d" % (len(ne), N))
+        self._bbmin, self._bbmax = lo.copy(), hi.copy()
+        self._ne = np.array(ne, dtype=np.int64)
+        self._nn = p * self._ne + 1
         h = ctypes.c_void_p()
-        _lib.check(self._lib.vfem_simq2_create(ctypes.byref(h), lo.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
-                                               hi.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
-                                               self._ne.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
+        _lib.check(self._lib.vfem_gsim_create(
+            ctypes.byref(h), N, p, lo.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+            hi.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), self._ne.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
         self._h = h
-        self._E0, self._Emin, self._gamma = 1.0, 1e-9, 3.0
+        self._E0, self._Emin, self._gamma = 1.0, 1e-9, 3.0           # TPS.hh:1392-1394
+        self._mask = np.zeros((self.numNodes(), N), dtype=bool)
+        self._dvals = np.zeros((self.numNodes(), N))
+        self._loads = torch.zeros((self.numNodes(), N), dtype=torch.float64, device=_dev())
 
     def __del__(self):
         h = getattr(self, "_h", None)
         if h is not None and h.value:
             try:
-                self._lib.vfem_simq2_destroy(h)
+                self._lib.vfem_gsim_destroy(h)
             except Exception:
                 pass
             self._h = None
 
+    # ---- sizes / geometry ----
     def numNodes(self):
         return int(np.prod(self._nn))
 
@@ -1002,62 +1013,410 @@ class TensorProductSimulator2_2_2:
     def NbElementsPerDimension(self):
         return self._ne.copy()
 
+    def nodePosition(self, ni):
+        idx = np.array(np.unravel_index(int(ni), tuple(self._nn)), dtype=np.float64)
+        return self._bbmin + idx * (self._bbmax - self._bbmin) / (self._nn - 1.0)
+
+    def elementIndexForGridCell(self, cellIdxs):
+        return int(np.ravel_multi_index(tuple(int(c) for c in cellIdxs), tuple(self._ne)))
+
+    def elementNodes(self, ei):
+        e = np.array(np.unravel_index(int(ei), tuple(self._ne)))
+        out = []
+        for loc in np.ndindex(*([self.P + 1] * self.N)):
+            out.append(int(np.ravel_multi_index(tuple(self.P * e + np.array(loc)), tuple(self._nn))))
+        return np.array(out, dtype=np.uint64)
+
+    def elemNodeGlobalIndex(self, ei, n):
+        return int(self.elementNodes(ei)[int(n)])
+
+    # ---- material / SIMP ----
     def readMaterial(self, materialPath):
         young, poisson = _read_isotropic_material(materialPath)
-        _lib.check(self._lib.vfem_simq2_set_isotropic(self._h, young, poisson))
+        _lib.check(self._lib.vfem_gsim_set_isotropic(self._h, young, poisson))
 
     def _push_simp(self):
-        _lib.check(self._lib.vfem_simq2_set_simp(self._h, self._E0, self._Emin, self._gamma))
+        _lib.check(self._lib.vfem_gsim_set_simp(self._h, self._E0, self._Emin, self._gamma))
 
     E_0 = property(lambda s: s._E0, lambda s, v: (setattr(s, "_E0", float(v)), s._push_simp())[0])
     E_min = property(lambda s: s._Emin, lambda s, v: (setattr(s, "_Emin", float(v)), s._push_simp())[0])
     gamma = property(lambda s: s._gamma, lambda s, v: (setattr(s, "_gamma", float(v)), s._push_simp())[0])
 
     def fullDensityElementStiffnessMatrix(self):
-        K0 = np.empty((81, 81))
-        _lib.check(self._lib.vfem_simq2_k0(self._h, K0.ctypes.data_as(ctypes.c_void_p)))
+        ke = int(self._lib.vfem_gsim_ke_size(self._h))
+        K0 = np.empty((ke, ke))
+        _lib.check(self._lib.vfem_gsim_k0(self._h, K0.ctypes.data_as(ctypes.c_void_p)))
         return K0
 
+    def elementStiffnessMatrix(self, ei):
+        rho = self.elementDensity(ei)
+        return (self._Emin + rho ** self._gamma * (self._E0 - self._Emin)) * self.fullDensityElementStiffnessMatrix()
+
+    def clearCachedElementStiffness(self):
+        pass
+
+    # ---- densities ----
     def setElementDensities(self, rho):
         t = _to_dev(rho, (self.numElements(),))
-        _lib.check(self._lib.vfem_simq2_set_densities(self._h, _ptr(t), _stream()))
+        _lib.check(self._lib.vfem_gsim_set_densities(self._h, _ptr(t), _stream()))
 
     def setUniformDensities(self, density):
         if density > 1.0 or density < 0:
             raise RuntimeError("Density value (%f) has to be in between 0 and 1" % density)
         self.setElementDensities(torch.full((self.numElements(),), float(density), dtype=torch.float64, device=_dev()))
 
-    def getDensities(self):
+    def getDensities_device(self):
         t = torch.empty(self.numElements(), dtype=torch.float64, device=_dev())
-        _lib.check(self._lib.vfem_simq2_get_densities(self._h, _ptr(t), _stream()))
-        return _to_np(t)
+        _lib.check(self._lib.vfem_gsim_get_densities(self._h, _ptr(t), _stream()))
+        return t
 
+    def getDensities(self):
+        return _to_np(self.getDensities_device())
+
+    def setElementDensity(self, ei, value):
+        t = self.getDensities_device()
+        t[int(ei)] = float(value)
+        self.setElementDensities(t)
+
+    def elementDensity(self, ei):
+        return float(self.getDensities_device()[int(ei)].item())
+
+    # ---- boundary conditions ----
+    def _push_dirichlet(self):
+        m = np.zeros(self.numNodes(), dtype=np.uint8)
+        for c in range(self.N):
+            m |= self._mask[:, c].astype(np.uint8) << c
+        vals = np.ascontiguousarray(self._dvals)
+        _lib.check(self._lib.vfem_gsim_set_dirichlet(self._h, m.ctypes.data_as(ctypes.c_void_p),
+                                                    vals.ctypes.data_as(ctypes.c_void_p)))
+
+    def applyDisplacementsAndLoadsFromFile(self, bcPath):
+        """applyDisplacementsAndLoads (TPS.hh:358-409), see ``TensorProductSimulator1_1_1``."""
+        N = self.N
+        size = self._bbmax - self._bbmin
+        spacing = size / (self._nn - 1.0)
+        coords = [self._bbmin[d] + np.arange(self._nn[d]) * spacing[d] for d in range(N)]
+        shape = tuple(self._nn)
+        mask3 = self._mask.reshape(shape + (N,))
+        vals3 = self._dvals.reshape(shape + (N,))
+        loads = np.zeros(shape + (N,))
+        loads[...] = _to_np(self._loads).reshape(shape + (N,))
+        for kind, comps, value, lo, hi, relative in _parse_regions(bcPath):
+            lo, hi = np.array(lo[:N]), np.array(hi[:N])
+            if relative:
+                lo, hi = self._bbmin + lo * size, self._bbmin + hi * size
+            sel = [np.flatnonzero((coords[d] >= lo[d]) & (coords[d] <= hi[d])) for d in range(N)]
+            count = int(np.prod([s.size for s in sel]))
+            blk = np.ix_(*sel)
+            if kind == "force":
+                if count == 0:
+                    raise RuntimeError("Force constraint region unmatched")
+                for c in range(N):
+                    loads[..., c][blk] = value[c] / count
+            else:
+                if count == 0:
+                    raise RuntimeError("Dirichlet region unmatched")
+                for c, name in enumerate("xyz"[:N]):
+                    if name not in comps:
+                        continue
+                    already = mask3[..., c][blk]
+                    if np.any(already & (np.abs(vals3[..., c][blk] - value[c]) > 1e-10)):
+                        raise RuntimeError("Conflicting dirichlet displacements.")
+                    vc = vals3[..., c]
+                    mc = mask3[..., c]
+                    vc[blk] = np.where(already, vc[blk], value[c])
+                    mc[blk] = True
+        self._loads = _to_dev(loads.reshape(-1, N))
+        self._push_dirichlet()
+
+    def _get_mask(self):
+        return self._mask.copy()
+
+    def _set_mask(self, mask):
+        mask = np.asarray(mask, dtype=bool)
+        if mask.shape != (self.numNodes(), self.N):
+            raise RuntimeError("Size mismatch")
+        self._mask = mask.copy()
+        self._push_dirichlet()
+
+    def _get_dvals(self):
+        return self._dvals.copy()
+
+    def _set_dvals(self, values):
+        values = np.asarray(values, dtype=np.float64)
+        if values.shape != (self.numNodes(), self.N):
+            raise RuntimeError("Size mismatch")
+        self._dvals = values.copy()
+        self._push_dirichlet()
+
+    dirichletMask = property(_get_mask, _set_mask)
+    dirichletValues = property(_get_dvals, _set_dvals)
+
+    def getDirichletVarsAndValues(self):
+        idx = np.flatnonzero(self._mask.reshape(-1))
+        return list(idx), list(self._dvals.reshape(-1)[idx])
+
+    def getForceMask(self):
+        return (_to_np(self._loads) != 0)
+
+    def setLoads_device(self, f):
+        self._loads = _to_dev(f, (self.numNodes(), self.N)).clone()
+
+    def buildLoadVector_device(self):
+        return self._loads.clone()
+
+    def buildLoadVector(self):
+        return _to_np(self._loads)
+
+    # ---- operators ----
     def applyK_device(self, u):
-        u = _to_dev(u, (self.numNodes(), 3))
+        u = _to_dev(u, (self.numNodes(), self.N))
         out = torch.empty_like(u)
-        _lib.check(self._lib.vfem_simq2_apply_k(self._h, _ptr(u), _ptr(out), _stream()))
+        _lib.check(self._lib.vfem_gsim_apply_k(self._h, _ptr(u), _ptr(out), _stream()))
         return out
 
     def applyK(self, u):
         return _to_np(self.applyK_device(u))
 
     def complianceGradient_device(self, u):
-        u = _to_dev(u, (self.numNodes(), 3))
+        u = _to_dev(u, (self.numNodes(), self.N))
         g = torch.empty(self.numElements(), dtype=torch.float64, device=_dev())
-        _lib.check(self._lib.vfem_simq2_compliance_gradient(self._h, _ptr(u), _ptr(g), _stream()))
+        _lib.check(self._lib.vfem_gsim_compliance_gradient(self._h, _ptr(u), _ptr(g), _stream()))
         return g
 
+    def _compliance(self, f, u):
+        v = ctypes.c_double(0.0)
+        _lib.check(self._lib.vfem_gsim_compliance(self._h, _ptr(f), _ptr(u), ctypes.byref(v), _stream()))
+        return v.value
+
     def multigridSolver(self, numCoarseningLevels):
-        raise RuntimeError("the degree-2 multigrid hierarchy is not built yet")
+        return _GenericMultigridSolver(self, int(numCoarseningLevels))
+
+    def _direct_levels(self):
+        lv, ne = 0, self._ne.copy()
+        while np.all(ne % 2 == 0) and np.prod(self.P * ne + 1) * self.N > 3000 and lv < 12:
+            ne //= 2
+            lv += 1
+        return lv
+
+    def solve(self, f):
+        """TPS::solve (TPS.hh:834-865).  The reference factorises with CHOLMOD; here the same system is solved by
+        multigrid-preconditioned CG driven to a relative residual of 1e-11 (the coarsest level is a dense Cholesky)."""
+        if np.any(self._dvals[self._mask] != 0):
+            raise RuntimeError("Nonzero Dirichlet constraints currently unsupported")
+        mg = getattr(self, "_direct_mg", None)
+        if mg is None:
+            mg = self.multigridSolver(self._direct_levels())
+            self._direct_mg = mg
+        # a grid with odd element counts cannot be coarsened; beyond the dense-factorisation size it is solved by plain CG
+        plain = mg.L == 0 and self.numNodes() * self.N > 40000
+        u = mg.preconditionedConjugateGradient_device(
+            torch.zeros((self.numNodes(), self.N), dtype=torch.float64, device=_dev()),
+            _to_dev(f, (self.numNodes(), self.N)), 500000 if plain else 2000, 1e-11, None, 1, 0 if plain else 2, True)
+        if mg.last_relative_residual > 1e-10:
+            raise RuntimeError("direct-solve replacement did not converge (relative residual %g)" % mg.last_relative_residual)
+        return _to_np(u)
+
+    def solveWithImposedLoads(self):
+        return self.solve(self.buildLoadVector())
+
+
+class TensorProductSimulator1_1(_GenericSimulator):
+    """``pyVoxelFEM.detail.TensorProductSimulator1_1`` (VoxelFEM.cc:226): bilinear quadrilaterals, plane stress."""
+    N, P = 2, 1
+
+
+class TensorProductSimulator2_2(_GenericSimulator):
+    N, P = 2, 2
+
+
+class TensorProductSimulator2_2_2(_GenericSimulator):
+    """27-node hexahedra; supported by the reference templates (TPS.hh:97-110), unbound there (VoxelFEM.cc:226-229)."""
+    N, P = 3, 2
+
+
+class _GenericLevelView:
+    def __init__(self, mg, l):
+        self._mg, self._l = mg, l
+
+    def numNodes(self):
+        return self._mg._nn(self._l)
+
+    def NbElementsPerDimension(self):
+        ne = (ctypes.c_int64 * 3)()
+        _lib.check(self._mg._lib.vfem_gmg_level_dims(self._mg._h, self._l, ne))
+        return np.array(list(ne)[:self._mg.N], dtype=np.int64)
+
+    def numElements(self):
+        return int(np.prod(self.NbElementsPerDimension()))
+
+    @property
+    def dirichletMask(self):
+        m = np.empty(self.numNodes(), dtype=np.uint8)
+        _lib.check(self._mg._lib.vfem_gmg_level_dirichlet_mask(self._mg._h, self._l, m.ctypes.data_as(ctypes.c_void_p)))
+        return np.stack([(m >> c) & 1 for c in range(self._mg.N)], axis=1).astype(bool)
+
+
+class _GenericMultigridSolver:
+    """MultigridSolver<p,..,p> on the generic path (MG.hh); same surface as ``MultigridSolver1_1_1``."""
+
+    def __init__(self, tps, numCoarseningLevels):
+        self._lib = _lib.load()
+        self._tps = tps
+        self.N = tps.N
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.vfem_gmg_create(ctypes.byref(h), tps._h, int(numCoarseningLevels)))
+        self._h = h
+        self.L = int(numCoarseningLevels)
+        self.buildBlockStiffnessMatrices = True
+        self.buildFinestBlockStiffnessMatrix = False
+        self.last_iterations = 0
+        self.last_relative_residual = 0.0
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                self._lib.vfem_gmg_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def _nn(self, l):
+        n = int(self._lib.vfem_gmg_level_num_nodes(self._h, int(l)))
+        if n < 0:
+            raise IndexError("vector::_M_range_check")
+        return n
+
+    def getSimulator(self, l):
+        self._nn(l)
+        return self._tps if int(l) == 0 else _GenericLevelView(self, int(l))
+
+    def setSymmetricGaussSeidel(self, symmetric):
+        self._lib.vfem_gmg_set_symmetric_gauss_seidel(self._h, int(bool(symmetric)))
+
+    def updateElementStiffnessMatrices(self):
+        _lib.check(self._lib.vfem_gmg_update_operators(self._h, _stream()))
+
+    updateBlockKs = updateElementStiffnessMatrices
+
+    def applyK_device(self, l, u):
+        u = _to_dev(u, (self._nn(l), self.N))
+        out = torch.empty_like(u)
+        _lib.check(self._lib.vfem_gmg_apply_k(self._h, int(l), _ptr(u), _ptr(out), _stream()))
+        return out
+
+    def applyK(self, l, u):
+        return _to_np(self.applyK_device(l, u))
+
+    def computeResidual_device(self, l, u, b):
+        u = _to_dev(u, (self._nn(l), self.N))
+        b = _to_dev(b, (self._nn(l), self.N))
+        r = torch.empty_like(u)
+        _lib.check(self._lib.vfem_gmg_residual(self._h, int(l), _ptr(u), _ptr(b), _ptr(r), _stream()))
+        return r
+
+    def computeResidual(self, l, u, b):
+        return _to_np(self.computeResidual_device(l, u, b))
+
+    def smoothing_device(self, l, u, b, forward=True):
+        u = _to_dev(u, (self._nn(l), self.N)).clone()
+        b = _to_dev(b, (self._nn(l), self.N))
+        _lib.check(self._lib.vfem_gmg_smooth(self._h, int(l), _ptr(u), _ptr(b), int(bool(forward)), _stream()))
+        return u
+
+    def smoothing(self, l, u, b):
+        self.updateElementStiffnessMatrices()
+        return _to_np(self.smoothing_device(l, u, b, True))
+
+    def zeroOutDirichletComponents(self, l, u):
+        t = _to_dev(u, (self._nn(l), self.N)).clone()
+        _lib.check(self._lib.vfem_gmg_zero_dirichlet(self._h, int(l), _ptr(t), _stream()))
+        return _to_np(t)
+
+    def restriction_device(self, fine_level, values):
+        v = _to_dev(values, (self._nn(fine_level), self.N))
+        out = torch.empty((self._nn(fine_level + 1), self.N), dtype=torch.float64, device=_dev())
+        _lib.check(self._lib.vfem_gmg_restrict(self._h, int(fine_level), _ptr(v), _ptr(out), _stream()))
+        return out
+
+    def interpolation_device(self, fine_level, values, out=None):
+        v = _to_dev(values, (self._nn(fine_level + 1), self.N))
+        acc = out is not None
+        if out is None:
+            out = torch.empty((self._nn(fine_level), self.N), dtype=torch.float64, device=_dev())
+        _lib.check(self._lib.vfem_gmg_interpolate(self._h, int(fine_level), _ptr(v), _ptr(out), int(acc), _stream()))
+        return out
+
+    def debugMulticolorVisit(self):
+        """Visit order of the multicoloured sweep on level 0 (MG.hh:285-334)."""
+        nn, p, N = tuple(self._tps._nn), self._tps.P, self.N
+        result = np.zeros(nn, dtype=np.int32)
+        counter = 0
+        for lni in np.ndindex(*([p + 1] * N)):
+            sl = tuple(slice(lni[d], None, (2 if lni[d] in (0, p) else 1) * p) for d in range(N))
+            sub = result[sl]
+            sub[...] = counter + np.arange(sub.size).reshape(sub.shape)
+            counter += sub.size
+        return result.reshape(-1)
+
+    def solve_device(self, u, f, numSteps, numSmoothingSteps, stiffnessUpdated=False, zeroDirichlet=False,
+                     it_callback=None, fullMultigrid=False):
+        x = _to_dev(u, (self._nn(0), self.N)).clone()
+        f = _to_dev(f, (self._nn(0), self.N))
+        steps = [(int(numSteps), bool(stiffnessUpdated), bool(fullMultigrid))] if it_callback is None else \
+            [(1, bool(stiffnessUpdated) or i > 0, bool(fullMultigrid) and i == 0) for i in range(int(numSteps))]
+        for i, (n, upd, fmg) in enumerate(steps):
+            _lib.check(self._lib.vfem_gmg_solve(self._h, _ptr(x), _ptr(f), n, int(numSmoothingSteps), int(upd),
+                                                int(bool(zeroDirichlet)), int(fmg), _stream()))
+            if it_callback is not None:
+                it_callback(i, _to_np(x))
+        return x
+
+    def solve(self, u, f, numSteps, numSmoothingSteps, stiffnessUpdated=False, zeroDirichlet=False,
+              it_callback=None, fullMultigrid=False):
+        return _to_np(self.solve_device(u, f, numSteps, numSmoothingSteps, stiffnessUpdated, zeroDirichlet,
+                                        it_callback, fullMultigrid))
+
+    def preconditionedConjugateGradient_device(self, u, b, maxIter, tol, it_callback=None, mgIterations=1,
+                                               mgSmoothingIterations=1, fullMultigrid=False, residual_cb=None):
+        x = _to_dev(u).reshape(-1, self.N).clone()
+        b = _to_dev(b).reshape(-1, self.N)
+        if x.shape[0] != b.shape[0]:
+            raise RuntimeError("x and b should have the same size")
+        if x.shape[0] != self._nn(0):
+            raise RuntimeError("size of input and number of nodes don't correspond")
+        its, rel = ctypes.c_int(0), ctypes.c_double(0.0)
+
+        def _cb(_user, it, rnorm):
+            if residual_cb is not None:
+                residual_cb(it, rnorm)
+            if it_callback is not None:
+                it_callback(it, _to_np(x), None)
+
+        cb = _lib.RESIDUAL_CB(_cb) if (residual_cb is not None or it_callback is not None) else _lib.RESIDUAL_CB()
+        _lib.check(self._lib.vfem_gmg_pcg(self._h, _ptr(x), _ptr(b), int(maxIter), float(tol), int(mgIterations),
+                                          int(mgSmoothingIterations), int(bool(fullMultigrid)), cb, None,
+                                          ctypes.byref(its), ctypes.byref(rel), _stream()))
+        self.last_iterations = its.value
+        self.last_relative_residual = rel.value
+        return x
+
+    def preconditionedConjugateGradient(self, u, b, maxIter, tol, it_callback=None, mgIterations=1,
+                                        mgSmoothingIterations=1, fullMultigrid=False):
+        return _to_np(self.preconditionedConjugateGradient_device(u, b, maxIter, tol, it_callback, mgIterations,
+                                                                  mgSmoothingIterations, fullMultigrid))
 
 
 def TensorProductSimulator(degreesPerDimension, domainBBox, elementsPerDimension):
+    """VoxelFEM.cc:234-240 (+ the degree-2 instantiations the reference leaves commented out, :227,229)"""
     degs = [int(d) for d in degreesPerDimension]
-    if degs == [1, 1, 1]:
-        return TensorProductSimulator1_1_1(domainBBox, elementsPerDimension)
-    if degs == [2, 2, 2]:
-        return TensorProductSimulator2_2_2(domainBBox, elementsPerDimension)
-    raise RuntimeError("No template instantiation matching degreesPerDimension!")
+    classes = {(1, 1, 1): TensorProductSimulator1_1_1, (1, 1): TensorProductSimulator1_1,
+               (2, 2): TensorProductSimulator2_2, (2, 2, 2): TensorProductSimulator2_2_2}
+    cls = classes.get(tuple(degs))
+    if cls is None:
+        raise RuntimeError("No template instantiation matching degreesPerDimension!")
+    return cls(domainBBox, elementsPerDimension)
 
 
 def TopologyOptimizationProblem(simulator, objective, constraints, filters):
@@ -1126,6 +1485,8 @@ def benchmark_report(include_messages=False):
 detail = types.ModuleType(__name__ + ".detail")
 detail.TensorProductSimulator1_1_1 = TensorProductSimulator1_1_1
 detail.TensorProductSimulator2_2_2 = TensorProductSimulator2_2_2
+detail.TensorProductSimulator1_1 = TensorProductSimulator1_1
+detail.TensorProductSimulator2_2 = TensorProductSimulator2_2
 detail.MultigridSolver1_1_1 = MultigridSolver1_1_1
 detail.TopologyOptimizationProblem1_1_1 = TopologyOptimizationProblem1_1_1
 detail.ComplianceObjective1_1_1 = ComplianceObjective1_1_1

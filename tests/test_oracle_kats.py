@@ -167,3 +167,55 @@ def test_degree2_element_analytic_properties():
     g = np.stack(np.meshgrid(*[np.arange(5)] * 3, indexing="ij"), axis=-1).reshape(-1, 3) * 0.5 * o.h
     f = o.apply_k(g @ A.T).reshape(5, 5, 5, 3)
     assert np.abs(f[1:4, 1:4, 1:4]).max() < 1e-12
+
+
+@pytest.mark.parametrize("N,ne,dom,bc", [(2, (16, 8), ([0, 0], [2, 1]), "2d/mbb_beam.bc"),
+                                        (3, (8, 4, 4), ([0, 0, 0], [2, 1, 1]), "3d/cantilever_flexion.bc")])
+def test_generic_oracle_equals_element_loop_oracle_at_degree_1(N, ne, dom, bc):
+    """The sparse-matrix generic restatement (used to check the degree-2 and 2-D HIP paths) must agree with the
+    element-loop restatement that reproduces the reference's logs, operator by operator, at degree 1."""
+    from oracle import generic_oracle as go
+    from oracle import vfem_oracle as vo
+    import helpers
+    bcp = os.path.join(helpers.GOLDEN, "bcs", bc)
+    if not os.path.exists(bcp):
+        pytest.skip("no such golden BC file")
+    a = vo.OracleSim(dom, ne)
+    a.read_material(helpers.MATERIAL)
+    a.apply_bc_file(bcp)
+    rho = np.random.default_rng(2).uniform(0.1, 1, size=a.num_elems)
+    a.Emin = 1e-4
+    a.set_densities(rho)
+    g = go.GenericSim(N, 1, dom, ne, 1.0, 0.3)
+    g.Emin = 1e-4
+    g.rho = rho.copy()
+    g.apply_bc_file(bcp)
+    assert np.abs(g.K0 - a.K0).max() < 1e-14
+    assert np.array_equal(g.mask, a.dmask != 0)
+    assert np.abs(g.loads - a.build_load_vector()).max() < 1e-15
+    u = np.random.default_rng(3).standard_normal((a.num_nodes, N))
+    assert np.abs(g.apply_k(u) - a.apply_k(u)).max() < 1e-12
+    assert np.abs(g.compliance_gradient(u) - a.compliance_gradient(u)).max() < 1e-12
+    ma, mg = vo.OracleMG(a, 2), go.GenericMG(g, 2)
+    ma.update_element_stiffness()
+    mg.update_element_stiffness()
+    for l in range(3):
+        assert np.array_equal(mg.sims[l].mask, ma.sims[l].dmask != 0)
+        v = np.random.default_rng(l).standard_normal((ma.sims[l].num_nodes, N))
+        assert np.abs(mg.apply_k(l, v) - ma.apply_k(l, v)).max() < 1e-12
+        if l < 2:
+            b = np.random.default_rng(9).standard_normal(v.shape)
+            x1, x2 = v.copy(), v.copy()
+            ma.zero_dirichlet(l, x1), mg.zero_dirichlet(l, x2)
+            for fwd in (True, False):
+                ma.smoothing(l, x1, b, fwd)
+                mg.smoothing(l, x2, b, fwd)
+                assert np.abs(x1 - x2).max() < 1e-11 * np.abs(x1).max()
+            assert np.abs(mg.restriction(l, v) - ma.restriction(l, v)).max() < 1e-13
+            w = np.random.default_rng(5).standard_normal((ma.sims[l + 1].num_nodes, N))
+            assert np.abs(mg.interpolation(l, w) - ma.interpolation(l, w)).max() < 1e-14
+    f = a.build_load_vector()
+    xa = ma.pcg(np.zeros_like(f), f, 50, 1e-8, 1, 2, True)
+    xg = mg.pcg(np.zeros_like(f), f, 50, 1e-8, 1, 2, True)
+    assert ma.last_iters == mg.last_iters
+    assert np.abs(xa - xg).max() < 1e-9 * np.abs(xa).max()
