@@ -33,7 +33,6 @@ extern "C" {
 typedef struct vfem_sim vfem_sim;   /* TensorProductSimulator<1,1,1>              (TPS.hh:219) */
 typedef struct vfem_mg  vfem_mg;    /* MultigridSolver<1,1,1>                      (MG.hh:11)   */
 typedef struct vfem_mlp vfem_mlp;
-typedef struct vfem_simq2 vfem_simq2;
 typedef struct vfem_gsim vfem_gsim;   /* TensorProductSimulator<p,..,p>, N = 2 or 3, p = 1 or 2 (generic path) */
 typedef struct vfem_gmg vfem_gmg;     /* MultigridSolver<p,..,p> of the generic path */ /* TensorProductSimulator<2,2,2> (27-node hexahedra; unbound in the reference, VoxelFEM.cc:226-229) */   /* networks.MLP (Fourier features + ReLU MLP)  (networks.py:128) */
 
@@ -155,21 +154,6 @@ int vfem_mg_pcg(vfem_mg *mg, double *x, const double *b, int max_iter, double to
                 int mg_iterations, int mg_smoothing_iterations, int fmg,
                 vfem_residual_cb residual_cb, void *cb_user,
                 int *iterations_out_host, double *relres_out_host, void *stream);
-
-/* ---- degree-2 simulator: TensorProductSimulator<2,2,2>.  Nodes (2nx+1)(2ny+1)(2nz+1), local node index
- * 9a+3b+c, K0 81x81 by 3-point Gauss quadrature (TPS.hh:110,127-140).  Operators: applyK (TPS.hh:905-952) and
- * complianceGradient (TPS.hh:730-751); the degree-2 multigrid hierarchy is not built yet. */
-int vfem_simq2_create(vfem_simq2 **out, const double bbox_min_host[3], const double bbox_max_host[3], const int64_t nelems_host[3]);
-int vfem_simq2_destroy(vfem_simq2 *sim);
-int64_t vfem_simq2_num_nodes(const vfem_simq2 *sim);
-int64_t vfem_simq2_num_elements(const vfem_simq2 *sim);
-int vfem_simq2_set_isotropic(vfem_simq2 *sim, double young, double poisson);
-int vfem_simq2_set_simp(vfem_simq2 *sim, double E0, double Emin, double gamma);
-int vfem_simq2_k0(const vfem_simq2 *sim, double *K0_host);          /* 81 x 81 row-major */
-int vfem_simq2_set_densities(vfem_simq2 *sim, const double *rho, void *stream);
-int vfem_simq2_get_densities(const vfem_simq2 *sim, double *rho, void *stream);
-int vfem_simq2_apply_k(const vfem_simq2 *sim, const double *u, double *out, void *stream);
-int vfem_simq2_compliance_gradient(const vfem_simq2 *sim, const double *u, double *g, void *stream);
 
 /* ---- generic path: every instantiation other than the tuned <1,1,1> one.  TensorProductSimulator<1,1> / <2,2> (2-D, plane
  * stress, ElasticityTensor.hh:100-133; the reference binds <1,1>, VoxelFEM.cc:226) and <2,2,2>; MultigridSolver of the same

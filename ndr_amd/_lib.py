@@ -70,17 +70,6 @@ SIGNATURES = {
     "vfem_mg_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vfem_mg_pcg": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_int, c_int,
                             RESIDUAL_CB, c_void_p, POINTER(c_int), POINTER(c_double), c_void_p]),
-    "vfem_simq2_create": (c_int, [POINTER(c_void_p), POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
-    "vfem_simq2_destroy": (c_int, [c_void_p]),
-    "vfem_simq2_num_nodes": (c_int64, [c_void_p]),
-    "vfem_simq2_num_elements": (c_int64, [c_void_p]),
-    "vfem_simq2_set_isotropic": (c_int, [c_void_p, c_double, c_double]),
-    "vfem_simq2_set_simp": (c_int, [c_void_p, c_double, c_double, c_double]),
-    "vfem_simq2_k0": (c_int, [c_void_p, c_void_p]),
-    "vfem_simq2_set_densities": (c_int, [c_void_p, c_void_p, c_void_p]),
-    "vfem_simq2_get_densities": (c_int, [c_void_p, c_void_p, c_void_p]),
-    "vfem_simq2_apply_k": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
-    "vfem_simq2_compliance_gradient": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "vfem_gsim_create": (c_int, [POINTER(c_void_p), c_int, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
     "vfem_gsim_destroy": (c_int, [c_void_p]),
     "vfem_gsim_num_nodes": (c_int64, [c_void_p]),

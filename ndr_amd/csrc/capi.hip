@@ -778,102 +778,6 @@ int vfem_mg_pcg(vfem_mg *mg, double *x, const double *b, int max_iter, double to
     VFEM_CATCH
 }
 
-// ---- degree-2 simulator ----
-}  // extern "C"
-// Reference element stiffness for tensor-product Lagrange elements of degree 2 (nodes at 0, 1/2, 1 per axis) by
-// 3-point Gauss quadrature per axis, as Element_T::Stiffness does with TensorProductQuadrature<4,4,4>
-// (TPS.hh:110, 127-140; TensorProductQuadrature.hh:118-133).
-void vfem_simq2::update_k0() {
-    static const double gp[3] = {0.11270166537925831148, 0.5, 0.88729833462074168852};
-    static const double gw[3] = {5.0 / 18.0, 8.0 / 18.0, 5.0 / 18.0};
-    auto N = [](int i, double x) { return i == 0 ? 2.0 * (x - 0.5) * (x - 1.0) : (i == 1 ? -4.0 * x * (x - 1.0) : 2.0 * x * (x - 0.5)); };
-    auto dN = [](int i, double x) { return i == 0 ? 4.0 * x - 3.0 : (i == 1 ? -8.0 * x + 4.0 : 4.0 * x - 1.0); };
-    K0.assign(81 * 81, 0.0);
-    const double vol = h[0] * h[1] * h[2];
-    double g[27][3];
-    for (int qa = 0; qa < 3; ++qa)
-        for (int qb = 0; qb < 3; ++qb)
-            for (int qc = 0; qc < 3; ++qc) {
-                const double x[3] = {gp[qa], gp[qb], gp[qc]};
-                const double w = gw[qa] * gw[qb] * gw[qc] * vol;
-                for (int n = 0; n < 27; ++n) {
-                    const int l[3] = {n / 9, (n / 3) % 3, n % 3};
-                    for (int dd = 0; dd < 3; ++dd) {
-                        double v = 1.0;
-                        for (int e = 0; e < 3; ++e) v *= (e == dd) ? dN(l[e], x[e]) : N(l[e], x[e]);
-                        g[n][dd] = v / h[dd];
-                    }
-                }
-                for (int n = 0; n < 27; ++n)
-                    for (int m = 0; m < 27; ++m) {
-                        const double dot = g[n][0] * g[m][0] + g[n][1] * g[m][1] + g[n][2] * g[m][2];
-                        for (int a = 0; a < 3; ++a)
-                            for (int b = 0; b < 3; ++b)
-                                K0[(size_t) (3 * n + a) * 81 + 3 * m + b] += w * (lambda * g[n][a] * g[m][b] + mu * g[n][b] * g[m][a] + (a == b ? mu * dot : 0.0));
-                    }
-            }
-    dK0.alloc(81 * 81);
-    VFEM_HIP(hipMemcpy(dK0.p, K0.data(), K0.size() * sizeof(double), hipMemcpyHostToDevice));
-}
-extern "C" {
-int vfem_simq2_create(vfem_simq2 **out, const double bbmin[3], const double bbmax[3], const int64_t ne[3]) {
-    VFEM_TRY
-    for (int dd = 0; dd < 3; ++dd)
-        if (ne[dd] < 1 || ne[dd] > 2048) throw Error("elements per dimension must be in [1, 2048]");
-    std::unique_ptr<vfem_simq2> sim(new vfem_simq2);
-    sim->nx = (int) ne[0]; sim->ny = (int) ne[1]; sim->nz = (int) ne[2];
-    for (int dd = 0; dd < 3; ++dd) {
-        sim->h[dd] = (bbmax[dd] - bbmin[dd]) / (double) ne[dd];
-        if (!(sim->h[dd] > 0)) throw Error("empty domain bounding box");
-    }
-    sim->update_k0();
-    sim->rho.alloc((size_t) sim->ne()); sim->rho.zero(nullptr);
-    sim->E.alloc((size_t) sim->ne());
-    launch_simp(sim->ne(), sim->rho.p, sim->E0, sim->Emin, sim->gamma, sim->E.p, nullptr);
-    VFEM_HIP(hipDeviceSynchronize());
-    *out = sim.release();
-    VFEM_CATCH
-}
-int vfem_simq2_destroy(vfem_simq2 *sim) { VFEM_TRY delete sim; VFEM_CATCH }
-int64_t vfem_simq2_num_nodes(const vfem_simq2 *sim) { return sim->nn(); }
-int64_t vfem_simq2_num_elements(const vfem_simq2 *sim) { return sim->ne(); }
-int vfem_simq2_set_isotropic(vfem_simq2 *sim, double young, double poisson) {
-    VFEM_TRY
-    sim->lambda = poisson * young / ((1.0 + poisson) * (1.0 - 2.0 * poisson));
-    sim->mu = young / (2.0 + 2.0 * poisson);
-    sim->update_k0();
-    VFEM_CATCH
-}
-int vfem_simq2_set_simp(vfem_simq2 *sim, double E0, double Emin, double gamma) {
-    VFEM_TRY
-    sim->E0 = E0; sim->Emin = Emin; sim->gamma = gamma;
-    launch_simp(sim->ne(), sim->rho.p, E0, Emin, gamma, sim->E.p, nullptr);
-    VFEM_HIP(hipDeviceSynchronize());
-    VFEM_CATCH
-}
-int vfem_simq2_k0(const vfem_simq2 *sim, double *K0_host) {
-    VFEM_TRY std::memcpy(K0_host, sim->K0.data(), sim->K0.size() * sizeof(double)); VFEM_CATCH
-}
-int vfem_simq2_set_densities(vfem_simq2 *sim, const double *rho, void *stream) {
-    VFEM_TRY
-    VFEM_HIP(hipMemcpyAsync(sim->rho.p, rho, (size_t) sim->ne() * sizeof(double), hipMemcpyDeviceToDevice, S(stream)));
-    launch_simp(sim->ne(), sim->rho.p, sim->E0, sim->Emin, sim->gamma, sim->E.p, S(stream));
-    VFEM_CATCH
-}
-int vfem_simq2_get_densities(const vfem_simq2 *sim, double *rho, void *stream) {
-    VFEM_TRY
-    VFEM_HIP(hipMemcpyAsync(rho, sim->rho.p, (size_t) sim->ne() * sizeof(double), hipMemcpyDeviceToDevice, S(stream)));
-    VFEM_CATCH
-}
-int vfem_simq2_apply_k(const vfem_simq2 *sim, const double *u, double *out, void *stream) {
-    VFEM_TRY launch_apply_q2(sim->nx, sim->ny, sim->nz, sim->dK0.p, sim->E.p, u, out, S(stream)); VFEM_CATCH
-}
-int vfem_simq2_compliance_gradient(const vfem_simq2 *sim, const double *u, double *g, void *stream) {
-    VFEM_TRY
-    launch_gradient_q2(sim->nx, sim->ny, sim->nz, sim->dK0.p, sim->rho.p, sim->E0, sim->Emin, sim->gamma, u, g, S(stream));
-    VFEM_CATCH
-}
-
 // ---- design-update path ----
 int vfem_box_filter(const int64_t n[3], int radius, const double *in, double *out, int transpose, void *stream) {
     VFEM_TRY

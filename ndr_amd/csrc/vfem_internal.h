@@ -193,15 +193,3 @@ struct vfem_mlp {
     float bout = 0.f;
     bool loaded = false;
 };
-
-struct vfem_simq2 {                              // TensorProductSimulator<2,2,2>: grid, K0 (81x81), SIMP, applyK, sensitivity
-    int nx = 0, ny = 0, nz = 0;
-    double h[3];
-    double lambda = 0.0, mu = 0.5;
-    double E0 = 1.0, Emin = 1e-9, gamma = 3.0;
-    std::vector<double> K0;                      // 81 x 81 row-major
-    vfem::DevBuf<double> dK0, rho, E;
-    long long nn() const { return (long long) (2 * nx + 1) * (2 * ny + 1) * (2 * nz + 1); }
-    long long ne() const { return (long long) nx * ny * nz; }
-    void update_k0();
-};

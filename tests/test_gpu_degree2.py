@@ -56,10 +56,7 @@ def test_q2_operator_properties_at_size():
     assert float(t.applyK_device(ones).abs().max()) < 1e-10 * float(Ku.abs().max())
 
 
-def test_q2_multigrid_not_built_is_loud():
+def test_unknown_degrees_are_refused():
     from ndr_amd import pyVoxelFEM as pv
-    t = pv.TensorProductSimulator([2, 2, 2], ([0, 0, 0], [1, 1, 1]), (2, 2, 2))
-    with pytest.raises(RuntimeError):
-        t.multigridSolver(1)
     with pytest.raises(RuntimeError):
         pv.TensorProductSimulator([3, 3, 3], ([0, 0, 0], [1, 1, 1]), (2, 2, 2))

@@ -155,3 +155,32 @@ def test_q1_q2_compliance_converge_on_the_same_problem():
         u = mg.preconditionedConjugateGradient_device(torch.zeros_like(f), f, 300, 1e-9, None, 1, 2, True)
         vals[p] = float((f * u).sum())
     assert vals[1] > 0 and abs(vals[2] - vals[1]) < 0.1 * vals[1]
+
+
+def test_config0_2d_mbb_160x80_driver_loop_matches_oracle():
+    """BASELINE configs[0]: 2-D MBB beam 160x80, SIMP p=3, OC update through the train_voxelfem.py call sequence
+    (fem.ground_truth_topopt with use_multigrid=False), HIP path vs the CPU oracle's OC loop, 5 design iterations"""
+    from ndr_amd import fem
+    from oracle import vfem_oracle as vo
+    ne, dom, v0, iters = [160, 80], [[0, 0], [2, 1]], 0.5, 5
+    dens, final, binary, hist = fem.ground_truth_topopt(MATERIAL, BC2D, [1, 1], dom, ne, 3, v0, "OC", 0, use_multigrid=False,
+                                                        max_iter=iters, obj_history=True, verbose=False)
+    sim = vo.OracleSim(dom, ne)
+    sim.read_material(MATERIAL)
+    sim.set_uniform_densities(v0)
+    sim.apply_bc_file(BC2D)
+    sim.E0, sim.Emin, sim.gamma = 1.0, 1e-4, 3.0
+    top = vo.OracleProblem(sim, vo.OracleComplianceObjective(sim), [vo.OracleVolumeConstraint(v0)],
+                           [vo.OracleSmoothingFilter(), vo.OracleProjectionFilter()])
+    oc = vo.OracleOC(top)
+    top.set_vars(sim.rho.copy())
+    ref = []
+    for _ in range(iters):
+        ref.append(2.0 * top.evaluate_objective())
+        oc.step()
+    assert len(hist) == iters and hist[0] > hist[-1]
+    for a, b in zip(hist, ref):
+        assert abs(a - b) < 1e-5 * abs(b), (hist, ref)
+    top.set_vars(sim.rho.copy())                 # fem.py:99-103 feeds the physical densities back as variables
+    assert abs(final - 2.0 * top.evaluate_objective()) < 1e-5 * final
+    assert dens.shape == (ne[0] * ne[1],)
