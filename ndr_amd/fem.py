@@ -105,3 +105,29 @@ class VoxelFEMFunction(autograd.Function):
     def backward(ctx, grad_output):
         (grad,) = ctx.saved_tensors
         return grad * grad_output, None
+
+
+def save_for_interactive_vis(density, grid_dimensions, title, visualize, path):
+    """utils.save_for_interactive_vis (utils.py:350-376): cell-data ``.vtr`` of the density field for ParaView"""
+    if not visualize:
+        return None
+    from . import io
+    if isinstance(density, torch.Tensor):
+        density = density.detach().cpu().numpy()
+    elif hasattr(density, "getDensities"):
+        density = density.getDensities()
+    elif not isinstance(density, np.ndarray):
+        raise TypeError('Datatype "{}" not understood.\n'.format(type(density)))
+    density = density.reshape(grid_dimensions)
+    fname = io.grid_to_vtr(path + title, np.arange(density.shape[0] + 1), np.arange(density.shape[1] + 1),
+                           np.arange(density.shape[2] + 1), cellData={"data": density.copy()})
+    sys.stderr.write("{}.vtr has been saved to {}.\n".format(title, path))
+    return fname
+
+
+def save_densities_mesh(tps, path):
+    """utils.save_densities, 3-D branch (utils.py:313-316): Gmsh field file of the simulator's densities"""
+    from . import io
+    mfw = io.MSHFieldWriter(path, *tps.getMesh())
+    mfw.addField("density", tps.getDensities())
+    return path

@@ -1030,6 +1030,19 @@ class _GenericSimulator:
     def elemNodeGlobalIndex(self, ei, n):
         return int(self.elementNodes(ei)[int(n)])
 
+    def getMesh(self):
+        """(V, F): all node positions; per element its corner nodes in Gmsh quad / hexahedron order (TPS.hh:531-565)"""
+        N, p = self.N, self.P
+        idx = np.stack(np.meshgrid(*[np.arange(n) for n in self._nn], indexing="ij"), -1).reshape(-1, N)
+        V = self._bbmin + idx * (self._bbmax - self._bbmin) / (self._nn - 1.0)
+        eidx = np.stack(np.meshgrid(*[np.arange(n) for n in self._ne], indexing="ij"), -1).reshape(-1, N)
+        nstr = np.array([int(np.prod(self._nn[d + 1:])) for d in range(N)])
+        first = (p * eidx) @ nstr
+        corners = [(0, 0), (1, 0), (1, 1), (0, 1)] if N == 2 else \
+            [(0, 0, 0), (0, 0, 1), (0, 1, 1), (0, 1, 0), (1, 0, 0), (1, 0, 1), (1, 1, 1), (1, 1, 0)]
+        F = np.stack([first + (p * np.array(c)) @ nstr for c in corners], axis=1)
+        return V, F
+
     # ---- material / SIMP ----
     def readMaterial(self, materialPath):
         young, poisson = _read_isotropic_material(materialPath)
