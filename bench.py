@@ -113,9 +113,21 @@ def mlp_rate(side=(512, 256, 256), es=1024, nn_=512, nl=4, sigma=4.0, reps=3):
     dt = (time.perf_counter() - t0) / reps
     nv = int(np.prod(side))
     flop = 2.0 * (3 * es + 2 * es * nn_ + (nl - 2) * nn_ * nn_ + nn_) * nv
-    return {"grid": "%dx%dx%d" % tuple(side), "network": "%d->%d x%d->1" % (2 * es, nn_, nl - 1), "operands": "f16, f32 accumulate",
-            "seconds": dt, "voxels_per_s": nv / dt, "tflops": flop / dt / 1e12,
-            "mfma_frac_of_2.5PF": flop / dt / 2.5e15}
+    res = {"grid": "%dx%dx%d" % tuple(side), "network": "%d->%d x%d->1" % (2 * es, nn_, nl - 1), "operands": "f16, f32 accumulate",
+           "seconds": dt, "voxels_per_s": nv / dt, "tflops": flop / dt / 1e12,
+           "mfma_frac_of_2.5PF": flop / dt / 2.5e15}
+    # parameter gradients of the whole grid (recomputed forward with saved activations + data path + weight-gradient GEMMs)
+    g = torch.randn(nv, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    m.backward_grid(side, g)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m.backward_grid(side, g)
+    torch.cuda.synchronize()
+    db = time.perf_counter() - t0
+    macs = (3 * es + 2 * es * nn_ + (nl - 2) * nn_ * nn_ + nn_) + (nl - 2) * nn_ * nn_ + (2 * es * nn_ + (nl - 2) * nn_ * nn_ + nn_)
+    res["backward"] = {"seconds": db, "voxels_per_s": nv / db, "tflops": 2.0 * macs * nv / db / 1e12,
+                       "note": "forward recompute + dX + dW GEMMs (rocBLAS f16->f32 for dW)"}
+    return res
 
 
 def main():

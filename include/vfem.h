@@ -208,20 +208,32 @@ int vfem_mean(int64_t n, const double *x, double *mean_host, void *stream);
 
 /* ---- Fourier-feature MLP density field: networks.MLP (networks.py:128-185), out_features = 1 ----
  * n_layers counts Linear layers as the reference does: Linear(2 es, nn), (n_layers - 2) x Linear(nn, nn), Linear(nn, 1).
- * Weights are handed over as fp32 HOST arrays in torch layout ([out][in] row-major) and converted once:
+ * Weights are handed over as fp32 arrays (host or device memory) in torch layout ([out][in] row-major) and converted to fp16:
  *   B [es][3] (MLP.B, already multiplied by `scale`), W_first [nn][2 es], W_hidden [(n_layers-2)][nn][nn],
  *   biases [(n_layers-1)][nn] (first layer, then hidden layers), w_out [nn], b_out.
  * Requirements of the MFMA tiling: es % 32 == 0, nn % 32 == 0, nn <= 512. */
 int vfem_mlp_create(vfem_mlp **out, int embedding_size, int n_neurons, int n_layers, int sigmoid_output);
 int vfem_mlp_destroy(vfem_mlp *mlp);
-int vfem_mlp_load_weights(vfem_mlp *mlp, const float *B_host, const float *W_first_host, const float *W_hidden_host,
-                          const float *biases_host, const float *w_out_host, float b_out);
+int vfem_mlp_load_weights(vfem_mlp *mlp, const float *B, const float *W_first, const float *W_hidden, const float *biases,
+                          const float *w_out, float b_out);
 /* forward on an explicit coordinate list [nvox][3] fp32 (device); either output pointer may be NULL */
 int vfem_mlp_forward(vfem_mlp *mlp, const float *coords, int64_t nvox, float *out_f32, double *out_f64, void *stream);
 /* forward on the regular grid of utils.get_mgrid (utils.py:35-53): n[d] points linspace(lo[d], hi[d]) incl. both ends,
  * flattened z-fastest = the solver's element order (train_xdg.py:245-247, 287) */
 int vfem_mlp_forward_grid(vfem_mlp *mlp, const int64_t n_host[3], const double lo_host[3], const double hi_host[3],
                           float *out_f32, double *out_f64, void *stream);
+/* Training (what torch.autograd does for networks.MLP in train_xdg.py:282-329): gradients of a scalar loss wrt the
+ * parameters given g_out[v] = dL/d(out[v]) (device, fp32).  Outputs are overwritten, fp32, same layouts as vfem_mlp_load_weights:
+ * dW1 [nn][2 es], dWh [n_layers-2][nn][nn], dbias [n_layers-1][nn], dwout [nn], dbout [1].  fp16 operands / fp32 accumulation;
+ * `loss_scale` multiplies g_out before it enters fp16 and is divided out of the results (power of two recommended). */
+int vfem_mlp_backward(vfem_mlp *mlp, const float *coords, int64_t nvox, const float *g_out, float loss_scale, float *dW1,
+                      float *dWh, float *dbias, float *dwout, float *dbout, void *stream);
+int vfem_mlp_backward_grid(vfem_mlp *mlp, const int64_t n_host[3], const double lo_host[3], const double hi_host[3],
+                           const float *g_out, float loss_scale, float *dW1, float *dWh, float *dbias, float *dwout, float *dbout,
+                           void *stream);
+/* torch.optim.Adam update (amsgrad off, weight_decay 0) of one fp32 parameter tensor, in place; step counts from 1 */
+int vfem_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float lr, float beta1,
+                   float beta2, float eps, int step, void *stream);
 
 /* ---- timers: BENCHMARK_* registry (MeshFEM GlobalBenchmark.hh / Timer.hh; VoxelFEM.cc:245-255) ---- */
 int vfem_timers_reset(void);

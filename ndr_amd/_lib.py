@@ -6,7 +6,7 @@ symbol/export checks run on a CPU-only box).
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvfem.so")
@@ -70,6 +70,10 @@ SIGNATURES = {
     "vfem_mg_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vfem_mg_pcg": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_int, c_int,
                             RESIDUAL_CB, c_void_p, POINTER(c_int), POINTER(c_double), c_void_p]),
+    "vfem_mlp_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vfem_mlp_backward_grid": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double), c_void_p, c_float,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vfem_adam_step": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int, c_void_p]),
     "vfem_gsim_create": (c_int, [POINTER(c_void_p), c_int, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
     "vfem_gsim_destroy": (c_int, [c_void_p]),
     "vfem_gsim_num_nodes": (c_int64, [c_void_p]),

@@ -820,26 +820,39 @@ int vfem_mlp_create(vfem_mlp **out, int es, int nn, int n_layers, int sigmoid) {
     *out = m.release();
     VFEM_CATCH
 }
-int vfem_mlp_destroy(vfem_mlp *mlp) { VFEM_TRY delete mlp; VFEM_CATCH }
+int vfem_mlp_destroy(vfem_mlp *mlp) {
+    VFEM_TRY
+    if (mlp && mlp->rocblas) rocblas_destroy_handle((rocblas_handle) mlp->rocblas);
+    delete mlp;
+    VFEM_CATCH
+}
 int vfem_mlp_load_weights(vfem_mlp *m, const float *B, const float *W1, const float *Wh, const float *biases,
                           const float *wout, float bout) {
     VFEM_TRY
     const int nh = m->n_layers - 2;
     auto up = [](DevBuf<float> &d, const float *h, size_t n) {
         d.alloc(n);
-        if (n) VFEM_HIP(hipMemcpy(d.p, h, n * sizeof(float), hipMemcpyHostToDevice));
+        if (n) VFEM_HIP(hipMemcpy(d.p, h, n * sizeof(float), hipMemcpyDefault));
     };
     auto up16 = [](DevBuf<uint16_t> &d, const float *h, size_t n) {
         d.alloc(n);
         if (!n) return;
         DevBuf<float> tmp; tmp.alloc(n);
-        VFEM_HIP(hipMemcpy(tmp.p, h, n * sizeof(float), hipMemcpyHostToDevice));
+        VFEM_HIP(hipMemcpy(tmp.p, h, n * sizeof(float), hipMemcpyDefault));
         launch_f32_to_f16((long long) n, tmp.p, d.p, nullptr);
         VFEM_HIP(hipDeviceSynchronize());
     };
     up(m->B, B, (size_t) m->es * 3);
     up16(m->W1, W1, (size_t) m->nn * 2 * m->es);
     up16(m->Wh, Wh, (size_t) nh * m->nn * m->nn);
+    m->WhT.alloc((size_t) nh * m->nn * m->nn);
+    if (nh) {
+        DevBuf<float> tmp; tmp.alloc((size_t) nh * m->nn * m->nn);
+        VFEM_HIP(hipMemcpy(tmp.p, Wh, tmp.n * sizeof(float), hipMemcpyDefault));
+        for (int l = 0; l < nh; ++l)
+            launch_transpose_f32_to_f16(m->nn, m->nn, tmp.p + (size_t) l * m->nn * m->nn, m->WhT.p + (size_t) l * m->nn * m->nn, nullptr);
+        VFEM_HIP(hipDeviceSynchronize());
+    }
     up(m->bias, biases, (size_t) (nh + 1) * m->nn);
     up(m->wout, wout, (size_t) m->nn);
     m->bout = bout;
@@ -878,6 +891,113 @@ int vfem_mlp_forward_grid(vfem_mlp *m, const int64_t n[3], const double lo[3], c
     }
     a.out32 = o32; a.out64 = o64;
     launch_mlp_forward(a, S(stream));
+    VFEM_CATCH
+}
+
+}  // extern "C"
+// Gradients of a scalar loss wrt the MLP parameters given dL/d(out) per voxel (what torch.autograd computes for
+// networks.MLP in the reference, train_xdg.py:282-329).  Voxels are processed in chunks: forward pass with saved fp16
+// activations, fused backward data pass (k_mlp_backward), then the weight gradients as split-V batched GEMMs
+// (rocBLAS, fp16 operands, fp32 accumulation/outputs) and column sums for the biases.
+static void mlp_backward_impl(vfem_mlp *m, vfem::MlpArgs base, const float *coords, const float *g_out, float scale,
+                              float *dW1, float *dWh, float *dbias, float *dwout, float *dbout, hipStream_t s) {
+    if (!m->loaded) throw Error("vfem_mlp_load_weights has not been called");
+    if (!(scale > 0.f)) throw Error("loss scale must be positive");
+    const long long V = base.nvox;
+    const int nn = m->nn, K1 = 2 * m->es, nh = m->n_layers - 2, nact = nh + 1;
+    if (V <= 0) throw Error("empty voxel set");
+    const long long Vc = std::min<long long>((V + 127) / 128 * 128, 1LL << 20);
+    auto plan = [](long long n_c, int &nb, long long &Vb) {
+        nb = (int) std::min<long long>(32, (n_c + 127) / 128);
+        Vb = ((n_c + nb - 1) / nb + 127) / 128 * 128;
+    };
+    int nb; long long Vb;
+    plan(std::min(Vc, V), nb, Vb);
+    const long long rows_max = (long long) nb * Vb;
+    m->acts.alloc((size_t) nact * rows_max * nn);
+    m->dz.alloc((size_t) nact * rows_max * nn);
+    m->feats.alloc((size_t) rows_max * K1);
+    m->gs.alloc((size_t) rows_max);
+    m->out_chunk.alloc((size_t) rows_max);
+    const size_t colblocks = (size_t) ((rows_max + 511) / 512);
+    m->partial.alloc(std::max((size_t) 32 * nn * K1, colblocks * (size_t) nn));
+    if (!m->rocblas) {
+        rocblas_handle hnd;
+        if (rocblas_create_handle(&hnd) != rocblas_status_success) throw Error("rocblas_create_handle failed");
+        m->rocblas = hnd;
+    }
+    rocblas_handle hnd = (rocblas_handle) m->rocblas;
+    rocblas_set_stream(hnd, s);
+    rocblas_set_pointer_mode(hnd, rocblas_pointer_mode_host);
+    const float inv = 1.f / scale, one = 1.f, zero = 0.f;
+    // C[n][k] (row-major, ld = kdim) = sum_v X[v][n] Y[v][k] over nbatch sub-ranges of Vb rows -> partial[b][n][k]
+    auto wgrad = [&](const uint16_t *Y, int kdim, const uint16_t *X, int nb_, long long Vb_, float beta, float *out) {
+        rocblas_status st = rocblas_gemm_strided_batched_ex(
+            hnd, rocblas_operation_none, rocblas_operation_transpose, kdim, nn, (rocblas_int) Vb_, &one,
+            Y, rocblas_datatype_f16_r, kdim, (rocblas_stride) Vb_ * kdim, X, rocblas_datatype_f16_r, nn, (rocblas_stride) Vb_ * nn, &zero,
+            m->partial.p, rocblas_datatype_f32_r, kdim, (rocblas_stride) nn * kdim,
+            m->partial.p, rocblas_datatype_f32_r, kdim, (rocblas_stride) nn * kdim, nb_, rocblas_datatype_f32_r,
+            rocblas_gemm_algo_standard, 0, 0);
+        if (st != rocblas_status_success) throw Error("rocblas_gemm_strided_batched_ex failed (status " + std::to_string((int) st) + ")");
+        launch_reduce_partials(nb_, (long long) nn * kdim, m->partial.p, inv, beta, out, s);
+    };
+    for (long long c0 = 0; c0 < V; c0 += Vc) {
+        const long long n_c = std::min(Vc, V - c0);
+        plan(n_c, nb, Vb);
+        const long long rows = (long long) nb * Vb;
+        const float beta = c0 == 0 ? 0.f : 1.f;
+        if (rows != n_c) { m->acts.zero(s); m->feats.zero(s); }       // padded rows must be finite (they meet dz = 0)
+        vfem::MlpArgs a = base;
+        a.nvox = n_c; a.v_offset = c0; a.coords = coords ? coords + 3 * c0 : nullptr;
+        a.out32 = m->out_chunk.p; a.out64 = nullptr; a.save_act = m->acts.p; a.act_rows = rows;
+        launch_mlp_forward(a, s);
+        vfem::MlpBwdArgs b{};
+        b.nn = nn; b.n_hidden = nh; b.sigmoid = m->sigmoid; b.WhT = m->WhT.p; b.wout = m->wout.p; b.g = g_out + c0;
+        b.out32 = m->out_chunk.p; b.scale = scale; b.act = m->acts.p; b.dz = m->dz.p; b.gs = m->gs.p; b.act_rows = rows; b.nvox = n_c;
+        launch_mlp_backward(b, rows, s);
+        a.save_act = nullptr;
+        launch_mlp_features(a, rows, m->feats.p, s);
+        wgrad(m->feats.p, K1, m->dz.p, nb, Vb, beta, dW1);
+        for (int l = 0; l < nh; ++l)
+            wgrad(m->acts.p + (size_t) l * rows * nn, nn, m->dz.p + (size_t) (l + 1) * rows * nn, nb, Vb, beta, dWh + (size_t) l * nn * nn);
+        const int cb = (int) ((rows + 511) / 512);
+        for (int j = 0; j < nact; ++j) {
+            launch_colsum_f16(rows, nn, m->dz.p + (size_t) j * rows * nn, nullptr, m->partial.p, s);
+            launch_reduce_partials(cb, nn, m->partial.p, inv, beta, dbias + (size_t) j * nn, s);
+        }
+        launch_colsum_f16(rows, nn, m->acts.p + (size_t) nh * rows * nn, m->gs.p, m->partial.p, s);
+        launch_reduce_partials(cb, nn, m->partial.p, inv, beta, dwout, s);
+        launch_sum_f32(rows, m->gs.p, inv, beta, dbout, s);
+    }
+}
+extern "C" {
+int vfem_mlp_backward(vfem_mlp *m, const float *coords, int64_t nvox, const float *g_out, float loss_scale, float *dW1,
+                      float *dWh, float *dbias, float *dwout, float *dbout, void *stream) {
+    VFEM_TRY
+    MlpArgs a = mlp_base_args(m);
+    a.nvox = nvox;
+    mlp_backward_impl(m, a, coords, g_out, loss_scale, dW1, dWh, dbias, dwout, dbout, S(stream));
+    VFEM_CATCH
+}
+int vfem_mlp_backward_grid(vfem_mlp *m, const int64_t n[3], const double lo[3], const double hi[3], const float *g_out,
+                           float loss_scale, float *dW1, float *dWh, float *dbias, float *dwout, float *dbout, void *stream) {
+    VFEM_TRY
+    MlpArgs a = mlp_base_args(m);
+    a.nvox = 1;
+    for (int dd = 0; dd < 3; ++dd) {
+        a.gn[dd] = (int) n[dd];
+        a.glo[dd] = (float) lo[dd];
+        a.gstep[dd] = n[dd] > 1 ? (float) ((hi[dd] - lo[dd]) / (double) (n[dd] - 1)) : 0.f;
+        a.nvox *= n[dd];
+    }
+    mlp_backward_impl(m, a, nullptr, g_out, loss_scale, dW1, dWh, dbias, dwout, dbout, S(stream));
+    VFEM_CATCH
+}
+int vfem_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float lr, float beta1,
+                   float beta2, float eps, int step, void *stream) {
+    VFEM_TRY
+    if (step < 1) throw Error("Adam step count starts at 1");
+    launch_adam(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, S(stream));
     VFEM_CATCH
 }
 

@@ -17,6 +17,25 @@ struct MlpArgs {
     long long nvox;
     float *out32;
     double *out64;
+    // training: first voxel of this chunk (grid mode: coordinates are generated for v_offset + local index) and the
+    // post-ReLU activations of every hidden layer, fp16 [1 + n_hidden][act_rows][nn], for the backward pass
+    long long v_offset;
+    void *save_act;
+    long long act_rows;
+};
+
+// backward pass of one voxel chunk (networks.MLP under torch.autograd in the reference, train_xdg.py:282-329)
+struct MlpBwdArgs {
+    int nn, n_hidden, sigmoid;
+    const void *WhT;                        // [n_hidden][nn (k)][nn (n)] fp16: transposed hidden weights
+    const float *wout;                      // [nn]
+    const float *g;                         // [nvox] dL/d(out)
+    const float *out32;                     // [nvox] forward outputs (sigmoid derivative)
+    float scale;                            // loss scale applied to g before it enters fp16
+    const void *act;                        // [1 + n_hidden][act_rows][nn] fp16
+    void *dz;                               // [1 + n_hidden][act_rows][nn] fp16: scaled gradients wrt the pre-activations
+    float *gs;                              // [act_rows] scaled dL/d(pre-sigmoid out), zero beyond nvox
+    long long act_rows, nvox;
 };
 
 }  // namespace vfem

@@ -128,6 +128,14 @@ void launch_gradient_q2(int nx, int ny, int nz, const double *K0, const double *
 struct MlpArgs;
 void launch_mlp_forward(const MlpArgs &a, hipStream_t s);
 void launch_f32_to_f16(long long n, const float *in, void *out, hipStream_t s);
+struct MlpBwdArgs;
+void launch_mlp_backward(const MlpBwdArgs &a, long long rows, hipStream_t s);
+void launch_mlp_features(const MlpArgs &a, long long rows, void *out, hipStream_t s);
+void launch_colsum_f16(long long rows, int ncols, const void *X, const float *w, float *partial, hipStream_t s);
+void launch_reduce_partials(int nb, long long n, const float *partial, float alpha, float beta, float *out, hipStream_t s);
+void launch_sum_f32(long long n, const float *x, float alpha, float beta, float *out, hipStream_t s);
+void launch_transpose_f32_to_f16(int rows, int cols, const float *in, void *out, hipStream_t s);
+void launch_adam(long long n, float *p, const float *g, float *m, float *v, float lr, float b1, float b2, float eps, int step, hipStream_t s);
 
 }  // namespace vfem
 
@@ -192,4 +200,8 @@ struct vfem_mlp {
     vfem::DevBuf<uint16_t> W1, Wh;               // fp16 bit patterns
     float bout = 0.f;
     bool loaded = false;
+    // training workspace (vfem_mlp_backward*): transposed hidden weights, per-chunk activations / gradients / features
+    vfem::DevBuf<uint16_t> WhT, acts, dz, feats;
+    vfem::DevBuf<float> gs, partial, out_chunk;
+    void *rocblas = nullptr;
 };

@@ -66,6 +66,64 @@ class MLP:
         self.load_arrays(model.B.detach().cpu().numpy(), [m.weight.detach().cpu().numpy() for m in lin],
                          [m.bias.detach().cpu().numpy() for m in lin])
 
+    def load_tensors(self, B, weights, biases):
+        """as ``load_arrays`` from float32 CUDA tensors, without a trip through host memory (training loop)"""
+        nl = self.n_layers
+        f = lambda t: t.detach().to(device=_dev(), dtype=torch.float32).contiguous()
+        Bt, W1 = f(B), f(weights[0])
+        Wh = torch.stack([f(w) for w in weights[1:-1]]).contiguous() if nl > 2 else torch.zeros(1, device=_dev())
+        bs = torch.stack([f(b) for b in biases[:-1]]).contiguous()
+        wout = f(weights[-1]).reshape(-1)
+        bout = float(biases[-1].detach().reshape(-1)[0].item())
+        if tuple(Bt.shape) != (self.embedding_size, 3) or tuple(W1.shape) != (self.n_neurons, 2 * self.embedding_size):
+            raise RuntimeError("weight shapes do not match the network configuration")
+        _lib.check(self._lib.vfem_mlp_load_weights(self._h, _ptr(Bt), _ptr(W1), _ptr(Wh), _ptr(bs), _ptr(wout), bout))
+
+    # ---- training (SURVEY 8f-2) ----
+    def _grad_buffers(self):
+        nn_, nl, es = self.n_neurons, self.n_layers, self.embedding_size
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=_dev())
+        return z(nn_, 2 * es), z(max(nl - 2, 1), nn_, nn_), z(nl - 1, nn_), z(nn_), z(1)
+
+    @staticmethod
+    def _auto_scale(g):
+        """power-of-two loss scale that brings max |g| to about 64 (fp16 operands in the backward GEMMs)"""
+        m = float(g.abs().max().item())
+        return 1.0 if not (m > 0) else float(2.0 ** int(np.round(np.log2(64.0 / m))))
+
+    def _unpack(self, bufs):
+        dW1, dWh, db, dwout, dbout = bufs
+        nl = self.n_layers
+        gw = [dW1] + [dWh[l] for l in range(nl - 2)] + [dwout.reshape(1, -1)]
+        gb = [db[j] for j in range(nl - 1)] + [dbout]
+        return gw, gb
+
+    def backward(self, coords, g_out, loss_scale=None):
+        """gradients of L wrt the Linear weights / biases (lists in layer order, torch layout) given
+        g_out = dL/d(out) for the coordinate list of the matching ``forward`` call"""
+        c = torch.as_tensor(coords, dtype=torch.float32, device=_dev()).contiguous()
+        g = torch.as_tensor(g_out, dtype=torch.float32, device=_dev()).contiguous().reshape(-1)
+        n = c.numel() // 3
+        if g.numel() != n:
+            raise RuntimeError("g_out must hold one value per coordinate")
+        bufs = self._grad_buffers()
+        sc = self._auto_scale(g) if loss_scale is None else float(loss_scale)
+        _lib.check(self._lib.vfem_mlp_backward(self._h, _ptr(c), n, _ptr(g), sc, *[_ptr(b) for b in bufs], _stream()))
+        return self._unpack(bufs)
+
+    def backward_grid(self, sidelen, g_out, domain=None, loss_scale=None):
+        n = (ctypes.c_int64 * 3)(*[int(s) for s in sidelen])
+        dom = domain if domain is not None else [[0.0, 1.0]] * 3
+        lo = (ctypes.c_double * 3)(*[float(d[0]) for d in dom])
+        hi = (ctypes.c_double * 3)(*[float(d[1]) for d in dom])
+        g = torch.as_tensor(g_out, dtype=torch.float32, device=_dev()).contiguous().reshape(-1)
+        if g.numel() != int(np.prod([int(s) for s in sidelen])):
+            raise RuntimeError("g_out must hold one value per voxel")
+        bufs = self._grad_buffers()
+        sc = self._auto_scale(g) if loss_scale is None else float(loss_scale)
+        _lib.check(self._lib.vfem_mlp_backward_grid(self._h, n, lo, hi, _ptr(g), sc, *[_ptr(b) for b in bufs], _stream()))
+        return self._unpack(bufs)
+
     def forward(self, coords):
         """coords [..., 3] float32 -> densities [..., 1] float32 (torch CUDA tensors)"""
         c = torch.as_tensor(coords, dtype=torch.float32, device=_dev()).contiguous()
@@ -88,3 +146,101 @@ class MLP:
         o64 = _ptr(out_f64) if out_f64 is not None else None
         _lib.check(self._lib.vfem_mlp_forward_grid(self._h, n, lo, hi, _ptr(out), o64, _stream()))
         return out.reshape(tuple(int(s) for s in sidelen))
+
+
+class _GridDensity(torch.autograd.Function):
+    """density field of the whole grid as an autograd node: forward = fused MFMA kernel, backward = vfem_mlp_backward_grid"""
+
+    @staticmethod
+    def forward(ctx, module, *params):
+        module._sync()
+        ctx.module = module
+        return module.kernel.forward_grid(module.sidelen, module.domain).reshape(-1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        mod = ctx.module
+        gw, gb = mod.kernel.backward_grid(mod.sidelen, grad_out, mod.domain)
+        grads = []
+        for w, b in zip(gw, gb):
+            grads += [w, b.reshape(-1)]
+        return (None,) + tuple(grads)
+
+
+class TrainableMLP(torch.nn.Module):
+    """``networks.MLP`` (networks.py:126-185) as a trainable torch module whose forward and backward passes run in the
+    libvfem kernels: same constructor keywords, same ``net`` Sequential of Linear/ReLU modules (so ``state_dict`` keys and
+    checkpoints interchange with the reference, utils.py:259-299), same orthogonal initialisation (networks.py:242-256),
+    ``B`` kept outside the parameters.  ``forward_grid()`` returns the flattened density field of the grid set with
+    ``set_grid`` (utils.get_mgrid rule); any torch optimiser works on ``parameters()``, ``adam_step`` is the fused one."""
+
+    def __init__(self, in_features=3, out_features=1, n_neurons=256, n_layers=4, embedding_size=256, scale=0,
+                 dropout_rate=-1, hidden_act=None, output_act=None):
+        super().__init__()
+        self.kernel = MLP(in_features, out_features, n_neurons, n_layers, embedding_size, scale, dropout_rate, hidden_act,
+                          output_act)
+        self.embedding_size, self.in_features, self.n_neurons, self.scale = embedding_size, in_features, n_neurons, scale
+        self.B = (torch.normal(0, 1, size=(embedding_size, in_features)) * scale).to(_dev())
+        layers = []
+        for i in range(n_layers):
+            if i == 0:
+                layers += [torch.nn.Linear(embedding_size * 2, n_neurons), torch.nn.ReLU()]
+            elif i == n_layers - 1:
+                layers += [torch.nn.Linear(n_neurons, out_features)] + ([torch.nn.Sigmoid()] if output_act is not None else [])
+            else:
+                layers += [torch.nn.Linear(n_neurons, n_neurons), torch.nn.ReLU()]
+        self.net = torch.nn.Sequential(*layers)
+        gain = 1.0 * np.sqrt(max(n_neurons / embedding_size, 1))
+        for m in self.net:
+            if isinstance(m, torch.nn.Linear):
+                torch.nn.init.orthogonal_(m.weight, gain=gain)
+                torch.nn.init.constant_(m.bias, 0.0)
+        self.to(_dev())
+        self.sidelen, self.domain = None, None
+        self._adam_state, self._adam_t = None, 0
+
+    def _linears(self):
+        return [m for m in self.net if isinstance(m, torch.nn.Linear)]
+
+    def _sync(self):
+        lin = self._linears()
+        self.kernel.load_tensors(self.B, [m.weight for m in lin], [m.bias for m in lin])
+
+    def set_grid(self, sidelen, domain=None):
+        self.sidelen, self.domain = tuple(int(s) for s in sidelen), domain
+
+    def forward_grid(self):
+        if self.sidelen is None:
+            raise RuntimeError("call set_grid first")
+        params = []
+        for m in self._linears():
+            params += [m.weight, m.bias]
+        return _GridDensity.apply(self, *params)
+
+    def forward(self, coords=None):
+        """with no argument: the grid set by ``set_grid``; with coordinates: inference on that list (no autograd)"""
+        if coords is None:
+            return self.forward_grid()
+        self._sync()
+        return self.kernel.forward(coords)
+
+    def homogeneous_init(self, v0):
+        """fem.homogeneous_init (fem.py:350-374): the last Linear gets weight ~ N(0, 1e-4) and bias v0, so the initial
+        field is uniform"""
+        last = self._linears()[-1]
+        with torch.no_grad():
+            last.weight.normal_(0.0, 1e-4)
+            last.bias.fill_(float(v0))
+
+    def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        """torch.optim.Adam update of every parameter from its ``.grad`` with the fused libvfem kernel"""
+        ps = [p for p in self.parameters() if p.grad is not None]
+        if self._adam_state is None:
+            self._adam_state = {id(p): (torch.zeros_like(p), torch.zeros_like(p)) for p in self.parameters()}
+        self._adam_t += 1
+        lib = _lib.load()
+        for p in ps:
+            m, v = self._adam_state[id(p)]
+            g = p.grad.contiguous()
+            _lib.check(lib.vfem_adam_step(p.numel(), _ptr(p.data), _ptr(g), _ptr(m), _ptr(v), float(lr), float(betas[0]),
+                                          float(betas[1]), float(eps), self._adam_t, _stream()))

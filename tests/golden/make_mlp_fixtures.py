@@ -32,11 +32,18 @@ def dump(tag, es, nn_, nl, sigma, sidelen, sigmoid, seed, weight_scale=None):
     coords = mgrid(sidelen)
     with torch.no_grad():
         out = model(coords)
-    arrays = {"B": model.B.numpy(), "coords": coords.numpy(), "out": out.numpy(),
+    # gradients of L = sum_v gout[v] * out[v] by the reference's own autograd path (train_xdg.py:282-329)
+    gen = torch.Generator().manual_seed(seed + 1000)
+    gout = torch.randn(out.shape, generator=gen) * torch.exp(2.0 * torch.randn(out.shape, generator=gen))
+    model.zero_grad()
+    (model(coords) * gout).sum().backward()
+    arrays = {"B": model.B.numpy(), "coords": coords.numpy(), "out": out.numpy(), "gout": gout.numpy(),
               "cfg": np.array([es, nn_, nl, int(sigmoid)]), "sigma": np.array([sigma])}
     for i, m in enumerate(lin):
         arrays["W%d" % i] = m.weight.detach().numpy()
         arrays["b%d" % i] = m.bias.detach().numpy()
+        arrays["gW%d" % i] = m.weight.grad.detach().numpy()
+        arrays["gb%d" % i] = m.bias.grad.detach().numpy()
     np.savez_compressed(os.path.join(HERE, "mlp_%s.npz" % tag), **arrays)
     print(tag, out.shape, float(out.min()), float(out.max()))
 

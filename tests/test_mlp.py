@@ -67,3 +67,118 @@ def test_hip_mlp_requires_weights_and_valid_shapes():
     m = MLP(3, 1, 64, 3, 32, 1.0)
     with pytest.raises(RuntimeError):
         m.forward(torch.zeros(4, 3))
+
+
+def _rel_l2(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / max(np.linalg.norm(np.asarray(b, np.float64)), 1e-300))
+
+
+# fp16 operands / fp32 accumulation in the backward GEMMs: relative L2 error of every gradient tensor against the
+# reference's fp32 autograd gradients; set from measurement
+TOL_GRAD = 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FIXTURES)
+def test_hip_mlp_gradients_match_reference_autograd(path):
+    """dL/dW, dL/db of L = sum_v gout[v] out[v] against the gradients torch.autograd computed on the reference's
+    networks.MLP (fixtures); explicit coordinate list and grid entry points"""
+    import torch
+    from ndr_amd.mlp import MLP
+    z, es, nn_, nl, sig, Ws, bs = _load(path)
+    m = MLP(3, 1, nn_, nl, es, float(z["sigma"][0]), output_act=torch.nn.Sigmoid() if sig else None)
+    m.load_arrays(z["B"], Ws, bs)
+    coords = torch.from_numpy(z["coords"]).cuda()
+    gout = torch.from_numpy(z["gout"]).cuda()
+    for gw, gb in (m.backward(coords, gout), m.backward_grid(z["coords"].shape[1:4], gout)):
+        for i in range(nl):
+            ew = _rel_l2(gw[i].cpu().numpy().reshape(z["gW%d" % i].shape), z["gW%d" % i])
+            eb = _rel_l2(gb[i].cpu().numpy().reshape(z["gb%d" % i].shape), z["gb%d" % i])
+            assert ew < TOL_GRAD and eb < TOL_GRAD, (i, ew, eb)
+
+
+@pytest.mark.gpu
+def test_hip_mlp_gradients_multi_chunk_and_linearity():
+    """a voxel set larger than one chunk (2^20 rows): gradients are linear in g_out and independent of the loss scale"""
+    import torch
+    from ndr_amd.mlp import MLP
+    rng = np.random.default_rng(5)
+    es, nn_, nl = 64, 128, 4
+    m = MLP(3, 1, nn_, nl, es, 3.0)
+    B = (rng.standard_normal((es, 3)) * 3.0).astype(np.float32)
+    Ws = [rng.standard_normal((nn_, 2 * es)).astype(np.float32) / np.sqrt(2 * es)] + \
+         [rng.standard_normal((nn_, nn_)).astype(np.float32) / np.sqrt(nn_) for _ in range(nl - 2)] + \
+         [rng.standard_normal((1, nn_)).astype(np.float32) / np.sqrt(nn_)]
+    bs = [rng.standard_normal(nn_).astype(np.float32) * 0.1 for _ in range(nl - 1)] + [np.array([0.1], np.float32)]
+    m.load_arrays(B, Ws, bs)
+    side = (130, 96, 100)                                      # 1 248 000 voxels: two chunks, ragged tail
+    g1 = torch.randn(int(np.prod(side)), device="cuda")
+    g2 = torch.randn(int(np.prod(side)), device="cuda")
+    a_w, a_b = m.backward_grid(side, g1, loss_scale=16.0)
+    b_w, b_b = m.backward_grid(side, g2, loss_scale=16.0)
+    c_w, c_b = m.backward_grid(side, g1 + 2.0 * g2, loss_scale=4.0)
+    for i in range(nl):
+        assert _rel_l2((a_w[i] + 2.0 * b_w[i]).cpu().numpy(), c_w[i].cpu().numpy()) < 5e-3, i
+        assert _rel_l2((a_b[i] + 2.0 * b_b[i]).cpu().numpy(), c_b[i].cpu().numpy()) < 5e-3, i
+    # the first chunk alone, through the explicit-coordinate entry point, against the grid's own coordinates
+    from oracle import vfem_oracle as vo
+    sub = (4, 96, 100)
+    coords = torch.from_numpy(vo.get_mgrid(side)[0, :4].reshape(-1, 3).astype(np.float32)).cuda()
+    gsub = g1[:coords.shape[0]].clone()
+    gfull = torch.zeros_like(g1)
+    gfull[:coords.shape[0]] = gsub
+    e_w, e_b = m.backward(coords, gsub)
+    f_w, f_b = m.backward_grid(side, gfull)
+    for i in range(nl):
+        assert _rel_l2(e_w[i].cpu().numpy(), f_w[i].cpu().numpy()) < 5e-3, i
+
+
+@pytest.mark.gpu
+def test_fused_adam_matches_torch_adam():
+    import ctypes
+    import torch
+    from ndr_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(0)
+    p0 = torch.randn(10007)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=3e-3, betas=(0.9, 0.99), eps=1e-8)
+    p = p0.clone().cuda()
+    mm, vv = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 6):
+        g = torch.randn(10007) * (1.0 + step)
+        ref.grad = g.clone()
+        opt.step()
+        gd = g.cuda()
+        _lib.check(lib.vfem_adam_step(p.numel(), ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(gd.data_ptr()),
+                                      ctypes.c_void_p(mm.data_ptr()), ctypes.c_void_p(vv.data_ptr()), 3e-3, 0.9, 0.99, 1e-8,
+                                      step, None))
+    torch.cuda.synchronize()
+    assert float((p.cpu() - ref.detach()).abs().max()) < 2e-6
+
+
+@pytest.mark.gpu
+def test_trainable_mlp_fits_a_target_field_and_keeps_reference_state_dict_layout():
+    """train_xdg-style loop on a toy objective: density = mlp(grid); loss(density).backward(); Adam.  The loss must drop,
+    state_dict keys must be those of the reference module (net.<i>.weight / bias), homogeneous_init gives a uniform field"""
+    import torch
+    from ndr_amd.mlp import TrainableMLP
+    torch.manual_seed(1)
+    net = TrainableMLP(3, 1, 64, 4, 64, 2.0, output_act=torch.nn.Sigmoid())
+    assert sorted(net.state_dict().keys()) == sorted(["net.%d.%s" % (i, k) for i in (0, 2, 4, 6) for k in ("weight", "bias")])
+    side = (24, 16, 16)
+    net.set_grid(side)
+    net.homogeneous_init(0.0)
+    rho0 = net.forward_grid()
+    assert float((rho0 - 0.5).abs().max()) < 5e-3                       # sigmoid(0) everywhere
+    x = torch.linspace(0, 1, side[0], device="cuda")[:, None, None].expand(side).reshape(-1)
+    target = (x > 0.5).float() * 0.8 + 0.1
+    losses = []
+    for it in range(60):
+        net.zero_grad()
+        rho = net.forward_grid()
+        loss = ((rho - target) ** 2).mean()
+        loss.backward()
+        net.adam_step(lr=3e-3)
+        losses.append(float(loss.item()))
+    assert losses[-1] < 0.25 * losses[0], (losses[0], losses[-1])
