@@ -95,9 +95,14 @@ class VoxelFEMFunction(autograd.Function):
     @staticmethod
     def forward(ctx, densities, top):
         dev = densities.device
-        top.setVars(densities.detach().to(torch.float64).cpu().numpy())
-        output_objective = 2.0 * top.evaluateObjective()
-        grad = torch.from_numpy(top.evaluateObjectiveGradient().astype(np.float32)).to(dev)
+        if densities.is_cuda:                                      # zero-copy: the solver consumes the device tensor
+            top.setVars(densities.detach().to(torch.float64).reshape(-1))
+            output_objective = 2.0 * top.evaluateObjective()
+            grad = top.evaluateObjectiveGradient_device().to(torch.float32).reshape(densities.shape)
+        else:
+            top.setVars(densities.detach().to(torch.float64).numpy())
+            output_objective = 2.0 * top.evaluateObjective()
+            grad = torch.from_numpy(top.evaluateObjectiveGradient().astype(np.float32)).reshape(densities.shape)
         ctx.save_for_backward(grad)
         return torch.tensor(output_objective, device=dev).float()
 
@@ -131,3 +136,122 @@ def save_densities_mesh(tps, path):
     mfw = io.MSHFieldWriter(path, *tps.getMesh())
     mfw.addField("density", tps.getDensities())
     return path
+
+
+# ------------------------------------------------------------------------------------------------------
+# volume-constraint satisfiers of the train_xdg closure (fem.py:137-307): hard modes shift the logits by the scalar b(x)
+# that solves mean(projection(x + b)) = V with the implicit-function derivative; soft modes return a penalty term.
+# torch tensor ops only (elementwise + reductions on the density field, device-resident).
+# ------------------------------------------------------------------------------------------------------
+class _ShiftToMean(autograd.Function):
+    """b(x) with mean(projection(x + b)) = average, found by bisection (at most 128 halvings, tolerance 1e-12 on the
+    bracket, fem.FindRootFunction); backward uses db/dx_i = -(df/dx_i) / (df/db)."""
+
+    @staticmethod
+    def forward(ctx, x, average, lower, upper, projection, dprojection):
+        lo, hi = float(lower), float(upper)
+        avg = float(average)
+        with torch.no_grad():
+            step = 0
+            while step < 128 and hi - lo >= 1e-12:
+                mid = 0.5 * (lo + hi)
+                if float(projection(x + mid).mean()) - avg > 0:
+                    hi = mid
+                else:
+                    lo = mid
+                step += 1
+            b = 0.5 * (lo + hi)
+            d = dprojection(x + b)
+        ctx.save_for_backward(d)
+        return x.new_tensor(b)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (d,) = ctx.saved_tensors
+        # f = mean(P(x + b)) - avg:  df/dx_i = P'(x_i + b) / n,  df/db = mean P'
+        return -(d / d.numel()) / d.mean() * grad_output, None, None, None, None, None
+
+
+def logit(p):
+    p = torch.clamp(torch.as_tensor(p, dtype=torch.float32), 0, 1)
+    return torch.log(p) - torch.log1p(-p)
+
+
+def _with_constrained_mean(x, average, projection, dprojection):
+    lg = logit(average).to(x.device)
+    b = _ShiftToMean.apply(x, average, lg - x.max(), lg - x.min(), projection, dprojection)
+    return projection(x + b)
+
+
+def sigmoid_with_constrained_mean(x, average, projection=torch.sigmoid):
+    """fem.sigmoid_with_constrained_mean (fem.py:213-229)"""
+    if projection is torch.sigmoid:
+        dproj = lambda t: torch.sigmoid(t) * (1 - torch.sigmoid(t))
+    else:
+        def dproj(t):
+            t = t.detach().requires_grad_(True)
+            with torch.enable_grad():
+                return autograd.grad(projection(t).sum(), t)[0]
+    return _with_constrained_mean(x, average, projection, dproj)
+
+
+def physical_density(x, maxVolume):
+    return sigmoid_with_constrained_mean(x, maxVolume)
+
+
+def compute_volume_loss_scaler(compliance_loss, volume_loss, mode='clip', constant=500.):
+    """fem.compute_volume_loss_scaler (fem.py:312-334)"""
+    with torch.no_grad():
+        scaler = compliance_loss / volume_loss
+        if mode == 'clip':
+            return torch.clamp_max(scaler, max=constant) if scaler >= constant else scaler
+        if mode == 'equalize':
+            return scaler
+    raise ValueError('The mode "{}" does not exist'.format(mode))
+
+
+def type_of_volume_constaint_satisfier(mode):
+    hard = {'constrained_sigmoid': True, 'constrained_projection': True, 'add_mean': False, 'one_sided_max': False,
+            'maxed_barrier': False, 'thresholded_barrier': False}
+    if mode not in hard:
+        raise ValueError('The mode "{}" does not exist'.format(mode))
+    return hard[mode]
+
+
+def satisfy_volume_constraint(density, max_volume, compliance_loss=None, mode='constrained_sigmoid', scaler_mode='clip',
+                              constant=500., **kwargs):
+    """fem.satisfy_volume_constraint (fem.py:257-309): hard modes return the constrained density, soft modes the weighted
+    volume penalty to add to the compliance"""
+    max_volume = torch.as_tensor(max_volume, dtype=density.dtype, device=density.device)
+    if mode == 'constrained_sigmoid':
+        return sigmoid_with_constrained_mean(density, max_volume, torch.sigmoid)
+    if mode == 'constrained_projection':
+        projection = kwargs.get('projection')
+        if projection is None:
+            raise ValueError("constrained_projection needs projection=<callable>")
+        return sigmoid_with_constrained_mean(density, max_volume, projection)
+    current = density.mean()
+    zero = torch.zeros_like(current)
+    eps = 1e-7
+    if mode == 'add_mean':
+        volume_loss = torch.abs(current - max_volume)
+    elif mode == 'one_sided_max':
+        volume_loss = torch.maximum(current - max_volume, zero) ** 2
+    elif mode == 'maxed_barrier':
+        volume_loss = torch.maximum(-torch.log(1 + max_volume + eps - current), zero)
+    elif mode == 'thresholded_barrier':
+        a = (1 + max_volume + eps - current).detach() if bool(current <= max_volume) else torch.ones_like(current)
+        volume_loss = torch.log(a / (1 + max_volume + eps - current)) ** 2
+    else:
+        raise ValueError('The mode "{}" does not exist'.format(mode))
+    return volume_loss * compute_volume_loss_scaler(compliance_loss, volume_loss, scaler_mode, constant)
+
+
+def homogeneous_init(model, constant):
+    """fem.homogeneous_init (fem.py:350-374) for modules with Linear layers: every Linear whose weight has a dimension of
+    size 1 or 2 (the output layer) gets weight ~ N(0, 1e-4) and bias = constant"""
+    for m in model.modules():
+        if isinstance(m, torch.nn.Linear) and (1 in m.weight.shape or 2 in m.weight.shape):
+            with torch.no_grad():
+                m.weight.normal_(0.0, 1e-4)
+                m.bias.fill_(float(constant))
