@@ -48,6 +48,7 @@ __device__ __forceinline__ void wait_plane(bool has_stores, bool steady) {
     }
 }
 
+template <int EXP>
 __global__ void __launch_bounds__(512, 2) k_apply_dma(Dims d, DmArgs2 dm, const double *__restrict__ E,
                                                       const double *__restrict__ u, double *__restrict__ out,
                                                       int planes_per_chunk, const char *u_last, const char *e_last,
@@ -211,6 +212,7 @@ __global__ void __launch_bounds__(512, 2) k_apply_dma(Dims d, DmArgs2 dm, const 
             const double p = acc[0][c] - acc[2][c], q = acc[1][c] - acc[3][c];
             const double r = acc[0][c] + acc[2][c], t = acc[1][c] + acc[3][c];
             wa[c] = p - q;
+            if (EXP == 1 || EXP >= 3) { wa[c] += (p + q) + (r - t) + (r + t); continue; }
             sB[(c * TY + ty) * TZ + tz] = p + q;
             sC[(c * TY + ty) * TZ + tz] = r - t;
             sD[(c * TY + ty) * TZ + tz] = r + t;
@@ -223,7 +225,8 @@ __global__ void __launch_bounds__(512, 2) k_apply_dma(Dims d, DmArgs2 dm, const 
         double w[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            w[c] = wa[c] + sB[(c * TY + ty) * TZ + tz - 1] + sC[(c * TY + ty - 1) * TZ + tz] + sD[(c * TY + ty - 1) * TZ + tz - 1];
+            w[c] = (EXP == 1 || EXP >= 3) ? wa[c]
+                                          : wa[c] + sB[(c * TY + ty) * TZ + tz - 1] + sC[(c * TY + ty - 1) * TZ + tz] + sD[(c * TY + ty - 1) * TZ + tz - 1];
         out[3 * n] = w[0]; out[3 * n + 1] = w[1]; out[3 * n + 2] = w[2];
     };
 
@@ -241,7 +244,21 @@ __global__ void __launch_bounds__(512, 2) k_apply_dma(Dims d, DmArgs2 dm, const 
     auto process = [&](double Ee, const double *su, const int q[4], int buf, double wa[3]) {
         if (!elem_ok) Ee = 0.0;
         double fnew[4][3];
-        face_modes_at(fnew, su, q[0], q[1], q[2], q[3]);
+        if (EXP == 4) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) fnew[qq][c] = Ee + qq + c;
+        } else face_modes_at(fnew, su, q[0], q[1], q[2], q[3]);
+        if (EXP >= 2) {
+            double acc2[4][3];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { acc2[qq][c] = Ee * (fnew[qq][c] + fold[qq][c]) + carry[qq][c]; carry[qq][c] = fnew[qq][c]; fold[qq][c] = fnew[qq][c]; }
+            scatter_face(acc2, wa, buf);
+            return;
+        }
         double m[8][3];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -369,12 +386,24 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
     dim3 blk(TZ, TY, 1), grd((np + ppc - 1) / ppc, (d.NZ + TZ - 2) / (TZ - 1), (d.NY + TY - 2) / (TY - 1));
     static bool attr = false;
     if (!attr) {
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
         attr = true;
     }
     // last admissible (aligned) piece: the one holding the last byte of each array
     auto last_piece = [](const char *end) { return reinterpret_cast<const char *>((reinterpret_cast<uintptr_t>(end) - 1) & ~(uintptr_t) 15); };
-    k_apply_dma<<<grd, blk, LDS_BYTES, s>>>(d, dm, E, u, out, ppc, last_piece(u_end), last_piece(e_end), plane_lo, plane_hi);
+    extern int g_apply_skeleton;
+#define VFEM_DMA_LAUNCH(X) k_apply_dma<X><<<grd, blk, LDS_BYTES, s>>>(d, dm, E, u, out, ppc, last_piece(u_end), last_piece(e_end), plane_lo, plane_hi)
+    switch (g_apply_skeleton) {
+        case 1: VFEM_DMA_LAUNCH(1); break;
+        case 2: VFEM_DMA_LAUNCH(2); break;
+        case 3: VFEM_DMA_LAUNCH(3); break;
+        case 4: VFEM_DMA_LAUNCH(4); break;
+        default: VFEM_DMA_LAUNCH(0);
+    }
     VFEM_HIP(hipGetLastError());
     return true;
 }

@@ -184,25 +184,16 @@ constexpr int GS_ROWBUF = 448;   // 129 nodes x 3 doubles = 387, padded to 7 x 6
 
 typedef double d8_t __attribute__((ext_vector_type(8)));
 
-// 8 consecutive doubles of a wave-uniform table into SGPRs, issued exactly here (the compiler would otherwise
-// hoist all 576 coefficient loads to the top of the kernel and spill them through v_writelane/v_readlane)
-__device__ __forceinline__ d8_t sload8(const double *p, int byte_off) {
-    d8_t r;
-    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(r) : "s"(p), "s"(byte_off));
-    return r;
-}
-__device__ __forceinline__ void swait3(d8_t &a, d8_t &b, d8_t &c) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c));
-}
-
+// Wave-uniform coefficient tables are read with explicit scalar loads issued exactly where they are consumed (the
+// compiler would otherwise hoist all 576 coefficient loads to the top of the kernel and spill them through
+// v_writelane/v_readlane).
 typedef double d4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ d4_t sload4(const double *p, int byte_off) {
-    d4_t r;
-    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(r) : "s"(p), "s"(byte_off));
-    return r;
-}
-__device__ __forceinline__ void swait2(d8_t &a, d4_t &b) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b));
+// 12 consecutive doubles, requested and awaited inside ONE asm statement: the compiler treats asm outputs as complete
+// when the statement ends, so a load left in flight between two statements could land in SGPRs it has already spilled
+// and reassigned (observed as a wild address once the allocator was under pressure)
+__device__ __forceinline__ void sload12(const double *p, int byte_off, d8_t &a, d4_t &b) {
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx8 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b) : "s"(p), "s"(byte_off), "s"(byte_off + 64));
 }
 
 // Host-side layout of the coefficient table consumed by k_gs_rows_mf0 (same loop nest as the kernel):
@@ -311,10 +302,11 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
                             const int sl = di * 4 + dj * 2 + dk;
 #pragma unroll
                             for (int mz = 0; mz < 2; ++mz) {
-                                d8_t k0 = sload8(tab, hg * 96);
-                                d4_t k1 = sload4(tab, hg * 96 + 64);
+                                d8_t k0;
+                                d4_t k1;
+                                sload12(tab, hg * 96, k0, k1);
                                 ++hg;
-                                swait2(k0, k1);
+
                                 const int n3 = dk + mz;            // dz + 1
 #pragma unroll
                                 for (int r = 0; r < 3; ++r)
@@ -336,9 +328,9 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
     for (int q = 0; q < 9; ++q) M[q] = 0.0;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
-        d8_t k0 = sload8(tab, (64 + g) * 96);
-        d4_t k1 = sload4(tab, (64 + g) * 96 + 64);
-        swait2(k0, k1);
+        d8_t k0;
+        d4_t k1;
+        sload12(tab, (64 + g) * 96, k0, k1);
         double kk[9];
 #pragma unroll
         for (int q = 0; q < 8; ++q) kk[q] = k0[q];
@@ -371,6 +363,7 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
 #pragma unroll
     for (int c = 0; c < 3; ++c) u[3 * n + c] += ud[c];
 }
+
 
 void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *gs_tab, const double *E, double *u,
                         const double *b, const uint8_t *mask, int forward, int xparity, int first, int count, hipStream_t s) {

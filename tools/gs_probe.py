@@ -1,0 +1,28 @@
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import BC_CANTILEVER, make_hip
+from ndr_amd import _lib
+lib = _lib.load()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+level = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+ne = (n, n, n)
+tps = make_hip(ne, ([0, 0, 0], [2, 1, 1]), BC_CANTILEVER, None, v0=0.5)
+g = torch.Generator(device="cuda").manual_seed(88)
+tps.setElementDensities(torch.rand(tps.numElements(), dtype=torch.float64, device="cuda", generator=g))
+mg = tps.multigridSolver(6 if n >= 512 else 5)
+mg.updateElementStiffnessMatrices()
+nn = mg._nn(level)
+u = torch.randn((nn, 3), dtype=torch.float64, device="cuda", generator=g)
+b = torch.randn((nn, 3), dtype=torch.float64, device="cuda", generator=g)
+from ndr_amd.pyVoxelFEM import _ptr, _stream
+for variant in (0, 1):
+    lib.vfem_debug_set(2, variant)
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        lib.vfem_mg_smooth(mg._h, level, _ptr(u), _ptr(b), 1, _stream())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print("level %d variant %d: %.3f ms per sweep" % (level, variant, dt * 1e3), flush=True)
+lib.vfem_debug_set(2, 0)
