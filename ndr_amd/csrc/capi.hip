@@ -190,13 +190,17 @@ static const double *level_E(const vfem_mg *mg, int l) {
 static void mg_apply(vfem_mg *mg, int l, const double *u, const double *b, int res, double *out, hipStream_t s) {
     MgLevel &L = mg->lv[l];
     if (L.kind == OP_STENCIL) launch_apply_stencil(L.d, L.S.p, u, b, L.maskp, res, out, s);
-    else if (L.kind == OP_MF0 && mg->fine->fast_ok)
-        launch_apply_fast(L.d, mg->fine->Dm, level_E(mg, 0), u, b, L.maskp, res, out, s);
+    else if (L.kind == OP_MF0 && mg->fine->fast_ok) {
+        const vfem_sim *sim = mg->fine;
+        if (res == 0 && g_apply_impl == 0 && launch_apply_dma(L.d, sim->Dm, level_E(mg, 0), sim->E.p + sim->n_store(), u, out, s)) return;
+        launch_apply_fast(L.d, sim->Dm, level_E(mg, 0), u, b, L.maskp, res, out, s);
+    }
     else launch_apply_gather(L.d, L.kind, level_K(mg, l), level_E(mg, l), u, b, L.maskp, res, out, s);
 }
 
 static void mg_smooth(vfem_mg *mg, int l, double *u, const double *b, int forward, hipStream_t s, int first = 0, int count = 8) {
     MgLevel &L = mg->lv[l];
+    g_mf1_sym = mg->mf1_sym ? 1 : 0;
     if (L.kind == OP_STENCIL) launch_gs_sweep_stencil(L.d, L.S.p, u, b, L.maskp, forward, L.xparity, first, count, s);
     else launch_gs_sweep_mf(L.d, L.kind, level_K(mg, l), l == 0 ? mg->fine->dGsTab.p : nullptr, level_E(mg, l), u, b, L.maskp,
                             forward, L.xparity, first, count, s);
@@ -512,6 +516,7 @@ static void finish_mg_create(vfem_mg *mg) {
     }
     mg->cK0.alloc(8 * 576);
     VFEM_HIP(hipMemcpy(mg->cK0.p, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice));
+    mg->mf1_sym = coarsened_matrices_are_mirror_images(c.data());
     for (int l = mg->first_active; l <= mg->L; ++l) {
         MgLevel &lv = mg->lv[(size_t) l];
         lv.x.alloc((size_t) lv.d.nn * 3); lv.b.alloc((size_t) lv.d.nn * 3); lv.r.alloc((size_t) lv.d.nn * 3);

@@ -12,11 +12,33 @@
 // node-centred gather (no atomics, deterministic summation order).
 #include "vfem_internal.h"
 
+#include <algorithm>
+#include <cmath>
+#include <type_traits>
+#include <utility>
+
 namespace vfem {
 
 __device__ __forceinline__ long long nidx(const Dims &d, int i, int j, int k) {
     return ((long long) i * d.NY + j) * d.NZ + k;
 }
+// compile-time loop: f(std::integral_constant<int, I>{}) for I = 0..N-1 (indices stay constant expressions however large the body)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// opaque copy of a wave-uniform pointer: loads through the result cannot be hoisted above this point; readfirstlane
+// restores the uniformity that an asm output loses (otherwise the loads become per-lane vector loads)
+template <class T>
+__device__ __forceinline__ const T *launder_uniform(const T *p) {
+    unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    asm volatile("" : "+s"(v));
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) (v & 0xffffffffull));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned) (v >> 32));
+    return reinterpret_cast<const T *>(((unsigned long long) hi << 32) | lo);
+}
+
 __device__ __forceinline__ long long eidx(const Dims &d, int i, int j, int k) {
     return ((long long) i * d.ny + j) * d.nz + k;
 }
@@ -365,6 +387,113 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
 }
 
 
+
+// ------------------------------------------------------------------------------------------
+// Level-1 colour sweep on the reflection symmetry of the coarsened reference matrices.
+//
+// cK0[f] = I_f^T K0 I_f (child f = 4fx+2fy+fz of a coarse element) is the mirror image of cK0[0]:
+//     cK0[f][(n,a),(m,b)] = s_a(f) s_b(f) cK0[0][(n^f, a),(m^f, b)],   s_a(f) = -1 if f has the bit of axis a
+// (box voxels, isotropic tensor; verified numerically at hierarchy creation).  The general kernel streams all eight
+// matrices (36.9 KB) through the 16 KB scalar cache and sits at ~35 % of the fp64 rate waiting on scalar-cache
+// misses.  Here only cK0[0] (4.6 KB, cache resident) is read: for a node with local index li in its element and child
+// f the rows are the rows rho = li ^ f of cK0[0]; the column permutation m -> m ^ f and the signs are resolved at
+// compile time (register renaming, per-component partial sums).  Register footprint as the general kernel.
+// ------------------------------------------------------------------------------------------
+// one row (24 doubles) of a wave-uniform table, requested and awaited inside one asm statement (see sload12)
+__device__ __forceinline__ void sload24(const double *p, int byte_off, d8_t &a, d8_t &b, d8_t &c) {
+    asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %5\n\ts_load_dwordx16 %2, %3, %6\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c) : "s"(p), "s"(byte_off), "s"(byte_off + 64), "s"(byte_off + 128));
+}
+
+__global__ void __launch_bounds__(256) k_gs_color_mf1_sym(Dims d, const double *__restrict__ K0c, const double *__restrict__ E,
+                                                          double *__restrict__ u, const double *__restrict__ b,
+                                                          const uint8_t *__restrict__ mask, int cx, int cy, int cz, int forward) {
+    const int k = 2 * (blockIdx.x * 64 + threadIdx.x) + cz;
+    const int j = 2 * (blockIdx.y * 4 + threadIdx.y) + cy;
+    const int i = 2 * blockIdx.z + cx;
+    if (k >= d.NZ || j >= d.NY || i >= d.NX) return;
+    const long long nyf = 2LL * d.ny, nzf = 2LL * d.nz;
+    const long long sx = (long long) d.NY * d.NZ, sy = d.NZ;
+    double S[3] = {0.0, 0.0, 0.0}, M[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) M[q] = 0.0;
+    static_for<8>([&](auto sc) {
+        constexpr int slot = decltype(sc)::value, li = 7 - slot;
+        constexpr int di = (slot >> 2) & 1, dj = (slot >> 1) & 1, dk = slot & 1;
+        const int ex = i - 1 + di, ey = j - 1 + dj, ez = k - 1 + dk;
+        const bool ok = ex >= 0 && ex < d.nx && ey >= 0 && ey < d.ny && ez >= 0 && ez < d.nz;
+        // out-of-grid elements (grid faces only) run with clamped indices and zero moduli: no divergent control flow
+        const int exc = min(max(ex, 0), d.nx - 1), eyc = min(max(ey, 0), d.ny - 1), ezc = min(max(ez, 0), d.nz - 1);
+        const long long base = nidx(d, exc, eyc, ezc);
+        double ue[24];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const long long nm = base + ((m >> 2) & 1) * sx + ((m >> 1) & 1) * sy + (m & 1);
+            ue[3 * m + 0] = u[3 * nm + 0];
+            ue[3 * m + 1] = u[3 * nm + 1];
+            ue[3 * m + 2] = u[3 * nm + 2];
+        }
+        double Ef[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const double v = E[((2LL * exc + ((f >> 2) & 1)) * nyf + (2LL * eyc + ((f >> 1) & 1))) * nzf + (2LL * ezc + (f & 1))];
+            Ef[f] = ok ? v : 0.0;
+        }
+        static_for<24>([&](auto gc) {
+            constexpr int f = decltype(gc)::value / 3, r = decltype(gc)::value % 3;
+            constexpr int rho = li ^ f;
+            d8_t c0, c1, c2;
+            sload24(K0c, (3 * rho + r) * 24 * 8, c0, c1, c2);
+            double coef[24];
+            static_for<24>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                coef[q] = q < 8 ? c0[q < 8 ? q : 0] : (q < 16 ? c1[(q >= 8 && q < 16) ? q - 8 : 0] : c2[q >= 16 ? q - 16 : 0]);
+            });
+            double acc[3] = {0.0, 0.0, 0.0};
+            static_for<24>([&](auto tc) {
+                constexpr int mq = decltype(tc)::value / 3, c = decltype(tc)::value % 3;
+                acc[c] = fma(coef[3 * mq + c], ue[3 * (mq ^ f) + c], acc[c]);
+            });
+            constexpr bool n0 = (f >> 2) & 1, n1 = (f >> 1) & 1, n2 = f & 1;      // sign flips of the x, y, z components
+            constexpr bool nr = (f >> (2 - r)) & 1;
+            // s_r * sum_c s_c acc_c
+            const double t = ((n0 != nr) ? -acc[0] : acc[0]) + ((n1 != nr) ? -acc[1] : acc[1]) + ((n2 != nr) ? -acc[2] : acc[2]);
+            S[r] = fma(Ef[f], t, S[r]);
+            // diagonal block: s_r s_c cK0[0][(rho,r),(rho,c)]
+            M[3 * r + 0] = fma((n0 != nr) ? -Ef[f] : Ef[f], coef[3 * rho + 0], M[3 * r + 0]);
+            M[3 * r + 1] = fma((n1 != nr) ? -Ef[f] : Ef[f], coef[3 * rho + 1], M[3 * r + 1]);
+            M[3 * r + 2] = fma((n2 != nr) ? -Ef[f] : Ef[f], coef[3 * rho + 2], M[3 * r + 2]);
+            // every consumer of this row's coefficients retires before the next row load (otherwise they stay live in SGPRs)
+            asm volatile("" : "+v"(S[r]), "+v"(M[3 * r + 0]), "+v"(M[3 * r + 1]), "+v"(M[3 * r + 2]));
+        });
+    });
+    const long long n = nidx(d, i, j, k);
+    double bms[3], ud[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bms[c] = b[3 * n + c] - S[c];
+    gs_solve(bms, M, mask[n], forward != 0, ud);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) u[3 * n + c] += ud[c];
+}
+
+// true when cK0[f] is the mirror image of cK0[0] to rounding (what k_gs_color_mf1_sym relies on)
+bool coarsened_matrices_are_mirror_images(const double *cK0 /* 8 x 576, host */) {
+    double scale = 0.0, err = 0.0;
+    for (int q = 0; q < 576; ++q) scale = std::max(scale, std::fabs(cK0[q]));
+    for (int f = 1; f < 8; ++f)
+        for (int n = 0; n < 8; ++n)
+            for (int a = 0; a < 3; ++a)
+                for (int m = 0; m < 8; ++m)
+                    for (int bb = 0; bb < 3; ++bb) {
+                        const double sg = (((f >> (2 - a)) & 1) ^ ((f >> (2 - bb)) & 1)) ? -1.0 : 1.0;
+                        const double want = sg * cK0[(3 * (n ^ f) + a) * 24 + 3 * (m ^ f) + bb];
+                        err = std::max(err, std::fabs(cK0[f * 576 + (3 * n + a) * 24 + 3 * m + bb] - want));
+                    }
+    return err <= 1e-13 * scale;
+}
+
+int g_mf1_sym = 0;     // set by the hierarchy when coarsened_matrices_are_mirror_images() holds
+
 void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *gs_tab, const double *E, double *u,
                         const double *b, const uint8_t *mask, int forward, int xparity, int first, int count, hipStream_t s) {
     for (int ci = first; ci < first + count; ++ci) {
@@ -375,6 +504,7 @@ void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const doubl
         dim3 blk(64, 4, 1), grd((cntz + 63) / 64, (cnty + 3) / 4, cntx);
         if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab) k_gs_rows_mf0<<<grd, blk, 0, s>>>(d, gs_tab, E, u, b, mask, cx, cy, cz, forward);
         else if (kind == OP_MF0) k_gs_color_mf<0><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
+        else if (g_mf1_sym && g_gs_variant == 0) k_gs_color_mf1_sym<<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
         else                k_gs_color_mf<1><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
     }
     VFEM_HIP(hipGetLastError());

@@ -85,6 +85,8 @@ extern int g_apply_impl;
 void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *gs_tab, const double *E, double *u,
                         const double *b, const uint8_t *mask, int forward, int xparity, int first, int count, hipStream_t s);
 void build_gs_table(const double *K0, double *tab /* 72*12 doubles */);
+bool coarsened_matrices_are_mirror_images(const double *cK0_host /* 8 x 576 */);
+extern int g_mf1_sym;
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
                              int forward, int xparity, int first, int count, hipStream_t s);
 
@@ -190,6 +192,7 @@ struct vfem_mg {
     int first_active = 0;                       // levels below are never cycled (replicated coarse hierarchy)
     bool symmetric_gs = true;                   // MG.hh:758
     bool operators_valid = false;
+    bool mf1_sym = false;                       // cK0[f] are mirror images of cK0[0]: level-1 sweeps read cK0[0] only
     void *rocblas = nullptr;                    // rocblas_handle for the coarsest factorisation
     vfem::DevBuf<int> info;
 };
