@@ -1,6 +1,6 @@
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 from helpers import make_hip
 from ndr_amd import _lib
 lib = _lib.load()

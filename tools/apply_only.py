@@ -1,6 +1,6 @@
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 from helpers import make_hip
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5

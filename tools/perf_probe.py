@@ -1,7 +1,7 @@
 """ad-hoc perf probe (not the bench contract): apply GVoxel/s and PCG timing on the GPU."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 from helpers import BC_CANTILEVER, make_hip, seeded_density
 
 def t_apply(n, variant, reps=10):
