@@ -130,6 +130,30 @@ def mlp_rate(side=(512, 256, 256), es=1024, nn_=512, nl=4, sigma=4.0, reps=3):
     return res
 
 
+def degree2_rate(ne=(512, 512, 512), reps=3):
+    """matrix-free SpMV of the 27-node (degree-2) elements, SURVEY 8(d) M1 (Q2): 393 B/voxel algorithmic"""
+    from ndr_amd import pyVoxelFEM as pv
+    t = pv.TensorProductSimulator([2, 2, 2], ([0, 0, 0], [1, 1, 1]), list(ne))
+    t.E_min = 1e-4
+    g = torch.Generator(device="cuda").manual_seed(88)
+    t.setElementDensities(torch.rand(t.numElements(), dtype=torch.float64, device="cuda", generator=g))
+    u = torch.randn((t.numNodes(), 3), dtype=torch.float64, device="cuda", generator=g)
+    t.applyK_device(u)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = t.applyK_device(u)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    nvox = ne[0] * ne[1] * ne[2]
+    ab = 2 * t.numNodes() * 24 + nvox * 8
+    del out
+    return {"grid": "%dx%dx%d" % tuple(ne), "nodes": t.numNodes(), "seconds": dt, "gvoxel_per_s": nvox / dt / 1e9,
+            "algorithmic_GBs": ab / dt / 1e9, "frac_of_8TBs": ab / dt / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_voxel": ab / nvox,
+            "note": "pencil kernel: reflection-mode blocks (855 of 6561 multiply-adds), 4 colour launches, 1104 B/voxel moved"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,6 +241,11 @@ def main():
             result["mlp_forward"] = mlp_rate()
         except RuntimeError as e:
             result["mlp_forward"] = {"error": str(e)}
+        torch.cuda.empty_cache()
+        try:
+            result["degree2_spmv"] = degree2_rate()
+        except RuntimeError as e:
+            result["degree2_spmv"] = {"error": str(e)}
     if not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline((160, 160, 160))
     print(json.dumps(result))

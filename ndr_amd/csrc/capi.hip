@@ -20,6 +20,9 @@
 namespace vfem {
 
 extern int g_apply_pd, g_apply_skeleton, g_gs_variant, g_apply_store;
+}
+extern int g_q2_impl;
+namespace vfem {
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
@@ -314,6 +317,7 @@ int vfem_debug_set(int key, int value) {
     else if (key == 2) vfem::g_gs_variant = value;
     else if (key == 3) vfem::g_apply_store = value;
     else if (key == 4) vfem::g_apply_impl = value;
+    else if (key == 6) g_q2_impl = value;
     else return 1;
     return 0;
 }

@@ -1,0 +1,50 @@
+// Device-side helpers shared by the kernel translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+namespace vfem {
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I = 0..N-1 (indices stay constant expressions however large the body)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// opaque copy of a wave-uniform pointer: loads through the result cannot be hoisted above this point; readfirstlane
+// restores the uniformity that an asm output loses (otherwise the loads become per-lane vector loads)
+template <class T>
+__device__ __forceinline__ const T *launder_uniform(const T *p) {
+    unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    asm volatile("" : "+s"(v));
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) (v & 0xffffffffull));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned) (v >> 32));
+    return reinterpret_cast<const T *>(((unsigned long long) hi << 32) | lo);
+}
+
+
+typedef double d8_t __attribute__((ext_vector_type(8)));
+
+// Wave-uniform coefficient tables are read with explicit scalar loads issued exactly where they are consumed (the
+// compiler would otherwise hoist all 576 coefficient loads to the top of the kernel and spill them through
+// v_writelane/v_readlane).
+typedef double d4_t __attribute__((ext_vector_type(4)));
+// 12 consecutive doubles, requested and awaited inside ONE asm statement: the compiler treats asm outputs as complete
+// when the statement ends, so a load left in flight between two statements could land in SGPRs it has already spilled
+// and reassigned (observed as a wild address once the allocator was under pressure)
+__device__ __forceinline__ void sload12(const double *p, int byte_off, d8_t &a, d4_t &b) {
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx8 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b) : "s"(p), "s"(byte_off), "s"(byte_off + 64));
+}
+
+
+// one row (24 doubles) of a wave-uniform table, requested and awaited inside one asm statement (see sload12)
+__device__ __forceinline__ void sload24(const double *p, int byte_off, d8_t &a, d8_t &b, d8_t &c) {
+    asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %5\n\ts_load_dwordx16 %2, %3, %6\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c) : "s"(p), "s"(byte_off), "s"(byte_off + 64), "s"(byte_off + 128));
+}
+
+
+}  // namespace vfem

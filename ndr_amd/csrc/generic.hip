@@ -10,10 +10,12 @@
 // the operator apply, the residual and the multicoloured block Gauss-Seidel (MG.hh:193-340) share it.  Deterministic:
 // fixed lane ownership and a fixed xor-shuffle reduction tree.
 #include "vfem_internal.h"
+#include "q2_modes.h"
 
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -334,6 +336,8 @@ __global__ void __launch_bounds__(256) kg_gradient(GDims d, const double *__rest
 
 using namespace vfem;
 
+int g_q2_impl = 0;       // vfem_debug_set(6, v): 0 = pencil kernel (mode space), 1 = dense gather kernel (cross-check)
+
 // ------------------------------------------------------------------------------------------
 // handles
 // ------------------------------------------------------------------------------------------
@@ -344,6 +348,8 @@ struct vfem_gsim {
     double E0 = 1.0, Emin = 1e-9, gamma = 3.0;     // TPS.hh:1392-1394
     std::vector<double> K0;
     DevBuf<double> dK0, rho, E, dvals;
+    DevBuf<double> q2tab;                          // degree-2 hexahedra: packed mode-space blocks (q2_modes.h)
+    bool q2_fast = false;
     DevBuf<uint8_t> dmask;
     std::vector<uint8_t> hmask;
     void update_k0();
@@ -422,6 +428,48 @@ void vfem_gsim::update_k0() {
     }
     dK0.alloc(K0.size());
     VFEM_HIP(hipMemcpy(dK0.p, K0.data(), K0.size() * sizeof(double), hipMemcpyHostToDevice));
+    q2_fast = false;
+    if (N == 3 && p == 2) {
+        // mode-space matrix Kt = T^-T K0 T^-1 (q2_modes.h); T^-1 per axis: u0 = (s - a)/2, u1 = m, u2 = (s + a)/2
+        static const double Ti[3][3] = {{0.5, 0.0, -0.5}, {0.0, 1.0, 0.0}, {0.5, 0.0, 0.5}};      // [node][mode]
+        std::vector<double> T3(27 * 27), A((size_t) 81 * 81), Kt((size_t) 81 * 81);
+        for (int n = 0; n < 27; ++n)
+            for (int m = 0; m < 27; ++m)
+                T3[n * 27 + m] = Ti[n / 9][m / 9] * Ti[(n / 3) % 3][(m / 3) % 3] * Ti[n % 3][m % 3];
+        for (int i = 0; i < 81; ++i)                       // A = K0 T^-1
+            for (int m = 0; m < 27; ++m)
+                for (int c = 0; c < 3; ++c) {
+                    double v = 0.0;
+                    for (int n = 0; n < 27; ++n) v += K0[(size_t) i * 81 + 3 * n + c] * T3[n * 27 + m];
+                    A[(size_t) i * 81 + 3 * m + c] = v;
+                }
+        double scale = 0.0;
+        for (int m = 0; m < 27; ++m)                       // Kt = T^-T A
+            for (int c = 0; c < 3; ++c)
+                for (int j = 0; j < 81; ++j) {
+                    double v = 0.0;
+                    for (int n = 0; n < 27; ++n) v += T3[n * 27 + m] * A[(size_t) (3 * n + c) * 81 + j];
+                    Kt[(size_t) (3 * m + c) * 81 + j] = v;
+                    scale = std::max(scale, std::fabs(v));
+                }
+        std::vector<int> cls(81, -1);
+        for (int P = 0; P < 8; ++P)
+            for (int j = 0; j < Q2C.n[P]; ++j) cls[Q2C.idx[P][j]] = P;
+        double off = 0.0;
+        for (int i = 0; i < 81; ++i)
+            for (int j = 0; j < 81; ++j)
+                if (cls[i] != cls[j]) off = std::max(off, std::fabs(Kt[(size_t) i * 81 + j]));
+        if (off <= 1e-12 * scale) {
+            std::vector<double> tab(Q2_TABLE_DOUBLES, 0.0);
+            for (int P = 0; P < 8; ++P)
+                for (int i = 0; i < Q2C.n[P]; ++i)
+                    for (int j = 0; j < Q2C.n[P]; ++j)
+                        tab[(size_t) (Q2C.rowbase[P] + i) * 12 + j] = Kt[(size_t) Q2C.idx[P][i] * 81 + Q2C.idx[P][j]];
+            q2tab.alloc(tab.size());
+            VFEM_HIP(hipMemcpy(q2tab.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+            q2_fast = true;
+        }
+    }
 }
 
 static inline hipStream_t GS(void *s) { return (hipStream_t) s; }
@@ -707,7 +755,9 @@ int vfem_gsim_get_densities(const vfem_gsim *sim, double *rho, void *stream) {
 }
 int vfem_gsim_apply_k(const vfem_gsim *sim, const double *u, double *out, void *stream) {
     G_TRY
-    if (sim->d.N == 3 && sim->d.p == 2)
+    if (sim->d.N == 3 && sim->d.p == 2 && sim->q2_fast && g_q2_impl == 0)
+        launch_apply_q2_pencil(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E.p, u, out, GS(stream));
+    else if (sim->d.N == 3 && sim->d.p == 2)
         launch_apply_q2(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->dK0.p, sim->E.p, u, out, GS(stream));
     else
         g_apply(sim->d, sim->dK0.p, 0, sim->E.p, u, nullptr, nullptr, 0, out, GS(stream));

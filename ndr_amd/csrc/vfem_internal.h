@@ -124,6 +124,7 @@ void launch_oc_candidate(long long n, const double *x0, const double *dJ, const 
 void launch_sum(long long n, const double *a, double *scratch, double *out, hipStream_t s);
 
 void launch_apply_q2(int nx, int ny, int nz, const double *K0, const double *E, const double *u, double *out, hipStream_t s);
+void launch_apply_q2_pencil(int nx, int ny, int nz, const double *mode_table, const double *E, const double *u, double *out, hipStream_t s);
 void launch_gradient_q2(int nx, int ny, int nz, const double *K0, const double *rho, double E0, double Emin, double gamma,
                         const double *u, double *g, hipStream_t s);
 
