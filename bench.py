@@ -241,11 +241,13 @@ def main():
             result["mlp_forward"] = mlp_rate()
         except RuntimeError as e:
             result["mlp_forward"] = {"error": str(e)}
-        torch.cuda.empty_cache()
-        try:
-            result["degree2_spmv"] = degree2_rate()
-        except RuntimeError as e:
-            result["degree2_spmv"] = {"error": str(e)}
+        result["degree2_spmv"] = []
+        for q2ne in ((256, 256, 256), (512, 512, 512)):
+            torch.cuda.empty_cache()
+            try:
+                result["degree2_spmv"].append(degree2_rate(q2ne))
+            except RuntimeError as e:
+                result["degree2_spmv"].append({"grid": "%dx%dx%d" % q2ne, "error": str(e)})
     if not args.no_cpu:
         result["cpu_baseline"] = cpu_baseline((160, 160, 160))
     print(json.dumps(result))
