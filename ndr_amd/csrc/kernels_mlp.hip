@@ -44,28 +44,80 @@ __device__ __forceinline__ void voxel_coord(const MlpArgs &a, long long v, float
     x[2] = a.glo[2] + a.gstep[2] * (float) k;
 }
 
-// one GEMM layer: acc[t][c] (row tile t of this wave, voxel tile c) += W[n][k] X[v][k] over k in [0, K)
-// X image: xs[v * xstride + k]; row tiles of this wave: rt0 + 8 t (t < ntile)
-template <int XSTRIDE>
-__device__ __forceinline__ void gemm_chunk(f16_t acc[2][4], const _Float16 *__restrict__ W, int ldw, int k_base,
-                                           const _Float16 *xs, int k_local0, int ksteps, int wave, int ntiles, int lane) {
-    const int r = lane & 31, h = lane >> 5;
-#pragma unroll 2
-    for (int ks = 0; ks < ksteps; ++ks) {
-        h8_t bfrag[4];
+// Weight (A operand) fragments are prefetched MLP_PD k-steps ahead in a register ring: a fragment is one 16-byte load from
+// the L2-resident weight matrix, whose latency (~600 cycles) is several times the 256 MFMA cycles of a k-step, so without
+// the ring the matrix pipe idles on every step.
+constexpr int MLP_PD = 4;
+
+struct APipe {
+    const _Float16 *row[2];
+    bool on[2];
+    h8_t ring[MLP_PD][2];
+    int total;                                  // k-steps of the whole layer
+
+    __device__ __forceinline__ void load(int slot, int ks) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            bfrag[c] = *reinterpret_cast<const h8_t *>(xs + (c * 32 + r) * XSTRIDE + k_local0 + ks * 16 + 8 * h);
+        for (int t = 0; t < 2; ++t)
+            if (on[t]) ring[slot][t] = *reinterpret_cast<const h8_t *>(row[t] + ks * 16);
+    }
+    __device__ __forceinline__ void init(const _Float16 *W, int ldw, int wave, int ntiles, int lane, int total_ksteps) {
+        const int r = lane & 31, h = lane >> 5;
+        total = total_ksteps;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int tile = wave + 8 * t;
-            if (tile < ntiles) {
-                const h8_t afrag = *reinterpret_cast<const h8_t *>(W + (long long) (tile * 32 + r) * ldw + k_base + ks * 16 + 8 * h);
+            on[t] = tile < ntiles;
+            row[t] = W + (long long) ((on[t] ? tile : 0) * 32 + r) * ldw + 8 * h;
+        }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bfrag[c], acc[t][c], 0, 0, 0);
+        for (int p = 0; p < MLP_PD; ++p)
+            if (p < total) load(p, p);
+    }
+};
+
+// MLP_PD consecutive k-steps (one revolution of the ring) starting at k-step ks0 of the layer:
+// acc[t][c] (row tile t of this wave, voxel tile c) += W[n][k] X[v][k];  X image: xs[v * XSTRIDE + k_local], the first
+// k-step of this call sits at k_local0
+// `between(p)` runs right after the MFMAs of k-step p were issued: independent vector work placed there executes while the
+// matrix pipe is busy (the first layer generates the next chunk's Fourier features this way)
+template <int XSTRIDE, class Between>
+__device__ __forceinline__ void gemm_ring(f16_t acc[2][4], APipe &ap, int ks0, const _Float16 *xs, int k_local0, int lane, Between &&between) {
+    const int r = lane & 31, h = lane >> 5;
+    h8_t bcur[4], bnext[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bcur[c] = *reinterpret_cast<const h8_t *>(xs + (c * 32 + r) * XSTRIDE + k_local0 + 8 * h);
+#pragma unroll
+    for (int p = 0; p < MLP_PD; ++p) {
+        const int ks = ks0 + p;
+        if (ks < ap.total) {
+            if (p + 1 < MLP_PD && ks + 1 < ap.total) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    bnext[c] = *reinterpret_cast<const h8_t *>(xs + (c * 32 + r) * XSTRIDE + k_local0 + (p + 1) * 16 + 8 * h);
             }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (ap.on[t]) {
+                    const h8_t afrag = ap.ring[p][t];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bcur[c], acc[t][c], 0, 0, 0);
+                }
+            }
+            if (ks + MLP_PD < ap.total) ap.load(p, ks + MLP_PD);
+            between(p);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bcur[c] = bnext[c];
         }
     }
+}
+
+// a whole layer whose operand image is resident in LDS (hidden layers, backward data path)
+template <int XSTRIDE>
+__device__ __forceinline__ void gemm_layer(f16_t acc[2][4], const _Float16 *W, int ldw, int K, const _Float16 *xs, int wave, int ntiles,
+                                           int lane) {
+    APipe ap;
+    ap.init(W, ldw, wave, ntiles, lane, K / 16);
+    for (int ks0 = 0; ks0 < ap.total; ks0 += MLP_PD) gemm_ring<XSTRIDE>(acc, ap, ks0, xs, ks0 * 16, lane, [](int) {});
 }
 
 __global__ void __launch_bounds__(512) k_mlp_forward(MlpArgs a) {
@@ -96,13 +148,13 @@ __global__ void __launch_bounds__(512) k_mlp_forward(MlpArgs a) {
     // ---- layer 1: K = 2 es, features generated chunk by chunk --------------------------------
     const int K1 = 2 * a.es;
     const int nchunks = K1 / MLP_KC;
-    auto make_features = [&](int chunk, int buf) {
+    // 128 voxels x 64 features = 8192 values, 16 per thread in four parts of 4: thread -> (voxel = tid & 127, features fq*16 ..)
+    auto make_features_part = [&](int chunk, int buf, int part) {
         _Float16 *Fb = F + buf * (MLP_TM * MLP_FSTRIDE);
-        // 128 voxels x 64 features = 8192 values, 16 per thread: thread -> (voxel = tid & 127, 16 features)
         const int v = tid & 127, fq = tid >> 7;                  // fq in 0..3 -> features fq*16 .. +15
         const float x0 = xc[3 * v], x1 = xc[3 * v + 1], x2 = xc[3 * v + 2];
-#pragma unroll
-        for (int j = 0; j < 16; j += 4) {
+        {
+            const int j = 4 * part;
             h4_t o;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -117,11 +169,19 @@ __global__ void __launch_bounds__(512) k_mlp_forward(MlpArgs a) {
             *reinterpret_cast<h4_t *>(Fb + v * MLP_FSTRIDE + fq * 16 + j) = o;
         }
     };
+    auto make_features = [&](int chunk, int buf) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) make_features_part(chunk, buf, part);
+    };
+    APipe ap1;
+    ap1.init((const _Float16 *) a.W1, K1, wave, ntiles, lane, K1 / 16);      // weight prefetch runs across the feature chunks
     make_features(0, 0);
     __syncthreads();
+    static_assert(MLP_KC / 16 == MLP_PD, "one feature chunk = one revolution of the weight ring");
     for (int ch = 0; ch < nchunks; ++ch) {
+        // (generating the features in parts between the MFMA groups of the chunk was measured slower than doing them first)
         if (ch + 1 < nchunks) make_features(ch + 1, (ch + 1) & 1);
-        gemm_chunk<MLP_FSTRIDE>(acc, (const _Float16 *) a.W1, K1, ch * MLP_KC, F + (ch & 1) * (MLP_TM * MLP_FSTRIDE), 0, MLP_KC / 16, wave, ntiles, lane);
+        gemm_ring<MLP_FSTRIDE>(acc, ap1, ch * MLP_PD, F + (ch & 1) * (MLP_TM * MLP_FSTRIDE), 0, lane, [](int) {});
         __syncthreads();
     }
 
@@ -165,7 +225,7 @@ __global__ void __launch_bounds__(512) k_mlp_forward(MlpArgs a) {
 
     // ---- hidden layers ----------------------------------------------------------------------
     for (int l = 0; l < a.n_hidden; ++l) {
-        gemm_chunk<MLP_HSTRIDE>(acc, (const _Float16 *) a.Wh + (long long) l * a.nn * a.nn, a.nn, 0, H, 0, a.nn / 16, wave, ntiles, lane);
+        gemm_layer<MLP_HSTRIDE>(acc, (const _Float16 *) a.Wh + (long long) l * a.nn * a.nn, a.nn, a.nn, H, wave, ntiles, lane);
         __syncthreads();          // every wave finished reading H
         store_layer(a.bias + (l + 1) * a.nn);
         __syncthreads();
@@ -253,7 +313,7 @@ __global__ void __launch_bounds__(512) k_mlp_backward(MlpBwdArgs a) {
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[t][c][q] = 0.f;
-        gemm_chunk<MLP_HSTRIDE>(acc, (const _Float16 *) a.WhT + (long long) l * a.nn * a.nn, a.nn, 0, H, 0, a.nn / 16, wave, ntiles, lane);
+        gemm_layer<MLP_HSTRIDE>(acc, (const _Float16 *) a.WhT + (long long) l * a.nn * a.nn, a.nn, a.nn, H, wave, ntiles, lane);
         __syncthreads();
         {   // raw dh -> H (fp16)
             const int col = lane & 31, h = lane >> 5;
