@@ -70,6 +70,8 @@ SIGNATURES = {
     "vfem_mg_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vfem_mg_pcg": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_int, c_int,
                             RESIDUAL_CB, c_void_p, POINTER(c_int), POINTER(c_double), c_void_p]),
+    "vfem_mlp_forward_grid_range": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double), c_int64, c_int64,
+                                            c_void_p, c_void_p, c_void_p]),
     "vfem_mlp_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vfem_mlp_backward_grid": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double), c_void_p, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

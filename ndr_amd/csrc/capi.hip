@@ -885,11 +885,7 @@ int vfem_mlp_forward(vfem_mlp *m, const float *coords, int64_t nvox, float *o32,
     launch_mlp_forward(a, S(stream));
     VFEM_CATCH
 }
-int vfem_mlp_forward_grid(vfem_mlp *m, const int64_t n[3], const double lo[3], const double hi[3], float *o32, double *o64,
-                          void *stream) {
-    VFEM_TRY
-    if (!m->loaded) throw Error("vfem_mlp_load_weights has not been called");
-    MlpArgs a = mlp_base_args(m);
+static void mlp_grid_args(MlpArgs &a, const int64_t n[3], const double lo[3], const double hi[3]) {
     a.coords = nullptr;
     a.nvox = 1;
     for (int dd = 0; dd < 3; ++dd) {
@@ -898,7 +894,27 @@ int vfem_mlp_forward_grid(vfem_mlp *m, const int64_t n[3], const double lo[3], c
         a.gstep[dd] = n[dd] > 1 ? (float) ((hi[dd] - lo[dd]) / (double) (n[dd] - 1)) : 0.f;
         a.nvox *= n[dd];
     }
+}
+int vfem_mlp_forward_grid(vfem_mlp *m, const int64_t n[3], const double lo[3], const double hi[3], float *o32, double *o64,
+                          void *stream) {
+    VFEM_TRY
+    if (!m->loaded) throw Error("vfem_mlp_load_weights has not been called");
+    MlpArgs a = mlp_base_args(m);
+    mlp_grid_args(a, n, lo, hi);
     a.out32 = o32; a.out64 = o64;
+    launch_mlp_forward(a, S(stream));
+    VFEM_CATCH
+}
+int vfem_mlp_forward_grid_range(vfem_mlp *m, const int64_t n[3], const double lo[3], const double hi[3], int64_t first_voxel,
+                                int64_t num_voxels, float *o32, double *o64, void *stream) {
+    VFEM_TRY
+    if (!m->loaded) throw Error("vfem_mlp_load_weights has not been called");
+    MlpArgs a = mlp_base_args(m);
+    mlp_grid_args(a, n, lo, hi);
+    if (first_voxel < 0 || num_voxels < 0 || first_voxel + num_voxels > a.nvox) throw Error("voxel range outside the grid");
+    if (num_voxels == 0) return 0;
+    a.v_offset = first_voxel; a.nvox = num_voxels;
+    a.out32 = o32; a.out64 = o64;                      // outputs are indexed from the start of the range
     launch_mlp_forward(a, S(stream));
     VFEM_CATCH
 }

@@ -259,6 +259,44 @@ def bench_pcg(ne, levels, tol=1e-4):
             "compliance": 2.0 * ds.compliance(f, u)}
 
 
+def bench_mlp(side=(512, 256, 256), es=1024, nn_=512, nl=4, sigma=4.0, reps=3):
+    """MLP-forward voxels/s over the ranks: the density field needs no exchange, every rank evaluates the x-planes of its
+    slab (a contiguous voxel range) with replicated weights; time = max over ranks, voxels = the whole grid"""
+    import numpy as np
+    from .mlp import MLP
+    world, rank = dist.get_world_size(), dist.get_rank()
+    rng = np.random.default_rng(88)
+    B = (rng.standard_normal((es, 3)) * sigma).astype(np.float32)
+    Ws = [rng.standard_normal((nn_, 2 * es)).astype(np.float32) / np.sqrt(2 * es)]
+    Ws += [rng.standard_normal((nn_, nn_)).astype(np.float32) / np.sqrt(nn_) for _ in range(nl - 2)]
+    Ws += [rng.standard_normal((1, nn_)).astype(np.float32) / np.sqrt(nn_)]
+    bs = [rng.standard_normal(nn_).astype(np.float32) * 0.1 for _ in range(nl - 1)] + [np.array([0.4], np.float32)]
+    m = MLP(3, 1, nn_, nl, es, sigma)
+    m.load_arrays(B, Ws, bs)
+    x0, x1 = rank * side[0] // world, (rank + 1) * side[0] // world
+    plane = side[1] * side[2]
+    m.forward_grid_range(side, x0 * plane, (x1 - x0) * plane)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = m.forward_grid_range(side, x0 * plane, (x1 - x0) * plane)
+    torch.cuda.synchronize()
+    dt = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64)
+    chk = out.double().sum().reshape(1)
+    if dist.get_backend() != "gloo":
+        dt = dt.cuda()
+    else:
+        chk = chk.cpu()
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dist.all_reduce(chk)
+    nv = side[0] * plane
+    flop = 2.0 * (3 * es + 2 * es * nn_ + (nl - 2) * nn_ * nn_ + nn_) * nv
+    sec = float(dt.item())
+    return {"grid": "%dx%dx%d" % tuple(side), "network": "%d->%d x%d->1" % (2 * es, nn_, nl - 1), "seconds": sec,
+            "voxels_per_s": nv / sec, "tflops": flop / sec / 1e12, "checksum": float(chk.item())}
+
+
 def bench_apply(ne, steps, warmup, with_cg=True):
     """bench.py's N > 1 leg: K steps of {halo exchange + local apply}, max over ranks, whole-grid GVoxel/s."""
     init_process_group_from_env()
@@ -310,6 +348,7 @@ def bench_apply(ne, steps, warmup, with_cg=True):
                      "note": "whole-step time (halo exchange included), aggregate peak of all GPUs"},
         "checksum_KuKu": float(chk.item()),
         "cg_mg": cg,
+        "mlp_forward": bench_mlp() if with_cg else None,
     }
 
 

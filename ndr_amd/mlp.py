@@ -79,6 +79,19 @@ class MLP:
             raise RuntimeError("weight shapes do not match the network configuration")
         _lib.check(self._lib.vfem_mlp_load_weights(self._h, _ptr(Bt), _ptr(W1), _ptr(Wh), _ptr(bs), _ptr(wout), bout))
 
+    def forward_grid_range(self, sidelen, first_voxel, num_voxels, domain=None, out_f64=None):
+        """densities of the voxels [first_voxel, first_voxel + num_voxels) of the grid (flat index, z fastest): what one
+        rank of an x-slab decomposition evaluates (its planes are a contiguous voxel range)"""
+        n = (ctypes.c_int64 * 3)(*[int(s) for s in sidelen])
+        dom = domain if domain is not None else [[0.0, 1.0]] * 3
+        lo = (ctypes.c_double * 3)(*[float(d[0]) for d in dom])
+        hi = (ctypes.c_double * 3)(*[float(d[1]) for d in dom])
+        out = torch.empty(int(num_voxels), dtype=torch.float32, device=_dev())
+        o64 = _ptr(out_f64) if out_f64 is not None else None
+        _lib.check(self._lib.vfem_mlp_forward_grid_range(self._h, n, lo, hi, int(first_voxel), int(num_voxels), _ptr(out), o64,
+                                                         _stream()))
+        return out
+
     # ---- training (SURVEY 8f-2) ----
     def _grad_buffers(self):
         nn_, nl, es = self.n_neurons, self.n_layers, self.embedding_size

@@ -185,3 +185,24 @@ def test_trainable_mlp_fits_a_target_field_and_keeps_reference_state_dict_layout
         net.adam_step(lr=3e-3)
         losses.append(float(loss.item()))
     assert losses[-1] < 0.25 * losses[0], (losses[0], losses[-1])
+
+
+@pytest.mark.gpu
+def test_grid_range_equals_slices_of_the_whole_grid():
+    """what a rank of the slab decomposition evaluates (a contiguous voxel range) is bit-identical to that part of the
+    whole-grid evaluation, float32 and float64 outputs"""
+    import torch
+    from ndr_amd.mlp import MLP
+    z, es, nn_, nl, sig, Ws, bs = _load(FIXTURES[-1])
+    m = MLP(3, 1, nn_, nl, es, float(z["sigma"][0]), output_act=torch.nn.Sigmoid() if sig else None)
+    m.load_arrays(z["B"], Ws, bs)
+    side = (20, 9, 13)
+    full = m.forward_grid(side).reshape(-1)
+    plane = side[1] * side[2]
+    for x0, x1 in ((0, 5), (5, 6), (6, 20), (0, 20)):
+        o64 = torch.empty((x1 - x0) * plane, dtype=torch.float64, device="cuda")
+        part = m.forward_grid_range(side, x0 * plane, (x1 - x0) * plane, out_f64=o64)
+        assert torch.equal(part, full[x0 * plane:x1 * plane])
+        assert torch.equal(o64, part.double())
+    with pytest.raises(RuntimeError):
+        m.forward_grid_range(side, 19 * plane, 2 * plane)
