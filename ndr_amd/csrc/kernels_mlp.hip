@@ -49,6 +49,7 @@ __device__ __forceinline__ void voxel_coord(const MlpArgs &a, long long v, float
 // the ring the matrix pipe idles on every step.
 constexpr int MLP_PD = 4;
 
+template <bool FULL>                            // FULL: 16 row tiles (both tiles of every wave live), k-steps a multiple of MLP_PD
 struct APipe {
     const _Float16 *row[2];
     bool on[2];
@@ -58,7 +59,7 @@ struct APipe {
     __device__ __forceinline__ void load(int slot, int ks) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-            if (on[t]) ring[slot][t] = *reinterpret_cast<const h8_t *>(row[t] + ks * 16);
+            if (FULL || on[t]) ring[slot][t] = *reinterpret_cast<const h8_t *>(row[t] + ks * 16);
     }
     __device__ __forceinline__ void init(const _Float16 *W, int ldw, int wave, int ntiles, int lane, int total_ksteps) {
         const int r = lane & 31, h = lane >> 5;
@@ -66,12 +67,12 @@ struct APipe {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int tile = wave + 8 * t;
-            on[t] = tile < ntiles;
+            on[t] = FULL || tile < ntiles;
             row[t] = W + (long long) ((on[t] ? tile : 0) * 32 + r) * ldw + 8 * h;
         }
 #pragma unroll
         for (int p = 0; p < MLP_PD; ++p)
-            if (p < total) load(p, p);
+            if (FULL || p < total) load(p, p);
     }
 };
 
@@ -80,8 +81,8 @@ struct APipe {
 // k-step of this call sits at k_local0
 // `between(p)` runs right after the MFMAs of k-step p were issued: independent vector work placed there executes while the
 // matrix pipe is busy (the first layer generates the next chunk's Fourier features this way)
-template <int XSTRIDE, class Between>
-__device__ __forceinline__ void gemm_ring(f16_t acc[2][4], APipe &ap, int ks0, const _Float16 *xs, int k_local0, int lane, Between &&between) {
+template <int XSTRIDE, bool FULL, class Between>
+__device__ __forceinline__ void gemm_ring(f16_t acc[2][4], APipe<FULL> &ap, int ks0, const _Float16 *xs, int k_local0, int lane, Between &&between) {
     const int r = lane & 31, h = lane >> 5;
     h8_t bcur[4], bnext[4];
 #pragma unroll
@@ -89,15 +90,15 @@ __device__ __forceinline__ void gemm_ring(f16_t acc[2][4], APipe &ap, int ks0, c
 #pragma unroll
     for (int p = 0; p < MLP_PD; ++p) {
         const int ks = ks0 + p;
-        if (ks < ap.total) {
-            if (p + 1 < MLP_PD && ks + 1 < ap.total) {
+        if (FULL || ks < ap.total) {
+            if (p + 1 < MLP_PD && (FULL || ks + 1 < ap.total)) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     bnext[c] = *reinterpret_cast<const h8_t *>(xs + (c * 32 + r) * XSTRIDE + k_local0 + (p + 1) * 16 + 8 * h);
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                if (ap.on[t]) {
+                if (FULL || ap.on[t]) {
                     const h8_t afrag = ap.ring[p][t];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bcur[c], acc[t][c], 0, 0, 0);
@@ -112,14 +113,15 @@ __device__ __forceinline__ void gemm_ring(f16_t acc[2][4], APipe &ap, int ks0, c
 }
 
 // a whole layer whose operand image is resident in LDS (hidden layers, backward data path)
-template <int XSTRIDE>
+template <int XSTRIDE, bool FULL>
 __device__ __forceinline__ void gemm_layer(f16_t acc[2][4], const _Float16 *W, int ldw, int K, const _Float16 *xs, int wave, int ntiles,
                                            int lane) {
-    APipe ap;
+    APipe<FULL> ap;
     ap.init(W, ldw, wave, ntiles, lane, K / 16);
-    for (int ks0 = 0; ks0 < ap.total; ks0 += MLP_PD) gemm_ring<XSTRIDE>(acc, ap, ks0, xs, ks0 * 16, lane, [](int) {});
+    for (int ks0 = 0; ks0 < ap.total; ks0 += MLP_PD) gemm_ring<XSTRIDE, FULL>(acc, ap, ks0, xs, ks0 * 16, lane, [](int) {});
 }
 
+template <bool FULL>
 __global__ void __launch_bounds__(512) k_mlp_forward(MlpArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     _Float16 *H = reinterpret_cast<_Float16 *>(smem);                            // [128][HSTRIDE]
@@ -161,10 +163,10 @@ __global__ void __launch_bounds__(512) k_mlp_forward(MlpArgs a) {
                 const int f = chunk * MLP_KC + fq * 16 + j + jj;     // feature index in [0, 2 es)
                 const bool is_cos = f >= a.es;
                 const int fi = is_cos ? f - a.es : f;
-                const float t = fmaf(x0, a.B[3 * fi], fmaf(x1, a.B[3 * fi + 1], x2 * a.B[3 * fi + 2]));   // revolutions
+                // phase in revolutions; cos x = sin(x + 1/4 turn): one transcendental per feature
+                const float t = fmaf(x0, a.B[3 * fi], fmaf(x1, a.B[3 * fi + 1], fmaf(x2, a.B[3 * fi + 2], is_cos ? 0.25f : 0.f)));
                 const float fr = t - floorf(t);
-                const float s = is_cos ? __builtin_amdgcn_cosf(fr) : __builtin_amdgcn_sinf(fr);
-                o[jj] = (_Float16) s;
+                o[jj] = (_Float16) __builtin_amdgcn_sinf(fr);
             }
             *reinterpret_cast<h4_t *>(Fb + v * MLP_FSTRIDE + fq * 16 + j) = o;
         }
@@ -173,7 +175,7 @@ __global__ void __launch_bounds__(512) k_mlp_forward(MlpArgs a) {
 #pragma unroll
         for (int part = 0; part < 4; ++part) make_features_part(chunk, buf, part);
     };
-    APipe ap1;
+    APipe<FULL> ap1;
     ap1.init((const _Float16 *) a.W1, K1, wave, ntiles, lane, K1 / 16);      // weight prefetch runs across the feature chunks
     make_features(0, 0);
     __syncthreads();
@@ -181,7 +183,7 @@ __global__ void __launch_bounds__(512) k_mlp_forward(MlpArgs a) {
     for (int ch = 0; ch < nchunks; ++ch) {
         // (generating the features in parts between the MFMA groups of the chunk was measured slower than doing them first)
         if (ch + 1 < nchunks) make_features(ch + 1, (ch + 1) & 1);
-        gemm_ring<MLP_FSTRIDE>(acc, ap1, ch * MLP_PD, F + (ch & 1) * (MLP_TM * MLP_FSTRIDE), 0, lane, [](int) {});
+        gemm_ring<MLP_FSTRIDE, FULL>(acc, ap1, ch * MLP_PD, F + (ch & 1) * (MLP_TM * MLP_FSTRIDE), 0, lane, [](int) {});
         __syncthreads();
     }
 
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(512) k_mlp_forward(MlpArgs a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int tile = wave + 8 * t;
-            if (tile >= ntiles) continue;
+            if (!FULL && tile >= ntiles) continue;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -225,7 +227,7 @@ __global__ void __launch_bounds__(512) k_mlp_forward(MlpArgs a) {
 
     // ---- hidden layers ----------------------------------------------------------------------
     for (int l = 0; l < a.n_hidden; ++l) {
-        gemm_layer<MLP_HSTRIDE>(acc, (const _Float16 *) a.Wh + (long long) l * a.nn * a.nn, a.nn, a.nn, H, wave, ntiles, lane);
+        gemm_layer<MLP_HSTRIDE, FULL>(acc, (const _Float16 *) a.Wh + (long long) l * a.nn * a.nn, a.nn, a.nn, H, wave, ntiles, lane);
         __syncthreads();          // every wave finished reading H
         store_layer(a.bias + (l + 1) * a.nn);
         __syncthreads();
@@ -253,11 +255,13 @@ void launch_mlp_forward(const MlpArgs &a, hipStream_t s) {
     const size_t lds = (size_t) MLP_TM * MLP_HSTRIDE * 2 + MLP_TM * 3 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_forward, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_forward<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_forward<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         attr_set = true;
     }
     const long long blocks = (a.nvox + MLP_TM - 1) / MLP_TM;
-    k_mlp_forward<<<dim3((unsigned) blocks), dim3(512), lds, s>>>(a);
+    if (a.nn == MLP_MAXN) k_mlp_forward<true><<<dim3((unsigned) blocks), dim3(512), lds, s>>>(a);      // every branch on tile / k-step validity folds away
+    else                  k_mlp_forward<false><<<dim3((unsigned) blocks), dim3(512), lds, s>>>(a);
     VFEM_HIP(hipGetLastError());
 }
 
@@ -313,7 +317,7 @@ __global__ void __launch_bounds__(512) k_mlp_backward(MlpBwdArgs a) {
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[t][c][q] = 0.f;
-        gemm_layer<MLP_HSTRIDE>(acc, (const _Float16 *) a.WhT + (long long) l * a.nn * a.nn, a.nn, a.nn, H, wave, ntiles, lane);
+        gemm_layer<MLP_HSTRIDE, false>(acc, (const _Float16 *) a.WhT + (long long) l * a.nn * a.nn, a.nn, a.nn, H, wave, ntiles, lane);
         __syncthreads();
         {   // raw dh -> H (fp16)
             const int col = lane & 31, h = lane >> 5;
