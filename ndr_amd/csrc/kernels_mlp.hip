@@ -153,7 +153,8 @@ __global__ void __launch_bounds__(512) k_mlp_forward(MlpArgs a) {
     // 128 voxels x 64 features = 8192 values, 16 per thread in four parts of 4: thread -> (voxel = tid & 127, features fq*16 ..)
     auto make_features_part = [&](int chunk, int buf, int part) {
         _Float16 *Fb = F + buf * (MLP_TM * MLP_FSTRIDE);
-        const int v = tid & 127, fq = tid >> 7;                  // fq in 0..3 -> features fq*16 .. +15
+        // fq in 0..3 -> features fq*16 .. +15; constant inside a wave, so the rows of B are fetched with scalar loads
+        const int v = tid & 127, fq = __builtin_amdgcn_readfirstlane(tid >> 7);
         const float x0 = xc[3 * v], x1 = xc[3 * v + 1], x2 = xc[3 * v + 2];
         {
             const int j = 4 * part;
