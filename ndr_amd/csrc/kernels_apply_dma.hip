@@ -25,7 +25,7 @@ constexpr int U_INSTR = 14;                 // 896 pieces of 16 B
 constexpr int E_INSTR = 5;                  // 8 rows x 33 pieces (32 + 1 for the alignment shift) = 264 <= 320
 constexpr int SLOT_BYTES = U_INSTR * 1024 + E_INSTR * 1024;   // 18432
 constexpr int RING = 4;
-constexpr int SS_DOUBLES = 9 * TY * TZ;     // one scatter buffer
+constexpr int SS_DOUBLES = 3 * TY * TZ;     // one scatter buffer (per component the sum owed to the next row in y)
 constexpr size_t LDS_BYTES = (size_t) RING * SLOT_BYTES + 2 * SS_DOUBLES * sizeof(double);
 }  // namespace dma
 
@@ -46,6 +46,14 @@ __device__ __forceinline__ void wait_plane(bool has_stores, bool steady) {
     } else {
         if (CNT == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     }
+}
+
+// value held by the previous lane of the wave (lane 0 receives 0): DPP wave shift, two 32-bit moves per double, no LDS
+__device__ __forceinline__ double lane_below(double v) {
+    const unsigned long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned) (b & 0xffffffffull), 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned) (b >> 32), 0x138, 0xf, 0xf, true);
+    return __longlong_as_double(((unsigned long long) hi << 32) | lo);
 }
 
 template <int EXP>
@@ -206,27 +214,27 @@ __global__ void __launch_bounds__(512, 2) k_apply_dma(Dims d, DmArgs2 dm, const 
         }
     };
     auto scatter_face = [&](const double acc[4][3], double wa[3], int buf) {
-        double *sB = sS + buf * SS_DOUBLES, *sC = sB + 3 * TY * TZ, *sD = sC + 3 * TY * TZ;
+        double *sX = sS + buf * SS_DOUBLES;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const double p = acc[0][c] - acc[2][c], q = acc[1][c] - acc[3][c];
             const double r = acc[0][c] + acc[2][c], t = acc[1][c] + acc[3][c];
             wa[c] = p - q;
             if (EXP == 1 || EXP >= 3) { wa[c] += (p + q) + (r - t) + (r + t); continue; }
-            sB[(c * TY + ty) * TZ + tz] = p + q;
-            sC[(c * TY + ty) * TZ + tz] = r - t;
-            sD[(c * TY + ty) * TZ + tz] = r + t;
+            // the two terms owed to the z-neighbour move one lane up (DPP), only the sum owed to the y-neighbour (next wave)
+            // goes through LDS: 3 instead of 9 doubles written and read per thread and plane
+            wa[c] += lane_below(p + q);
+            sX[(c * TY + ty) * TZ + tz] = (r - t) + lane_below(r + t);
         }
     };
     auto emit_plane = [&](int i, const double wa[3], int buf) {
         if (!out_ok) return;
-        const double *sB = sS + buf * SS_DOUBLES, *sC = sB + 3 * TY * TZ, *sD = sC + 3 * TY * TZ;
+        const double *sX = sS + buf * SS_DOUBLES;
         const long long n = (long long) i * plane + (long long) ej * d.NZ + ek;
         double w[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            w[c] = (EXP == 1 || EXP >= 3) ? wa[c]
-                                          : wa[c] + sB[(c * TY + ty) * TZ + tz - 1] + sC[(c * TY + ty - 1) * TZ + tz] + sD[(c * TY + ty - 1) * TZ + tz - 1];
+            w[c] = (EXP == 1 || EXP >= 3) ? wa[c] : wa[c] + sX[(c * TY + ty - 1) * TZ + tz];
         out[3 * n] = w[0]; out[3 * n + 1] = w[1]; out[3 * n + 2] = w[2];
     };
 

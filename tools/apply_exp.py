@@ -12,7 +12,8 @@ g = torch.Generator(device="cuda").manual_seed(88)
 tps.setElementDensities(torch.rand(tps.numElements(), dtype=torch.float64, device="cuda", generator=g))
 u = torch.randn((tps.numNodes(), 3), dtype=torch.float64, device="cuda", generator=g)
 out = torch.empty_like(u)
-names = {0: "production", 1: "no scatter LDS", 2: "no Dm compute", 3: "no compute, no scatter", 4: "no compute/scatter/u reads"}
+names = {0: "production", 1: "no scatter LDS", 2: "no Dm compute", 3: "no compute, no scatter", 4: "no compute/scatter/u reads", 5: "z-neighbour terms by lane shift"}
+ref = None
 for exp in [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4, 0]:
     lib.vfem_debug_set(1, exp)
     for _ in range(3):
@@ -23,5 +24,8 @@ for exp in [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4, 0]:
     for _ in range(20):
         lib.vfem_sim_apply_k(tps._h, _ptr(u), _ptr(out), 0, _stream())
     b.record(); torch.cuda.synchronize()
-    print("EXP %d %-28s %.3f ms" % (exp, names.get(exp, ""), a.elapsed_time(b) / 20), flush=True)
+    if exp == 0 and ref is None:
+        ref = out.clone()
+    dev = float((out - ref).abs().max() / ref.abs().max()) if ref is not None else float("nan")
+    print("EXP %d %-32s %.3f ms   max rel deviation from production %.2e" % (exp, names.get(exp, ""), a.elapsed_time(b) / 20, dev), flush=True)
 lib.vfem_debug_set(1, 0)
