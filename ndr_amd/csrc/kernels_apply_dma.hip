@@ -18,11 +18,16 @@
 namespace vfem {
 
 namespace dma {
-constexpr int TY = 8, TZ = 64;
+#ifndef VFEM_DMA_TY
+#define VFEM_DMA_TY 12
+#endif
+constexpr int TY = VFEM_DMA_TY, TZ = 64;    // TY waves = TY element rows per block (8: 87.5 % of the lanes emit; 12: 91.7 %)
 constexpr int ROW_D = 196;                  // doubles per staged node row (98 pieces)
-constexpr int U_PIECES = (TY + 1) * 98;     // 882
-constexpr int U_INSTR = 14;                 // 896 pieces of 16 B
-constexpr int E_INSTR = 5;                  // 8 rows x 33 pieces (32 + 1 for the alignment shift) = 264 <= 320
+constexpr int U_PIECES = (TY + 1) * 98;
+constexpr int U_INSTR = (U_PIECES + 63) / 64;          // 64 pieces of 16 B per instruction (TY = 8: 14, TY = 12: 20)
+constexpr int E_INSTR = (TY * 33 + 63) / 64;           // TY rows x 33 pieces (32 + 1 for the alignment shift) (5 / 7)
+static_assert(U_INSTR <= 2 * TY && U_INSTR + E_INSTR <= 3 * TY && E_INSTR <= TY, "every wave issues 2 or 3 DMA instructions per plane");
+static_assert(U_INSTR + E_INSTR >= 2 * TY, "every wave issues at least 2 DMA instructions per plane (wait_plane counts on it)");
 constexpr int SLOT_BYTES = U_INSTR * 1024 + E_INSTR * 1024;   // 18432
 constexpr int RING = 4;
 constexpr int SS_DOUBLES = 3 * TY * TZ;     // one scatter buffer (per component the sum owed to the next row in y)
@@ -57,7 +62,7 @@ __device__ __forceinline__ double lane_below(double v) {
 }
 
 template <int EXP>
-__global__ void __launch_bounds__(512, 2) k_apply_dma(Dims d, DmArgs2 dm, const double *__restrict__ E,
+__global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, const double *__restrict__ E,
                                                       const double *__restrict__ u, double *__restrict__ out,
                                                       int planes_per_chunk, const char *u_last, const char *e_last,
                                                       int plane_lo, int plane_hi) {
@@ -88,13 +93,13 @@ __global__ void __launch_bounds__(512, 2) k_apply_dma(Dims d, DmArgs2 dm, const 
     const long long ubase8 = (long long) (reinterpret_cast<uintptr_t>(u) >> 3);
     const long long ebase8 = (long long) (reinterpret_cast<uintptr_t>(E) >> 3);
     const int ppar = (int) ((3 * plane) & 1), epar = (int) (elayer & 1);       // parity added per plane / element layer
-    // u: instruction j moves pieces [64 j, 64 j + 64) of the (TY+1) x 98 piece image; this wave owns j = wave, wave + 8
+    // u: instruction j moves pieces [64 j, 64 j + 64) of the (TY+1) x 98 piece image; this wave owns j = wave, wave + TY
     long long ugo[2];          // double offset (from plane start) of this lane's row start + 2 q
     int upar[2];               // parity of (ubase8 + row start) at plane 0
     bool uhas[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const int j = wave + 8 * s;
+        const int j = wave + TY * s;
         uhas[s] = j < U_INSTR;
         const int P = 64 * j + tz;
         int r = P / 98, q = P - r * 98;
@@ -106,8 +111,8 @@ __global__ void __launch_bounds__(512, 2) k_apply_dma(Dims d, DmArgs2 dm, const 
         upar[s] = (int) ((ubase8 + rs) & 1);
     }
     // E: instruction e moves pieces [64 e, 64 e + 64) of the TY x 33 piece image (32 + 1 for the shift);
-    // e = 0,1 -> waves 6,7 (which own a single u instruction), e = 2,3,4 -> waves 3,4,5
-    const int eidx = wave == 6 ? 0 : (wave == 7 ? 1 : ((wave >= 3 && wave <= 5) ? wave - 1 : -1));
+    // the E instructions go first to the waves that own a single u instruction (from the top), then to the waves below them
+    const int eidx = (TY - 1 - wave) < E_INSTR ? (TY - 1 - wave) : -1;
     const bool ehas = eidx >= 0;
     long long ego = 0;
     int epar0 = 0;
@@ -122,7 +127,7 @@ __global__ void __launch_bounds__(512, 2) k_apply_dma(Dims d, DmArgs2 dm, const 
         ego = rs + 2LL * q;
         epar0 = (int) ((ebase8 + rs) & 1);
     }
-    const int cnt = (uhas[1] ? 2 : 1) + (ehas ? 1 : 0);          // 2,2,2,3,3,3,2,2
+    const int cnt = (uhas[1] ? 2 : 1) + (ehas ? 1 : 0);          // TY = 8: 2,2,2,3,3,3,2,2
     // parities of the rows this thread consumes (node rows ty, ty+1; element row ty)
     int rpar[2], erpar;
 #pragma unroll
@@ -146,7 +151,7 @@ __global__ void __launch_bounds__(512, 2) k_apply_dma(Dims d, DmArgs2 dm, const 
                 const long long off = 3LL * i * plane + ugo[s] - ((upar[s] + ip) & 1);
                 const char *g = reinterpret_cast<const char *>(u + off);
                 g = g > u_last ? u_last : g;
-                glds16(g, slot + 1024 * (wave + 8 * s));
+                glds16(g, slot + 1024 * (wave + TY * s));
             }
         }
         if (ehas) {
@@ -181,7 +186,7 @@ __global__ void __launch_bounds__(512, 2) k_apply_dma(Dims d, DmArgs2 dm, const 
             if (uhas[s2]) {
                 const char *g = up_run[k][s2];
                 if (last) g = g > u_last ? u_last : g;
-                glds16(g, slot + 1024 * (wave + 8 * s2));
+                glds16(g, slot + 1024 * (wave + TY * s2));
                 up_run[k][s2] += 48LL * plane;         // two planes of 24 * plane bytes
             }
         }
