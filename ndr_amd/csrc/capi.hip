@@ -223,7 +223,7 @@ static void update_operators(vfem_mg *mg, hipStream_t s) {
     for (int l = 2; l <= L; ++l) {
         MgLevel &lv = mg->lv[l];
         lv.Ke.alloc((size_t) lv.da.ne * 576);
-        if (l == 2) launch_coarsen_ke(lv.da, 1, mg->cK0.p, sim->E.p, nullptr, lv.Ke.p, s);
+        if (l == 2) launch_coarsen_ke(lv.da, 3, mg->c2K0.p, sim->E.p, nullptr, lv.Ke.p, s);
         else        launch_coarsen_ke(lv.da, 2, nullptr, nullptr, mg->lv[l - 1].Ke.p, lv.Ke.p, s);
     }
     for (int l = std::max(2, mg->first_active); l <= L; ++l) {
@@ -520,6 +520,42 @@ static void finish_mg_create(vfem_mg *mg) {
     }
     mg->cK0.alloc(8 * 576);
     VFEM_HIP(hipMemcpy(mg->cK0.p, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice));
+    {   // c2K0[g][f] = I_g^T cK0[f] I_g: level-2 element matrices are a plain weighted sum of these 64 over the fine moduli
+        std::vector<double> c2((size_t) 64 * 576, 0.0);
+        for (int g = 0; g < 8; ++g) {
+            double ph[8][8];
+            for (int fn = 0; fn < 8; ++fn)
+                for (int cn = 0; cn < 8; ++cn) {
+                    double v = 1.0;
+                    for (int dd = 0; dd < 3; ++dd) {
+                        const int sh = 2 - dd;
+                        const double p = 0.5 * ((fn >> sh) & 1) + 0.5 * ((g >> sh) & 1);
+                        v *= ((cn >> sh) & 1) ? p : (1.0 - p);
+                    }
+                    ph[fn][cn] = v;
+                }
+            for (int f = 0; f < 8; ++f) {
+                const double *Kf = c.data() + (size_t) f * 576;
+                for (int a = 0; a < 24; ++a)
+                    for (int j = 0; j < 8; ++j)
+                        for (int dd = 0; dd < 3; ++dd) {
+                            double v = 0.0;
+                            for (int i = 0; i < 8; ++i) v += Kf[a * 24 + 3 * i + dd] * ph[i][j];
+                            T[a * 24 + 3 * j + dd] = v;
+                        }
+                double *out = c2.data() + (size_t) (g * 8 + f) * 576;
+                for (int j = 0; j < 8; ++j)
+                    for (int cc = 0; cc < 3; ++cc)
+                        for (int b = 0; b < 24; ++b) {
+                            double v = 0.0;
+                            for (int i = 0; i < 8; ++i) v += ph[i][j] * T[(3 * i + cc) * 24 + b];
+                            out[(3 * j + cc) * 24 + b] = v;
+                        }
+            }
+        }
+        mg->c2K0.alloc(c2.size());
+        VFEM_HIP(hipMemcpy(mg->c2K0.p, c2.data(), c2.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     mg->mf1_sym = coarsened_matrices_are_mirror_images(c.data());
     for (int l = mg->first_active; l <= mg->L; ++l) {
         MgLevel &lv = mg->lv[(size_t) l];

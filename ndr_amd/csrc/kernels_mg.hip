@@ -718,9 +718,47 @@ __global__ void __launch_bounds__(576) k_coarsen_ke(Dims c, const double *__rest
     Kec[ec * 576 + t] = acc;
 }
 
+// level-2 element matrices straight from the 64 fine moduli inside the element: Ke = sum_{g,f} E[g,f] * c2K0[g][f] with
+// c2K0[g][f] = I_g^T cK0[f] I_g precomputed on the host (the same sum as MODE 1 of k_coarsen_ke with the two triple products
+// folded into the table: 37 k instead of 250 k multiply-adds per element)
+constexpr int CK2_NB = 8;       // elements per block: every table entry fetched from L2 serves 8 elements
+__global__ void __launch_bounds__(576) k_coarsen_ke_two_levels(Dims c, const double *__restrict__ c2K0, const double *__restrict__ Ef,
+                                                               double *__restrict__ Kec) {
+    __shared__ double Es[CK2_NB][64];
+    const int t = threadIdx.x;
+    const long long e0 = (long long) blockIdx.x * CK2_NB;
+    const long long ny0 = 4LL * c.ny, nz0 = 4LL * c.nz;          // fine element dims
+    if (t < 64 * CK2_NB) {
+        const int b = t >> 6, q = t & 63, g = q >> 3, f = q & 7;
+        const long long ec = e0 + b;
+        double v = 0.0;
+        if (ec < c.ne) {
+            const int ez = (int) (ec % c.nz), ey = (int) ((ec / c.nz) % c.ny), ex = (int) (ec / ((long long) c.nz * c.ny));
+            const long long fx = 4LL * ex + 2 * ((g >> 2) & 1) + ((f >> 2) & 1), fy = 4LL * ey + 2 * ((g >> 1) & 1) + ((f >> 1) & 1),
+                            fz = 4LL * ez + 2 * (g & 1) + (f & 1);
+            v = Ef[(fx * ny0 + fy) * nz0 + fz];
+        }
+        Es[b][q] = v;
+    }
+    __syncthreads();
+    double acc[CK2_NB];
+#pragma unroll
+    for (int b = 0; b < CK2_NB; ++b) acc[b] = 0.0;
+#pragma unroll 4
+    for (int q = 0; q < 64; ++q) {
+        const double k = c2K0[q * 576 + t];
+#pragma unroll
+        for (int b = 0; b < CK2_NB; ++b) acc[b] = fma(Es[b][q], k, acc[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < CK2_NB; ++b)
+        if (e0 + b < c.ne) Kec[(e0 + b) * 576 + t] = acc[b];
+}
+
 void launch_coarsen_ke(const Dims &c, int mode, const double *cK0, const double *Efine, const double *Kef,
                        double *Kec, hipStream_t s) {
-    if (mode == 1) k_coarsen_ke<1><<<dim3((unsigned) c.ne), dim3(576), 0, s>>>(c, cK0, Efine, Kef, Kec);
+    if (mode == 3) k_coarsen_ke_two_levels<<<dim3((unsigned) ((c.ne + CK2_NB - 1) / CK2_NB)), dim3(576), 0, s>>>(c, cK0, Efine, Kec);
+    else if (mode == 1) k_coarsen_ke<1><<<dim3((unsigned) c.ne), dim3(576), 0, s>>>(c, cK0, Efine, Kef, Kec);
     else           k_coarsen_ke<2><<<dim3((unsigned) c.ne), dim3(576), 0, s>>>(c, cK0, Efine, Kef, Kec);
     VFEM_HIP(hipGetLastError());
 }

@@ -186,6 +186,7 @@ struct vfem_mg {
     int L = 0;                                  // numCoarseningLevels
     std::vector<MgLevel> lv;
     vfem::DevBuf<double> cK0;                   // 8 x 576 coarsened reference matrices (MG.hh:644-648)
+    vfem::DevBuf<double> c2K0;                  // 64 x 576: I_g^T cK0[f] I_g (level-2 element matrices from the fine moduli)
     vfem::DevBuf<double> Ainv;                  // coarsest-level dense inverse
     vfem::DevBuf<double> pr, pd, pAd, ps;       // PCG vectors
     vfem::DevBuf<double> scal, scratch;
