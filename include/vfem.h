@@ -235,6 +235,11 @@ int vfem_mlp_backward(vfem_mlp *mlp, const float *coords, int64_t nvox, const fl
 int vfem_mlp_backward_grid(vfem_mlp *mlp, const int64_t n_host[3], const double lo_host[3], const double hi_host[3],
                            const float *g_out, float loss_scale, float *dW1, float *dWh, float *dbias, float *dwout, float *dbout,
                            void *stream);
+/* the same for the voxels [first_voxel, first_voxel + num_voxels) of the grid (g_out indexed from the start of the range): the
+ * partial gradient a rank of the slab decomposition contributes; the ranks' results are summed by one all-reduce */
+int vfem_mlp_backward_grid_range(vfem_mlp *mlp, const int64_t n_host[3], const double lo_host[3], const double hi_host[3],
+                                 int64_t first_voxel, int64_t num_voxels, const float *g_out, float loss_scale, float *dW1,
+                                 float *dWh, float *dbias, float *dwout, float *dbout, void *stream);
 /* torch.optim.Adam update (amsgrad off, weight_decay 0) of one fp32 parameter tensor, in place; step counts from 1 */
 int vfem_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float lr, float beta1,
                    float beta2, float eps, int step, void *stream);

@@ -75,6 +75,8 @@ SIGNATURES = {
     "vfem_mlp_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vfem_mlp_backward_grid": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double), c_void_p, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vfem_mlp_backward_grid_range": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double), c_int64, c_int64, c_void_p,
+                                             c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vfem_adam_step": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int, c_void_p]),
     "vfem_gsim_create": (c_int, [POINTER(c_void_p), c_int, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
     "vfem_gsim_destroy": (c_int, [c_void_p]),

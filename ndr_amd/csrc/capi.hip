@@ -1009,7 +1009,7 @@ static void mlp_backward_impl(vfem_mlp *m, vfem::MlpArgs base, const float *coor
         const float beta = c0 == 0 ? 0.f : 1.f;
         if (rows != n_c) { m->acts.zero(s); m->feats.zero(s); }       // padded rows must be finite (they meet dz = 0)
         vfem::MlpArgs a = base;
-        a.nvox = n_c; a.v_offset = c0; a.coords = coords ? coords + 3 * c0 : nullptr;
+        a.nvox = n_c; a.v_offset = base.v_offset + c0; a.coords = coords ? coords + 3 * c0 : nullptr;
         a.out32 = m->out_chunk.p; a.out64 = nullptr; a.save_act = m->acts.p; a.act_rows = rows;
         launch_mlp_forward(a, s);
         vfem::MlpBwdArgs b{};
@@ -1051,6 +1051,17 @@ int vfem_mlp_backward_grid(vfem_mlp *m, const int64_t n[3], const double lo[3], 
         a.gstep[dd] = n[dd] > 1 ? (float) ((hi[dd] - lo[dd]) / (double) (n[dd] - 1)) : 0.f;
         a.nvox *= n[dd];
     }
+    mlp_backward_impl(m, a, nullptr, g_out, loss_scale, dW1, dWh, dbias, dwout, dbout, S(stream));
+    VFEM_CATCH
+}
+int vfem_mlp_backward_grid_range(vfem_mlp *m, const int64_t n[3], const double lo[3], const double hi[3], int64_t first_voxel,
+                                 int64_t num_voxels, const float *g_out, float loss_scale, float *dW1, float *dWh, float *dbias,
+                                 float *dwout, float *dbout, void *stream) {
+    VFEM_TRY
+    MlpArgs a = mlp_base_args(m);
+    mlp_grid_args(a, n, lo, hi);
+    if (first_voxel < 0 || num_voxels <= 0 || first_voxel + num_voxels > a.nvox) throw Error("voxel range outside the grid");
+    a.v_offset = first_voxel; a.nvox = num_voxels;
     mlp_backward_impl(m, a, nullptr, g_out, loss_scale, dW1, dWh, dbias, dwout, dbout, S(stream));
     VFEM_CATCH
 }

@@ -137,6 +137,22 @@ class MLP:
         _lib.check(self._lib.vfem_mlp_backward_grid(self._h, n, lo, hi, _ptr(g), sc, *[_ptr(b) for b in bufs], _stream()))
         return self._unpack(bufs)
 
+    def backward_grid_range(self, sidelen, first_voxel, num_voxels, g_out, domain=None, loss_scale=None):
+        """partial parameter gradients from the voxels [first_voxel, first_voxel + num_voxels) (g_out indexed from the
+        start of the range); summed over the ranks of a slab decomposition they are the whole-grid gradients"""
+        n = (ctypes.c_int64 * 3)(*[int(s) for s in sidelen])
+        dom = domain if domain is not None else [[0.0, 1.0]] * 3
+        lo = (ctypes.c_double * 3)(*[float(d[0]) for d in dom])
+        hi = (ctypes.c_double * 3)(*[float(d[1]) for d in dom])
+        g = torch.as_tensor(g_out, dtype=torch.float32, device=_dev()).contiguous().reshape(-1)
+        if g.numel() != int(num_voxels):
+            raise RuntimeError("g_out must hold one value per voxel of the range")
+        bufs = self._grad_buffers()
+        sc = self._auto_scale(g) if loss_scale is None else float(loss_scale)
+        _lib.check(self._lib.vfem_mlp_backward_grid_range(self._h, n, lo, hi, int(first_voxel), int(num_voxels), _ptr(g), sc,
+                                                          *[_ptr(b) for b in bufs], _stream()))
+        return self._unpack(bufs)
+
     def forward(self, coords):
         """coords [..., 3] float32 -> densities [..., 1] float32 (torch CUDA tensors)"""
         c = torch.as_tensor(coords, dtype=torch.float32, device=_dev()).contiguous()
@@ -168,15 +184,22 @@ class _GridDensity(torch.autograd.Function):
     def forward(ctx, module, *params):
         module._sync()
         ctx.module = module
-        return module.kernel.forward_grid(module.sidelen, module.domain).reshape(-1)
+        if module.voxel_range is None:
+            return module.kernel.forward_grid(module.sidelen, module.domain).reshape(-1)
+        return module.kernel.forward_grid_range(module.sidelen, module.voxel_range[0], module.voxel_range[1], module.domain)
 
     @staticmethod
     def backward(ctx, grad_out):
         mod = ctx.module
-        gw, gb = mod.kernel.backward_grid(mod.sidelen, grad_out, mod.domain)
+        if mod.voxel_range is None:
+            gw, gb = mod.kernel.backward_grid(mod.sidelen, grad_out, mod.domain)
+        else:
+            gw, gb = mod.kernel.backward_grid_range(mod.sidelen, mod.voxel_range[0], mod.voxel_range[1], grad_out, mod.domain)
         grads = []
         for w, b in zip(gw, gb):
             grads += [w, b.reshape(-1)]
+        if mod.voxel_range is not None and mod.reduce_gradients:
+            grads = mod._all_reduce(grads)       # every rank holds a slab of the field and the same weights
         return (None,) + tuple(grads)
 
 
@@ -209,7 +232,8 @@ class TrainableMLP(torch.nn.Module):
                 torch.nn.init.orthogonal_(m.weight, gain=gain)
                 torch.nn.init.constant_(m.bias, 0.0)
         self.to(_dev())
-        self.sidelen, self.domain = None, None
+        self.sidelen, self.domain, self.voxel_range = None, None, None
+        self.reduce_gradients = True
         self._adam_state, self._adam_t = None, 0
 
     def _linears(self):
@@ -219,8 +243,29 @@ class TrainableMLP(torch.nn.Module):
         lin = self._linears()
         self.kernel.load_tensors(self.B, [m.weight for m in lin], [m.bias for m in lin])
 
-    def set_grid(self, sidelen, domain=None):
+    def set_grid(self, sidelen, domain=None, voxel_range=None):
+        """voxel_range = (first_voxel, num_voxels): this rank evaluates (and differentiates through) only that contiguous part
+        of the grid -- the x-planes of its slab; parameter gradients are then summed over the process group"""
         self.sidelen, self.domain = tuple(int(s) for s in sidelen), domain
+        self.voxel_range = None if voxel_range is None else (int(voxel_range[0]), int(voxel_range[1]))
+
+    @staticmethod
+    def _all_reduce(grads):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return grads
+        flat = torch.cat([g.reshape(-1) for g in grads])          # one all-reduce of the 1.57 M gradients
+        if dist.get_backend() == "gloo":
+            h = flat.cpu()
+            dist.all_reduce(h)
+            flat = h.to(flat.device)
+        else:
+            dist.all_reduce(flat)
+        out, o = [], 0
+        for g in grads:
+            out.append(flat[o:o + g.numel()].reshape(g.shape))
+            o += g.numel()
+        return out
 
     def forward_grid(self):
         if self.sidelen is None:

@@ -108,3 +108,52 @@ def test_distributed_pcg_matches_single_process(world, ne, levels):
         assert it_d == it_s, (it_d, it_s)
         assert abs(comp - cg) < 1e-9 * abs(cg), (comp, cg)
         assert err < 1e-7, err
+
+
+def _mlp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from ndr_amd.mlp import TrainableMLP
+    side = (24, 10, 12)
+    plane = side[1] * side[2]
+    torch.manual_seed(5)                                   # same initial weights and B on every rank
+    net = TrainableMLP(3, 1, 64, 4, 64, 2.0)
+    x0, x1 = rank * side[0] // world, (rank + 1) * side[0] // world
+    tgt = torch.linspace(0, 1, side[0] * plane, device="cuda")
+    # sharded: every rank differentiates through its planes only, gradients are summed over the group
+    net.set_grid(side, voxel_range=(x0 * plane, (x1 - x0) * plane))
+    net.zero_grad()
+    rho = net.forward_grid()
+    loss = ((rho - tgt[x0 * plane:x1 * plane]) ** 2).sum()
+    loss.backward()
+    sharded = [p.grad.clone() for p in net.parameters()]
+    # the same step on the whole grid in this process
+    net.set_grid(side)
+    net.zero_grad()
+    rho_full = net.forward_grid()
+    ((rho_full - tgt) ** 2).sum().backward()
+    full = [p.grad.clone() for p in net.parameters()]
+    err = max(float((a - b).norm() / b.norm()) for a, b in zip(sharded, full))
+    same = bool(torch.equal(rho.detach(), rho_full.detach()[x0 * plane:x1 * plane]))
+    q.put((rank, err, same))
+    dist.destroy_process_group()
+
+
+def test_mlp_training_step_sharded_over_ranks_equals_whole_grid():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_mlp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, same in res:
+        assert same, rank
+        assert err < 5e-3, (rank, err)       # fp16 operands: chunk boundaries differ between the two evaluations
