@@ -626,3 +626,16 @@ class DistributedMGSolver:
 
     def compliance(self, f, u):
         return 0.5 * self.dot(f, u)
+
+    def compliance_gradient(self, u):
+        """sensitivity d(1/2 f.u)/d(rho_e) (TPS::complianceGradient, TPS.hh:730-751) for the element layers this rank owns,
+        flat [owned_layers * ny * nz]; element-local, so after one halo refresh of u no further communication"""
+        self.halo(0, u)
+        g0 = self.geom[0]
+        g = self.lsim.complianceGradient_device(u).view(g0.nx, -1)
+        return g[g0.gl:g0.gl + (self.part.x1 - self.part.x0)].reshape(-1)
+
+    def owned_element_range(self):
+        """(first, count) of this rank's elements in the global flat element order (x-layers are contiguous)"""
+        layer = self.ne[1] * self.ne[2]
+        return self.part.x0 * layer, (self.part.x1 - self.part.x0) * layer

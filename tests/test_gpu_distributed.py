@@ -86,6 +86,12 @@ def _pcg_worker(rank, world, port, ne, levels, q):
     mine = u.view(g.n_planes, -1)[g.first_owned:g.last_owned + 1]
     want = ug.view(ne[0] + 1, -1)[ds.part.x0:ds.part.x1 + 1]
     err = float((mine - want).abs().max() / want.abs().max())
+    # sensitivity of the owned element layers against the single-process sensitivity
+    first, count = ds.owned_element_range()
+    gd = ds.compliance_gradient(u)
+    gs = t.complianceGradient_device(ug)[first:first + count]
+    gerr = float((gd - gs).abs().max() / gs.abs().max())
+    err = max(err, gerr)
     q.put((rank, ds.Ld, ds.last_iterations, mg.last_iterations, comp, cg, err))
     dist.destroy_process_group()
 
