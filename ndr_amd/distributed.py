@@ -639,3 +639,76 @@ class DistributedMGSolver:
         """(first, count) of this rank's elements in the global flat element order (x-layers are contiguous)"""
         layer = self.ne[1] * self.ne[2]
         return self.part.x0 * layer, (self.part.x1 - self.part.x0) * layer
+
+
+# ==============================================================================================
+# One evaluation of the train_xdg closure (training/train_xdg.py:282-329) over the slab ranks:
+#   MLP logits of the rank's planes -> constrained sigmoid (mean over the WHOLE field) -> compliance by the distributed
+#   MG-PCG -> sensitivities of the owned elements -> MLP backward on the rank's planes -> one all-reduce of the gradients.
+# The density field crosses ranks once per evaluation (all-gather: the slab solver builds its replicated coarse
+# hierarchy from the whole field); displacements, sensitivities and activations never do.
+# ==============================================================================================
+class _ShardedCompliance(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, density_local, trainer):
+        ds = trainer.solver
+        parts = trainer._gather(density_local.detach().to(torch.float64))
+        ds.set_global_densities(parts)
+        f = ds.local_loads()
+        if trainer._u is None or trainer.zero_init:
+            trainer._u = torch.zeros_like(f)
+        trainer._u = ds.pcg(trainer._u, f, trainer.cg_iter, trainer.tol, 1, 2, True)
+        # as in the reference's autograd node the value is 2 J but the gradient is that of J (fem.py:122-126)
+        ctx.save_for_backward(ds.compliance_gradient(trainer._u).to(torch.float32))
+        return density_local.new_tensor(2.0 * ds.compliance(f, trainer._u))
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (g,) = ctx.saved_tensors
+        return g * grad_output, None
+
+
+class DistributedDensityTrainer:
+    """density = constrained_sigmoid(mlp(grid)) sharded by x-planes; loss = compliance of the distributed solve"""
+
+    def __init__(self, solver, net, max_volume, tol=1e-4, cg_iter=100, zero_init=False):
+        self.solver, self.net, self.max_volume = solver, net, float(max_volume)
+        self.tol, self.cg_iter, self.zero_init = tol, cg_iter, zero_init
+        self.first, self.count = solver.owned_element_range()
+        net.set_grid(solver.ne, voxel_range=(self.first, self.count))
+        self._u = None
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+
+    def _reduce(self, t, op):
+        if self.world == 1:
+            return t
+        if dist.get_backend() == "gloo":
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=op)
+            return h.to(t.device)
+        t = t.detach().clone()
+        dist.all_reduce(t, op=op)
+        return t
+
+    def _gather(self, local):
+        if self.world == 1:
+            return local
+        counts = [None] * self.world
+        dist.all_gather_object(counts, int(local.numel()))
+        m = max(counts)                                   # equal-size buffers (slabs differ by at most one aligned block)
+        gloo = dist.get_backend() == "gloo"
+        mine = torch.zeros(m, dtype=local.dtype, device="cpu" if gloo else local.device)
+        mine[:local.numel()] = local.cpu() if gloo else local
+        bufs = [torch.empty_like(mine) for _ in counts]
+        dist.all_gather(bufs, mine)
+        return torch.cat([b[:c] for b, c in zip(bufs, counts)]).to(local.device)
+
+    def loss(self):
+        """compliance (2 J) of the constrained density predicted by the network; call .backward() on it"""
+        from . import fem
+        logits = self.net.forward_grid()
+        density = fem.sigmoid_with_constrained_mean(
+            logits, torch.tensor(self.max_volume, device=logits.device),
+            allsum=lambda t: self._reduce(t, dist.ReduceOp.SUM), allmax=lambda t: self._reduce(t, dist.ReduceOp.MAX))
+        self.last_density = density.detach()
+        return _ShardedCompliance.apply(density, self)

@@ -148,28 +148,35 @@ class _ShiftToMean(autograd.Function):
     bracket, fem.FindRootFunction); backward uses db/dx_i = -(df/dx_i) / (df/db)."""
 
     @staticmethod
-    def forward(ctx, x, average, lower, upper, projection, dprojection):
+    def forward(ctx, x, average, lower, upper, projection, dprojection, allsum=None):
+        # allsum(t): sum of a small tensor over the ranks that hold the other parts of x (None: x is the whole field)
         lo, hi = float(lower), float(upper)
         avg = float(average)
+        red = (lambda t: t) if allsum is None else allsum
         with torch.no_grad():
+            n = float(red(x.new_tensor([float(x.numel())]))[0])
             step = 0
             while step < 128 and hi - lo >= 1e-12:
                 mid = 0.5 * (lo + hi)
-                if float(projection(x + mid).mean()) - avg > 0:
+                if float(red(projection(x + mid).sum().reshape(1))[0]) / n - avg > 0:
                     hi = mid
                 else:
                     lo = mid
                 step += 1
             b = 0.5 * (lo + hi)
             d = dprojection(x + b)
+            dmean = float(red(d.sum().reshape(1))[0]) / n
         ctx.save_for_backward(d)
+        ctx.n, ctx.dmean, ctx.red = n, dmean, red
         return x.new_tensor(b)
 
     @staticmethod
     def backward(ctx, grad_output):
         (d,) = ctx.saved_tensors
-        # f = mean(P(x + b)) - avg:  df/dx_i = P'(x_i + b) / n,  df/db = mean P'
-        return -(d / d.numel()) / d.mean() * grad_output, None, None, None, None, None
+        # f = mean(P(x + b)) - avg:  df/dx_i = P'(x_i + b) / n,  df/db = mean P'; b is shared by all parts of x, so the
+        # incoming gradient (dL/db) is the sum over the ranks
+        g = ctx.red(grad_output.reshape(1).clone())[0]
+        return -(d / ctx.n) / ctx.dmean * g, None, None, None, None, None, None
 
 
 def logit(p):
@@ -177,14 +184,18 @@ def logit(p):
     return torch.log(p) - torch.log1p(-p)
 
 
-def _with_constrained_mean(x, average, projection, dprojection):
+def _with_constrained_mean(x, average, projection, dprojection, allsum=None, allmax=None):
     lg = logit(average).to(x.device)
-    b = _ShiftToMean.apply(x, average, lg - x.max(), lg - x.min(), projection, dprojection)
+    xmax, xmin = x.max().detach().reshape(1), (-x.min()).detach().reshape(1)
+    if allmax is not None:
+        xmax, xmin = allmax(xmax), allmax(xmin)
+    b = _ShiftToMean.apply(x, average, lg - xmax[0], lg + xmin[0], projection, dprojection, allsum)
     return projection(x + b)
 
 
-def sigmoid_with_constrained_mean(x, average, projection=torch.sigmoid):
-    """fem.sigmoid_with_constrained_mean (fem.py:213-229)"""
+def sigmoid_with_constrained_mean(x, average, projection=torch.sigmoid, allsum=None, allmax=None):
+    """fem.sigmoid_with_constrained_mean (fem.py:213-229); `allsum` / `allmax` reduce a small tensor over the ranks when x is
+    one rank's part of a sharded field (the mean constraint is on the whole field)"""
     if projection is torch.sigmoid:
         dproj = lambda t: torch.sigmoid(t) * (1 - torch.sigmoid(t))
     else:
@@ -192,7 +203,7 @@ def sigmoid_with_constrained_mean(x, average, projection=torch.sigmoid):
             t = t.detach().requires_grad_(True)
             with torch.enable_grad():
                 return autograd.grad(projection(t).sum(), t)[0]
-    return _with_constrained_mean(x, average, projection, dproj)
+    return _with_constrained_mean(x, average, projection, dproj, allsum, allmax)
 
 
 def physical_density(x, maxVolume):

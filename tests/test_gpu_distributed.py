@@ -163,3 +163,64 @@ def test_mlp_training_step_sharded_over_ranks_equals_whole_grid():
     for rank, err, same in res:
         assert same, rank
         assert err < 5e-3, (rank, err)       # fp16 operands: chunk boundaries differ between the two evaluations
+
+
+def _trainer_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from helpers import BC_CANTILEVER, MATERIAL
+    from ndr_amd import distributed as vd, fem, pyVoxelFEM
+    from ndr_amd.mlp import TrainableMLP
+    grid, dom, v0, levels = (32, 16, 16), ([0.0, 0.0, 0.0], [2.0, 1.0, 1.0]), 0.5, 2
+    torch.manual_seed(7)
+    net = TrainableMLP(3, 1, 64, 4, 64, 1.5)
+    with torch.no_grad():                                     # a non-trivial field: scale the output layer up
+        net._linears()[-1].weight.mul_(3.0)
+    # sharded evaluation of the closure
+    ds = vd.DistributedMGSolver(grid, dom[0], dom[1], BC_CANTILEVER, MATERIAL, levels)
+    tr = vd.DistributedDensityTrainer(ds, net, v0, tol=1e-9, zero_init=True)
+    net.zero_grad()
+    loss_d = tr.loss()
+    loss_d.backward()
+    gd = [p.grad.clone() for p in net.parameters()]
+    vol = float(tr._reduce(tr.last_density.sum().reshape(1), dist.ReduceOp.SUM)[0]) / (grid[0] * grid[1] * grid[2])
+    # the same closure in this process alone (fem.satisfy_volume_constraint + VoxelFEMFunction)
+    tps = fem.initializeTensorProductSimulator([1, 1, 1], [np.array(dom[0]), np.array(dom[1])], list(grid), v0, 1, 1e-4, 3, MATERIAL, BC_CANTILEVER)
+    obj = pyVoxelFEM.MultigridComplianceObjective(tps.multigridSolver(levels))
+    obj.tol, obj.mgIterations, obj.fullMultigrid, obj.zeroInit, obj.mgSmoothingIterations = 1e-9, 1, True, True, 2
+    top = pyVoxelFEM.TopologyOptimizationProblem(tps, obj, [pyVoxelFEM.TotalVolumeConstraint(v0)], [])
+    net.set_grid(grid)
+    net.zero_grad()
+    density = fem.satisfy_volume_constraint(net.forward_grid().view(grid), torch.tensor(v0, device="cuda"), mode="constrained_sigmoid")
+    loss_s = fem.VoxelFEMFunction.apply(density.flatten(), top)
+    loss_s.backward()
+    gs = [p.grad.clone() for p in net.parameters()]
+    # one norm over all parameters: the output bias has a vanishing gradient under the mean constraint (a constant added to
+    # every logit is absorbed by the shift), so its own relative error is noise over noise
+    fa, fb = torch.cat([g.reshape(-1) for g in gd]), torch.cat([g.reshape(-1) for g in gs])
+    gerr = float((fa - fb).norm() / fb.norm())
+    q.put((rank, float(loss_d.detach()), float(loss_s.detach()), vol, gerr))
+    dist.destroy_process_group()
+
+
+def test_distributed_closure_equals_single_process_closure():
+    """train_xdg closure over 2 slab ranks: loss (2 J), volume and parameter gradients equal the single-process evaluation"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ld, ls, vol, gerr in res:
+        assert abs(vol - 0.5) < 1e-6, vol
+        assert abs(ld - ls) < 2e-5 * abs(ls), (ld, ls)          # float32 loss value of the autograd node
+        assert gerr < 1e-2, gerr
