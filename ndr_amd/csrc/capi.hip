@@ -19,7 +19,7 @@
 
 namespace vfem {
 
-extern int g_apply_pd, g_apply_skeleton, g_gs_variant, g_apply_store;
+extern int g_apply_pd, g_apply_skeleton, g_gs_variant, g_apply_store, g_dma_chunks;
 }
 extern int g_q2_impl;
 namespace vfem {
@@ -318,6 +318,7 @@ int vfem_debug_set(int key, int value) {
     else if (key == 3) vfem::g_apply_store = value;
     else if (key == 4) vfem::g_apply_impl = value;
     else if (key == 6) g_q2_impl = value;
+    else if (key == 7) vfem::g_dma_chunks = value;
     else return 1;
     return 0;
 }

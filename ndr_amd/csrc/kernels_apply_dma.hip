@@ -36,6 +36,8 @@ constexpr size_t LDS_BYTES = (size_t) RING * SLOT_BYTES + 2 * SS_DOUBLES * sizeo
 
 struct DmArgs2 { double v[36]; };
 
+int g_dma_chunks = 0;        // vfem_debug_set(7, n): number of x-chunks of the marching blocks (0 = default)
+
 __device__ __forceinline__ void glds16(const void *g, void *l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) g,
                                      (__attribute__((address_space(3))) void *) l, 16, 0, 0);
@@ -395,6 +397,7 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
     for (int q = 0; q < 36; ++q) dm.v[q] = Dm_host[q];
     int nchunks = np >= 64 ? 8 : (np >= 16 ? 4 : 1);
     if (np >= 1024) nchunks = 16;
+    if (g_dma_chunks > 0 && np >= 4 * g_dma_chunks) nchunks = g_dma_chunks;
     const int ppc = (np + nchunks - 1) / nchunks;
     dim3 blk(TZ, TY, 1), grd((np + ppc - 1) / ppc, (d.NZ + TZ - 2) / (TZ - 1), (d.NY + TY - 2) / (TY - 1));
     static bool attr = false;
