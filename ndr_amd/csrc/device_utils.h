@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 #include <type_traits>
 #include <utility>
 
@@ -44,6 +46,26 @@ __device__ __forceinline__ void sload12(const double *p, int byte_off, d8_t &a, 
 __device__ __forceinline__ void sload24(const double *p, int byte_off, d8_t &a, d8_t &b, d8_t &c) {
     asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %5\n\ts_load_dwordx16 %2, %3, %6\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(a), "=&s"(b), "=&s"(c) : "s"(p), "s"(byte_off), "s"(byte_off + 64), "s"(byte_off + 128));
+}
+
+
+// component-sequential 3x3 solve of m_smoothNode (MG.hh:254-264)
+__device__ __forceinline__ void gs_solve(const double bms[3], const double M[9], uint8_t mask, bool forward,
+                                         double ud[3]) {
+    ud[0] = ud[1] = ud[2] = 0.0;
+    if (forward) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double t = bms[i] - (M[i * 3 + 0] * ud[0] + M[i * 3 + 1] * ud[1] + M[i * 3 + 2] * ud[2]);
+            ud[i] = t * (((mask >> i) & 1) ? 0.0 : 1.0 / M[i * 3 + i]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 2; i >= 0; --i) {
+            const double t = bms[i] - (M[i * 3 + 0] * ud[0] + M[i * 3 + 1] * ud[1] + M[i * 3 + 2] * ud[2]);
+            ud[i] = t * (((mask >> i) & 1) ? 0.0 : 1.0 / M[i * 3 + i]);
+        }
+    }
 }
 
 

@@ -488,6 +488,12 @@ static void level_op(const vfem_gmg *mg, int l, const double *&K, long long &kst
 }
 
 static void gmg_apply(vfem_gmg *mg, int l, const double *u, const double *b, int mode, double *out, hipStream_t s) {
+    const vfem_gsim *sim = mg->fine;
+    if (l == 0 && sim->d.N == 3 && sim->d.p == 2 && sim->q2_fast && g_q2_impl == 0) {       // finest degree-2 level: pencil kernel
+        launch_apply_q2_pencil(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E.p, u, out, s);
+        if (mode != 0) launch_q2_residual_fix(sim->d.nnodes, b, mg->lv[0].mask.p, mode, out, s);
+        return;
+    }
     const double *K, *scale; long long ks;
     level_op(mg, l, K, ks, scale);
     g_apply(mg->lv[l].d, K, ks, scale, u, b, mg->lv[l].mask.p, mode, out, s);
@@ -495,6 +501,10 @@ static void gmg_apply(vfem_gmg *mg, int l, const double *u, const double *b, int
 
 static void gmg_smooth(vfem_gmg *mg, int l, double *u, const double *b, int forward, hipStream_t s) {
     const GDims &d = mg->lv[l].d;
+    if (l == 0 && d.N == 3 && d.p == 2 && g_q2_impl == 0) {                                  // finest degree-2 level: thread per node
+        launch_gs_sweep_q2_level0(d.ne[0], d.ne[1], d.ne[2], mg->fine->dK0.p, mg->fine->E.p, u, b, mg->lv[0].mask.p, forward, s);
+        return;
+    }
     const double *K, *scale; long long ks;
     level_op(mg, l, K, ks, scale);
     int ncol = 1;

@@ -95,25 +95,6 @@ __device__ __forceinline__ void mf_node(const Dims &d, const double *__restrict_
 
 int g_gs_variant = 0;   // 0: row-streaming level-0 sweep, 1: plain gather sweep (cross-check)
 
-// component-sequential 3x3 solve of m_smoothNode (MG.hh:254-264)
-__device__ __forceinline__ void gs_solve(const double bms[3], const double M[9], uint8_t mask, bool forward,
-                                         double ud[3]) {
-    ud[0] = ud[1] = ud[2] = 0.0;
-    if (forward) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const double t = bms[i] - (M[i * 3 + 0] * ud[0] + M[i * 3 + 1] * ud[1] + M[i * 3 + 2] * ud[2]);
-            ud[i] = t * (((mask >> i) & 1) ? 0.0 : 1.0 / M[i * 3 + i]);
-        }
-    } else {
-#pragma unroll
-        for (int i = 2; i >= 0; --i) {
-            const double t = bms[i] - (M[i * 3 + 0] * ud[0] + M[i * 3 + 1] * ud[1] + M[i * 3 + 2] * ud[2]);
-            ud[i] = t * (((mask >> i) & 1) ? 0.0 : 1.0 / M[i * 3 + i]);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // apply / residual, matrix-free gather form
 // ------------------------------------------------------------------------------------------

@@ -273,6 +273,106 @@ void launch_apply_q2_pencil(int nx, int ny, int nz, const double *tab, const dou
     VFEM_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------------
+// One colour of the 27-colour block Gauss-Seidel sweep on the finest degree-2 level (MG.hh:193-340 with Degrees = 2,2,2):
+// one thread per node of the colour (colour = local node index; per axis nodes start at the local index and advance by one
+// element for the mid node, by two for a boundary node).  All nodes of a colour have the same local index in each of their
+// incident elements, so the rows of K0 are wave-uniform.
+// ------------------------------------------------------------------------------------------------------
+struct Q2Color { int start[3], inc[3], cnt[3]; };
+
+__global__ void __launch_bounds__(256) k_gs_q2_level0(DimsQ2 d, Q2Color col, const double *__restrict__ K0, const double *__restrict__ E,
+                                                      double *__restrict__ u, const double *__restrict__ b,
+                                                      const uint8_t *__restrict__ mask, int forward) {
+    const int c = blockIdx.x * 64 + threadIdx.x, bq = blockIdx.y * 4 + threadIdx.y, a = blockIdx.z;
+    if (c >= col.cnt[2] || bq >= col.cnt[1] || a >= col.cnt[0]) return;
+    const int i = col.start[0] + a * col.inc[0], j = col.start[1] + bq * col.inc[1], k = col.start[2] + c * col.inc[2];
+    const int px = i & 1, py = j & 1, pz = k & 1;                 // wave-uniform (colour property)
+    const int nex = px ? 1 : 2, ney = py ? 1 : 2, nez = pz ? 1 : 2;
+    double S[3] = {0.0, 0.0, 0.0}, M[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) M[q] = 0.0;
+    for (int sx = 0; sx < nex; ++sx) {
+        const int ex = px ? i / 2 : i / 2 - 1 + sx, lx = px ? 1 : (sx ? 0 : 2);
+        if (ex < 0 || ex >= d.nx) continue;
+        for (int sy = 0; sy < ney; ++sy) {
+            const int ey = py ? j / 2 : j / 2 - 1 + sy, ly = py ? 1 : (sy ? 0 : 2);
+            if (ey < 0 || ey >= d.ny) continue;
+            for (int sz = 0; sz < nez; ++sz) {
+                const int ez = pz ? k / 2 : k / 2 - 1 + sz, lz = pz ? 1 : (sz ? 0 : 2);
+                if (ez < 0 || ez >= d.nz) continue;
+                const int ln = 9 * lx + 3 * ly + lz;
+                const double Ee = E[((long long) ex * d.ny + ey) * d.nz + ez];
+                const double *r0 = K0 + (3 * ln) * 81, *r1 = r0 + 81, *r2 = r1 + 81;
+                double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+                for (int ma = 0; ma < 3; ++ma)
+                    for (int mb = 0; mb < 3; ++mb) {
+                        const long long rowbase = ((long long) (2 * ex + ma) * d.NY + (2 * ey + mb)) * d.NZ + 2 * ez;
+#pragma unroll
+                        for (int mc = 0; mc < 3; ++mc) {
+                            const int m = 9 * ma + 3 * mb + mc;
+                            const double *um = u + 3 * (rowbase + mc);
+                            const double u0 = um[0], u1 = um[1], u2 = um[2];
+                            t0 = fma(r0[3 * m], u0, fma(r0[3 * m + 1], u1, fma(r0[3 * m + 2], u2, t0)));
+                            t1 = fma(r1[3 * m], u0, fma(r1[3 * m + 1], u1, fma(r1[3 * m + 2], u2, t1)));
+                            t2 = fma(r2[3 * m], u0, fma(r2[3 * m + 1], u1, fma(r2[3 * m + 2], u2, t2)));
+                        }
+                    }
+                S[0] = fma(Ee, t0, S[0]); S[1] = fma(Ee, t1, S[1]); S[2] = fma(Ee, t2, S[2]);
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    M[cc] = fma(Ee, r0[3 * ln + cc], M[cc]);
+                    M[3 + cc] = fma(Ee, r1[3 * ln + cc], M[3 + cc]);
+                    M[6 + cc] = fma(Ee, r2[3 * ln + cc], M[6 + cc]);
+                }
+            }
+        }
+    }
+    const long long n = ((long long) i * d.NY + j) * d.NZ + k;
+    double bms[3], ud[3];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) bms[cc] = b[3 * n + cc] - S[cc];
+    gs_solve(bms, M, mask ? mask[n] : (uint8_t) 0, forward != 0, ud);
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) u[3 * n + cc] += ud[cc];
+}
+
+void launch_gs_sweep_q2_level0(int nx, int ny, int nz, const double *K0, const double *E, double *u, const double *b,
+                               const uint8_t *mask, int forward, hipStream_t s) {
+    DimsQ2 d{nx, ny, nz, 2 * nx + 1, 2 * ny + 1, 2 * nz + 1};
+    const int NN[3] = {d.NX, d.NY, d.NZ};
+    for (int ci = 0; ci < 27; ++ci) {
+        const int lni = forward ? ci : 26 - ci;                      // MG.hh:293-295
+        const int l[3] = {lni / 9, (lni / 3) % 3, lni % 3};
+        Q2Color col;
+        bool empty = false;
+        for (int a = 0; a < 3; ++a) {
+            col.start[a] = l[a];
+            col.inc[a] = (l[a] == 1) ? 2 : 4;                        // MG.hh:301-305: (1 + isBoundary) * degree
+            col.cnt[a] = l[a] > NN[a] - 1 ? 0 : (NN[a] - 1 - l[a]) / col.inc[a] + 1;
+            empty = empty || col.cnt[a] == 0;
+        }
+        if (empty) continue;
+        k_gs_q2_level0<<<dim3((col.cnt[2] + 63) / 64, (col.cnt[1] + 3) / 4, col.cnt[0]), dim3(64, 4, 1), 0, s>>>(d, col, K0, E, u, b, mask, forward);
+    }
+    VFEM_HIP(hipGetLastError());
+}
+
+// r = zeroDirichlet(b - Ku) (mode 1) or zeroDirichlet(Ku) (mode 2) in place on Ku
+__global__ void __launch_bounds__(256) k_q2_residual_fix(long long nn, const double *__restrict__ b, const uint8_t *__restrict__ mask, int mode,
+                                                         double *__restrict__ out) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * nn) return;
+    double v = out[i];
+    if (mode == 1) v = b[i] - v;
+    if (mask && ((mask[i / 3] >> (i % 3)) & 1)) v = 0.0;
+    out[i] = v;
+}
+void launch_q2_residual_fix(long long nn, const double *b, const uint8_t *mask, int mode, double *out, hipStream_t s) {
+    k_q2_residual_fix<<<dim3((unsigned) ((3 * nn + 255) / 256)), dim3(256), 0, s>>>(nn, b, mask, mode, out);
+    VFEM_HIP(hipGetLastError());
+}
+
 // g_e = -1/2 gamma rho^(gamma-1) (E0 - Emin) u_e^T K0 u_e, one wave per element (81 dofs over 64 lanes)
 __global__ void __launch_bounds__(256) k_gradient_q2(DimsQ2 d, const double *__restrict__ K0, const double *__restrict__ rho,
                                                      double E0, double Emin, double gamma, const double *__restrict__ u,
