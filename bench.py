@@ -167,6 +167,29 @@ def degree2_rate(ne=(512, 512, 512), reps=3):
             "note": "pencil kernel: reflection-mode blocks (855 of 6561 multiply-adds), 4 colour launches, 1104 B/voxel moved"}
 
 
+def degree2_pcg_rate(n=128, levels=5):
+    """CG-MG iterations/s of the degree-2 (27-node) discretisation, cantilever, reference solver settings"""
+    from helpers import BC_CANTILEVER, MATERIAL
+    from ndr_amd import pyVoxelFEM as pv
+    t = pv.TensorProductSimulator([2, 2, 2], ([0, 0, 0], [2, 1, 1]), [n, n, n])
+    t.readMaterial(MATERIAL)
+    t.applyDisplacementsAndLoadsFromFile(BC_CANTILEVER)
+    t.E_min = 1e-4
+    g = torch.Generator(device="cuda").manual_seed(88)
+    t.setElementDensities(torch.rand(t.numElements(), dtype=torch.float64, device="cuda", generator=g))
+    mg = t.multigridSolver(levels)
+    f = t.buildLoadVector_device()
+    mg.preconditionedConjugateGradient_device(torch.zeros_like(f), f, 1, 1e-4, None, 1, 2, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    u = mg.preconditionedConjugateGradient_device(torch.zeros_like(f), f, 100, 1e-4, None, 1, 2, True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"grid": "%dx%dx%d" % (n, n, n), "nodes": t.numNodes(), "levels": levels, "iterations": mg.last_iterations, "seconds": dt,
+            "iterations_per_s": mg.last_iterations / dt, "relative_residual": mg.last_relative_residual,
+            "compliance": float((f * u).sum())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,6 +277,10 @@ def main():
             result["mlp_forward"] = mlp_rate()
         except RuntimeError as e:
             result["mlp_forward"] = {"error": str(e)}
+        try:
+            result["degree2_cg_mg"] = degree2_pcg_rate()
+        except RuntimeError as e:
+            result["degree2_cg_mg"] = {"error": str(e)}
         result["degree2_spmv"] = []
         for q2ne in ((256, 256, 256), (512, 512, 512)):
             torch.cuda.empty_cache()

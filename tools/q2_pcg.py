@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import BC_CANTILEVER, MATERIAL
 from ndr_amd import pyVoxelFEM as pv
-for n, levels in ((64, 4), (128, 5)):
+for n, levels in [(int(sys.argv[1]), int(sys.argv[2]))] if len(sys.argv) > 2 else ((64, 4), (128, 5)):
     t = pv.TensorProductSimulator([2, 2, 2], ([0, 0, 0], [2, 1, 1]), [n, n, n])
     t.readMaterial(MATERIAL); t.applyDisplacementsAndLoadsFromFile(BC_CANTILEVER); t.E_min = 1e-4
     g = torch.Generator(device="cuda").manual_seed(88)
