@@ -218,13 +218,13 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
 
     // staged doubles q = lane + 64 s; loads are unconditional with the offset clamped into the row: values
     // outside the grid only ever meet elements outside the grid, whose modulus is 0
-    int qc[7];
+    unsigned qc[7];                                     // byte offsets: scalar row base + 32-bit lane offset addressing
 #pragma unroll
     for (int s7 = 0; s7 < 7; ++s7) {
         int q = lane + 64 * s7;
         const int lo = -3 * zlo > 0 ? -3 * zlo : 0, hi = 3 * (d.NZ - zlo) - 1;
         q = q < lo ? lo : (q > hi ? hi : q);
-        qc[s7] = q;
+        qc[s7] = 8u * (unsigned) q;
     }
 
     double T[8][3];
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
         const int hi = __builtin_amdgcn_readfirstlane((int) (ro >> 32));
         const double *rowp = u + (((long long) hi << 32) | (long long) lo);
 #pragma unroll
-        for (int s7 = 0; s7 < 7; ++s7) pre[s7] = rowp[qc[s7]];
+        for (int s7 = 0; s7 < 7; ++s7) pre[s7] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(rowp) + qc[s7]);
     };
     issue(0);
     int hg = 0;
@@ -273,21 +273,22 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
 #pragma unroll
                         for (int dk = 0; dk < 2; ++dk) {
                             const int sl = di * 4 + dj * 2 + dk;
+                            {   // the two groups (mz = 0, 1) of this element slot in one 24-double scalar load: 18 FMAs per round trip
+                                d8_t c0, c1, c2;
+                                sload24(tab, hg * 96, c0, c1, c2);
+                                hg += 2;
 #pragma unroll
-                            for (int mz = 0; mz < 2; ++mz) {
-                                d8_t k0;
-                                d4_t k1;
-                                sload12(tab, hg * 96, k0, k1);
-                                ++hg;
-
-                                const int n3 = dk + mz;            // dz + 1
+                                for (int mz = 0; mz < 2; ++mz) {
+                                    const int n3 = dk + mz;            // dz + 1
 #pragma unroll
-                                for (int r = 0; r < 3; ++r)
+                                    for (int r = 0; r < 3; ++r)
 #pragma unroll
-                                    for (int c = 0; c < 3; ++c) {
-                                        const int q = r * 3 + c;
-                                        T[sl][r] = fma(q < 8 ? k0[q < 8 ? q : 0] : k1[0], u3[n3][c], T[sl][r]);
-                                    }
+                                        for (int c = 0; c < 3; ++c) {
+                                            const int q = 12 * mz + r * 3 + c;                   // position in the 24 doubles
+                                            const double kv = q < 8 ? c0[q < 8 ? q : 0] : (q < 16 ? c1[(q >= 8 && q < 16) ? q - 8 : 0] : c2[q >= 16 ? q - 16 : 0]);
+                                            T[sl][r] = fma(kv, u3[n3][c], T[sl][r]);
+                                        }
+                                }
                                 // pin: these FMAs retire before the next coefficient load is issued
                                 asm volatile("" : "+v"(T[sl][0]), "+v"(T[sl][1]), "+v"(T[sl][2]));
                             }
