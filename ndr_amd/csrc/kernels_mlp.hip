@@ -125,7 +125,7 @@ template <bool FULL>
 __global__ void __launch_bounds__(512) k_mlp_forward(MlpArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     _Float16 *H = reinterpret_cast<_Float16 *>(smem);                            // [128][HSTRIDE]
-    _Float16 *F = reinterpret_cast<_Float16 *>(smem);                            // layer 1: 2 x [128][FSTRIDE] (aliases H)
+    _Float16 *F = reinterpret_cast<_Float16 *>(smem);                            // layer 1: 3 x [128][FSTRIDE] (aliases H)
     float *xc = reinterpret_cast<float *>(smem + (size_t) MLP_TM * MLP_HSTRIDE * 2);   // [128][3] coordinates
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -178,14 +178,25 @@ __global__ void __launch_bounds__(512) k_mlp_forward(MlpArgs a) {
     };
     APipe<FULL> ap1;
     ap1.init((const _Float16 *) a.W1, K1, wave, ntiles, lane, K1 / 16);      // weight prefetch runs across the feature chunks
+    // Three feature buffers: while chunk ch is multiplied, chunk ch+2 is generated.  The two waves that share a SIMD (w and
+    // w+4) do the two halves of an iteration in opposite order, so that one is on the vector pipe (features) while the other
+    // is on the matrix pipe; with both in the same order the barrier per chunk keeps them in lockstep and the pipes alternate.
     make_features(0, 0);
+    if (nchunks > 1) make_features(1, 1);
     __syncthreads();
     static_assert(MLP_KC / 16 == MLP_PD, "one feature chunk = one revolution of the weight ring");
-    for (int ch = 0; ch < nchunks; ++ch) {
-        // (generating the features in parts between the MFMA groups of the chunk was measured slower than doing them first)
-        if (ch + 1 < nchunks) make_features(ch + 1, (ch + 1) & 1);
-        gemm_ring<MLP_FSTRIDE, FULL>(acc, ap1, ch * MLP_PD, F + (ch & 1) * (MLP_TM * MLP_FSTRIDE), 0, lane, [](int) {});
+    for (int ch = 0, cur = 0, nxt = 2; ch < nchunks; ++ch) {
+        const bool more = ch + 2 < nchunks;
+        if (wave < 4) {
+            if (more) make_features(ch + 2, nxt);
+            gemm_ring<MLP_FSTRIDE, FULL>(acc, ap1, ch * MLP_PD, F + cur * (MLP_TM * MLP_FSTRIDE), 0, lane, [](int) {});
+        } else {
+            gemm_ring<MLP_FSTRIDE, FULL>(acc, ap1, ch * MLP_PD, F + cur * (MLP_TM * MLP_FSTRIDE), 0, lane, [](int) {});
+            if (more) make_features(ch + 2, nxt);
+        }
         __syncthreads();
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt = nxt == 2 ? 0 : nxt + 1;
     }
 
     // ---- epilogue of a layer: bias + ReLU -> fp16 activations in H ([voxel][k]) ----------------
