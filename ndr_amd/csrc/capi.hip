@@ -1029,7 +1029,7 @@ static void mlp_backward_impl(vfem_mlp *m, vfem::MlpArgs base, const float *coor
         }
         launch_colsum_f16(rows, nn, m->acts.p + (size_t) nh * rows * nn, m->gs.p, m->partial.p, s);
         launch_reduce_partials(cb, nn, m->partial.p, inv, beta, dwout, s);
-        launch_sum_f32(rows, m->gs.p, inv, beta, dbout, s);
+        launch_sum_f32(rows, m->gs.p, inv, beta, dbout, m->partial.p, s);
     }
 }
 extern "C" {

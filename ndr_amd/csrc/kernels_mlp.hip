@@ -423,24 +423,55 @@ __global__ void __launch_bounds__(512) k_colsum_f16(long long rows, int ncols, c
         partial[(long long) blockIdx.x * ncols + c] = acc;
     }
 }
-// out[i] = beta * out[i] + alpha * sum_b partial[b][i]
+// out[i] = beta * out[i] + alpha * sum_b partial[b][i]; four consecutive outputs per thread (16-byte loads), the loop over
+// the partials unrolled so that many loads are in flight
 __global__ void __launch_bounds__(256) k_reduce_partials(int nb, long long n, const float *__restrict__ partial, float alpha,
                                                          float beta, float *__restrict__ out) {
-    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float acc = 0.f;
-    for (int b = 0; b < nb; ++b) acc += partial[(long long) b * n + i];
-    out[i] = (beta == 0.f ? 0.f : beta * out[i]) + alpha * acc;
+    const long long i4 = ((long long) blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    if (i4 + 3 < n && (n & 3) == 0) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int b = 0; b < nb; ++b) {
+            const float4 v = *reinterpret_cast<const float4 *>(partial + (long long) b * n + i4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (beta != 0.f) { o = *reinterpret_cast<const float4 *>(out + i4); o.x *= beta; o.y *= beta; o.z *= beta; o.w *= beta; }
+        o.x += alpha * acc.x; o.y += alpha * acc.y; o.z += alpha * acc.z; o.w += alpha * acc.w;
+        *reinterpret_cast<float4 *>(out + i4) = o;
+        return;
+    }
+    for (long long i = i4; i < n && i < i4 + 4; ++i) {
+        float acc = 0.f;
+        for (int b = 0; b < nb; ++b) acc += partial[(long long) b * n + i];
+        out[i] = (beta == 0.f ? 0.f : beta * out[i]) + alpha * acc;
+    }
 }
 void launch_colsum_f16(long long rows, int ncols, const void *X, const float *w, float *partial, hipStream_t s) {
     k_colsum_f16<<<dim3((unsigned) ((rows + 511) / 512)), dim3(512), 0, s>>>(rows, ncols, (const _Float16 *) X, w, partial);
     VFEM_HIP(hipGetLastError());
 }
 void launch_reduce_partials(int nb, long long n, const float *partial, float alpha, float beta, float *out, hipStream_t s) {
-    k_reduce_partials<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s>>>(nb, n, partial, alpha, beta, out);
+    k_reduce_partials<<<dim3((unsigned) (((n + 3) / 4 + 255) / 256)), dim3(256), 0, s>>>(nb, n, partial, alpha, beta, out);
     VFEM_HIP(hipGetLastError());
 }
 
+// sum of a float vector in two passes: 4096 elements per block into partial[], then one small block over the partials
+__global__ void __launch_bounds__(256) k_sum_f32_partial(long long n, const float *__restrict__ x, float *__restrict__ partial) {
+    __shared__ float sm[256];
+    const long long base = (long long) blockIdx.x * 4096;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const long long i = base + threadIdx.x + 256 * k;
+        if (i < n) acc += x[i];
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int) threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
 __global__ void __launch_bounds__(256) k_sum_f32(long long n, const float *__restrict__ x, float alpha, float beta, float *__restrict__ out) {
     __shared__ float sm[256];
     float acc = 0.f;
@@ -450,8 +481,10 @@ __global__ void __launch_bounds__(256) k_sum_f32(long long n, const float *__res
     for (int o = 128; o > 0; o >>= 1) { if ((int) threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) out[0] = (beta == 0.f ? 0.f : beta * out[0]) + alpha * sm[0];
 }
-void launch_sum_f32(long long n, const float *x, float alpha, float beta, float *out, hipStream_t s) {
-    k_sum_f32<<<dim3(1), dim3(256), 0, s>>>(n, x, alpha, beta, out);
+void launch_sum_f32(long long n, const float *x, float alpha, float beta, float *out, float *scratch, hipStream_t s) {
+    const long long nblk = (n + 4095) / 4096;                      // scratch holds >= nblk floats
+    k_sum_f32_partial<<<dim3((unsigned) nblk), dim3(256), 0, s>>>(n, x, scratch);
+    k_sum_f32<<<dim3(1), dim3(256), 0, s>>>(nblk, scratch, alpha, beta, out);
     VFEM_HIP(hipGetLastError());
 }
 

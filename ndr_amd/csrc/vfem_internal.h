@@ -139,7 +139,7 @@ void launch_mlp_backward(const MlpBwdArgs &a, long long rows, hipStream_t s);
 void launch_mlp_features(const MlpArgs &a, long long rows, void *out, hipStream_t s);
 void launch_colsum_f16(long long rows, int ncols, const void *X, const float *w, float *partial, hipStream_t s);
 void launch_reduce_partials(int nb, long long n, const float *partial, float alpha, float beta, float *out, hipStream_t s);
-void launch_sum_f32(long long n, const float *x, float alpha, float beta, float *out, hipStream_t s);
+void launch_sum_f32(long long n, const float *x, float alpha, float beta, float *out, float *scratch, hipStream_t s);
 void launch_transpose_f32_to_f16(int rows, int cols, const float *in, void *out, hipStream_t s);
 void launch_adam(long long n, float *p, const float *g, float *m, float *v, float lr, float b1, float b2, float eps, int step, hipStream_t s);
 
