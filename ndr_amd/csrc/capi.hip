@@ -205,7 +205,7 @@ static void mg_smooth(vfem_mg *mg, int l, double *u, const double *b, int forwar
     MgLevel &L = mg->lv[l];
     g_mf1_sym = mg->mf1_sym ? 1 : 0;
     if (L.kind == OP_STENCIL) launch_gs_sweep_stencil(L.d, L.S.p, u, b, L.maskp, forward, L.xparity, first, count, s);
-    else launch_gs_sweep_mf(L.d, L.kind, level_K(mg, l), l == 0 ? mg->fine->dGsTab.p : nullptr, level_E(mg, l), u, b, L.maskp,
+    else launch_gs_sweep_mf(L.d, L.kind, level_K(mg, l), l == 0 ? mg->fine->dGsTab.p : mg->mf1diag.p, level_E(mg, l), u, b, L.maskp,
                             forward, L.xparity, first, count, s);
 }
 
@@ -558,6 +558,12 @@ static void finish_mg_create(vfem_mg *mg) {
         VFEM_HIP(hipMemcpy(mg->c2K0.p, c2.data(), c2.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     mg->mf1_sym = coarsened_matrices_are_mirror_images(c.data());
+    {
+        double dt[96];
+        build_mf1_diag_table(c.data(), dt);
+        mg->mf1diag.alloc(96);
+        VFEM_HIP(hipMemcpy(mg->mf1diag.p, dt, sizeof(dt), hipMemcpyHostToDevice));
+    }
     for (int l = mg->first_active; l <= mg->L; ++l) {
         MgLevel &lv = mg->lv[(size_t) l];
         lv.x.alloc((size_t) lv.d.nn * 3); lv.b.alloc((size_t) lv.d.nn * 3); lv.r.alloc((size_t) lv.d.nn * 3);

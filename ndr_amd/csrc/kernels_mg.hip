@@ -351,9 +351,10 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
 // f the rows are the rows rho = li ^ f of cK0[0]; the column permutation m -> m ^ f and the signs are resolved at
 // compile time (register renaming, per-component partial sums).  Register footprint as the general kernel.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_gs_color_mf1_sym(Dims d, const double *__restrict__ K0c, const double *__restrict__ E,
-                                                          double *__restrict__ u, const double *__restrict__ b,
-                                                          const uint8_t *__restrict__ mask, int cx, int cy, int cz, int forward) {
+__global__ void __launch_bounds__(256, 4) k_gs_color_mf1_sym(Dims d, const double *__restrict__ K0c, const double *__restrict__ Dtab,
+                                                             const double *__restrict__ E, double *__restrict__ u,
+                                                             const double *__restrict__ b, const uint8_t *__restrict__ mask, int cx,
+                                                             int cy, int cz, int forward) {
     const int k = 2 * (blockIdx.x * 64 + threadIdx.x) + cz;
     const int j = 2 * (blockIdx.y * 4 + threadIdx.y) + cy;
     const int i = 2 * blockIdx.z + cx;
@@ -363,9 +364,12 @@ __global__ void __launch_bounds__(256) k_gs_color_mf1_sym(Dims d, const double *
     double S[3] = {0.0, 0.0, 0.0}, M[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) M[q] = 0.0;
-    static_for<8>([&](auto sc) {
-        constexpr int slot = decltype(sc)::value, li = 7 - slot;
-        constexpr int di = (slot >> 2) & 1, dj = (slot >> 1) & 1, dk = slot & 1;
+    // the element slot is a run-time loop: fully unrolled the kernel is ~60 KB of straight-line code, about the size of
+    // the instruction cache two CUs share; the child index f stays compile-time (it permutes registers and fixes the signs)
+#pragma unroll 1
+    for (int slot = 0; slot < 8; ++slot) {
+        const int li = 7 - slot;
+        const int di = (slot >> 2) & 1, dj = (slot >> 1) & 1, dk = slot & 1;
         const int ex = i - 1 + di, ey = j - 1 + dj, ez = k - 1 + dk;
         const bool ok = ex >= 0 && ex < d.nx && ey >= 0 && ey < d.ny && ez >= 0 && ez < d.nz;
         // out-of-grid elements (grid faces only) run with clamped indices and zero moduli: no divergent control flow
@@ -387,7 +391,7 @@ __global__ void __launch_bounds__(256) k_gs_color_mf1_sym(Dims d, const double *
         }
         static_for<24>([&](auto gc) {
             constexpr int f = decltype(gc)::value / 3, r = decltype(gc)::value % 3;
-            constexpr int rho = li ^ f;
+            const int rho = li ^ f;                                   // wave-uniform, run-time
             d8_t c0, c1, c2;
             sload24(K0c, (3 * rho + r) * 24 * 8, c0, c1, c2);
             double coef[24];
@@ -405,14 +409,24 @@ __global__ void __launch_bounds__(256) k_gs_color_mf1_sym(Dims d, const double *
             // s_r * sum_c s_c acc_c
             const double t = ((n0 != nr) ? -acc[0] : acc[0]) + ((n1 != nr) ? -acc[1] : acc[1]) + ((n2 != nr) ? -acc[2] : acc[2]);
             S[r] = fma(Ef[f], t, S[r]);
-            // diagonal block: s_r s_c cK0[0][(rho,r),(rho,c)]
-            M[3 * r + 0] = fma((n0 != nr) ? -Ef[f] : Ef[f], coef[3 * rho + 0], M[3 * r + 0]);
-            M[3 * r + 1] = fma((n1 != nr) ? -Ef[f] : Ef[f], coef[3 * rho + 1], M[3 * r + 1]);
-            M[3 * r + 2] = fma((n2 != nr) ? -Ef[f] : Ef[f], coef[3 * rho + 2], M[3 * r + 2]);
-            // every consumer of this row's coefficients retires before the next row load (otherwise they stay live in SGPRs)
-            asm volatile("" : "+v"(S[r]), "+v"(M[3 * r + 0]), "+v"(M[3 * r + 1]), "+v"(M[3 * r + 2]));
+            asm volatile("" : "+v"(S[r]));                            // retire before the next row load
         });
-    });
+        // diagonal block: sum_f E_f s_r s_c cK0[0][(rho,r),(rho,c)] from the 8 x 9 table of diagonal blocks
+        static_for<8>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            const int rho = li ^ f;
+            d8_t k0;
+            d4_t k1;
+            sload12(Dtab, rho * 96, k0, k1);
+            constexpr bool ng[3] = {(bool) ((f >> 2) & 1), (bool) ((f >> 1) & 1), (bool) (f & 1)};
+            static_for<9>([&](auto qc) {
+                constexpr int q = decltype(qc)::value, r = q / 3, c = q % 3;
+                const double kv = q < 8 ? k0[q < 8 ? q : 0] : k1[0];
+                M[q] = fma((ng[r] != ng[c]) ? -Ef[f] : Ef[f], kv, M[q]);
+            });
+            asm volatile("" : "+v"(M[0]), "+v"(M[4]), "+v"(M[8]), "+v"(M[1]), "+v"(M[2]), "+v"(M[5]));
+        });
+    }
     const long long n = nidx(d, i, j, k);
     double bms[3], ud[3];
 #pragma unroll
@@ -420,6 +434,15 @@ __global__ void __launch_bounds__(256) k_gs_color_mf1_sym(Dims d, const double *
     gs_solve(bms, M, mask[n], forward != 0, ud);
 #pragma unroll
     for (int c = 0; c < 3; ++c) u[3 * n + c] += ud[c];
+}
+
+// diagonal blocks of cK0[0] for k_gs_color_mf1_sym: 8 groups of 12 doubles (9 used)
+void build_mf1_diag_table(const double *cK0_0, double *tab /* 8*12 */) {
+    for (int rho = 0; rho < 8; ++rho) {
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) tab[rho * 12 + 3 * r + c] = cK0_0[(3 * rho + r) * 24 + 3 * rho + c];
+        for (int q = 9; q < 12; ++q) tab[rho * 12 + q] = 0.0;
+    }
 }
 
 // true when cK0[f] is the mirror image of cK0[0] to rounding (what k_gs_color_mf1_sym relies on)
@@ -450,7 +473,7 @@ void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const doubl
         dim3 blk(64, 4, 1), grd((cntz + 63) / 64, (cnty + 3) / 4, cntx);
         if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab) k_gs_rows_mf0<<<grd, blk, 0, s>>>(d, gs_tab, E, u, b, mask, cx, cy, cz, forward);
         else if (kind == OP_MF0) k_gs_color_mf<0><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
-        else if (g_mf1_sym && g_gs_variant == 0) k_gs_color_mf1_sym<<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
+        else if (g_mf1_sym && g_gs_variant == 0 && gs_tab) k_gs_color_mf1_sym<<<grd, blk, 0, s>>>(d, K, gs_tab, E, u, b, mask, cx, cy, cz, forward);
         else                k_gs_color_mf<1><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
     }
     VFEM_HIP(hipGetLastError());

@@ -86,6 +86,7 @@ void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const doubl
                         const double *b, const uint8_t *mask, int forward, int xparity, int first, int count, hipStream_t s);
 void build_gs_table(const double *K0, double *tab /* 72*12 doubles */);
 bool coarsened_matrices_are_mirror_images(const double *cK0_host /* 8 x 576 */);
+void build_mf1_diag_table(const double *cK0_0, double *tab /* 8*12 */);
 extern int g_mf1_sym;
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
                              int forward, int xparity, int first, int count, hipStream_t s);
@@ -189,6 +190,7 @@ struct vfem_mg {
     int L = 0;                                  // numCoarseningLevels
     std::vector<MgLevel> lv;
     vfem::DevBuf<double> cK0;                   // 8 x 576 coarsened reference matrices (MG.hh:644-648)
+    vfem::DevBuf<double> mf1diag;               // 8 x 12: diagonal blocks of cK0[0] (level-1 Gauss-Seidel)
     vfem::DevBuf<double> c2K0;                  // 64 x 576: I_g^T cK0[f] I_g (level-2 element matrices from the fine moduli)
     vfem::DevBuf<double> Ainv;                  // coarsest-level dense inverse
     vfem::DevBuf<double> pr, pd, pAd, ps;       // PCG vectors
