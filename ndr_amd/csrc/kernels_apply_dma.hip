@@ -29,9 +29,14 @@ constexpr int E_INSTR = (TY * 33 + 63) / 64;           // TY rows x 33 pieces (3
 static_assert(U_INSTR <= 2 * TY && U_INSTR + E_INSTR <= 3 * TY && E_INSTR <= TY, "every wave issues 2 or 3 DMA instructions per plane");
 static_assert(U_INSTR + E_INSTR >= 2 * TY, "every wave issues at least 2 DMA instructions per plane (wait_plane counts on it)");
 constexpr int SLOT_BYTES = U_INSTR * 1024 + E_INSTR * 1024;   // 18432
-constexpr int RING = 4;
+#ifndef VFEM_DMA_RING
+#define VFEM_DMA_RING 4
+#endif
+constexpr int RING = VFEM_DMA_RING;     // planes staged per block; plane ii + RING - 1 is requested while plane ii is consumed
+constexpr int PD = RING - 1;
 constexpr int SS_DOUBLES = 3 * TY * TZ;     // one scatter buffer (per component the sum owed to the next row in y)
 constexpr size_t LDS_BYTES = (size_t) RING * SLOT_BYTES + 2 * SS_DOUBLES * sizeof(double);
+static_assert(LDS_BYTES <= 160 * 1024, "ring + scatter buffers must fit the 160 KB of LDS of a CU");
 }  // namespace dma
 
 struct DmArgs2 { double v[36]; };
@@ -45,14 +50,12 @@ __device__ __forceinline__ void glds16(const void *g, void *l) {
 
 template <int CNT>   // CNT = LDS-DMA instructions this wave issues per plane (2 or 3)
 __device__ __forceinline__ void wait_plane(bool has_stores, bool steady) {
-    // retire the DMA of the oldest plane in flight; two newer planes (2 CNT instructions) and, in the steady
-    // state, the four output stores of the last two phases were issued after it
+    // retire the DMA of the oldest plane in flight (vmcnt retires in issue order); in the steady state PD - 1 newer planes
+    // (CNT instructions each) and the two output stores (dwordx4 + dwordx2) of each of the last PD - 1 phases were issued after it
+    using namespace dma;
     if (!steady) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-    if (has_stores) {
-        if (CNT == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    } else {
-        if (CNT == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    }
+    if (has_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * (CNT + 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * CNT) : "memory");
 }
 
 // value held by the previous lane of the wave (lane 0 receives 0): DPP wave shift, two 32-bit moves per double, no LDS
@@ -69,6 +72,9 @@ __global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, 
                                                       int planes_per_chunk, const char *u_last, const char *e_last,
                                                       int plane_lo, int plane_hi) {
     using namespace dma;
+    // 7 / 8: variants 6 / 0 with non-temporal stores; 9: variant 4 storing to two planes only; 10: variant 4 loading four planes only
+    constexpr int X = (EXP == 8) ? 0 : (EXP == 7 ? 6 : (EXP >= 9 ? 4 : EXP));
+    constexpr bool NT = EXP == 7 || EXP == 8;
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char *ring = smem;
     double *sS = reinterpret_cast<double *>(smem + (size_t) RING * SLOT_BYTES);
@@ -143,8 +149,9 @@ __global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, 
         erpar = (int) ((ebase8 + (long long) jj * d.nz + k0e) & 1);
     }
 
-    auto issue_plane = [&](int i) {                    // node plane i + element layer min(i, nx-1) -> ring slot i & 3
-        unsigned char *slot = ring + (size_t) (i & (RING - 1)) * SLOT_BYTES;
+    auto issue_plane = [&](int i, int sl) {            // node plane i + element layer min(i, nx-1) -> ring slot sl
+        if (X == 6) return;
+        unsigned char *slot = ring + (size_t) sl * SLOT_BYTES;
         const int ip = i & ppar;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -180,13 +187,15 @@ __global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, 
             ep_run[k] = reinterpret_cast<const char *>(E + ((long long) i * elayer + ego - ((epar0 + (i & epar)) & 1)));
         }
     };
-    auto issue_running = [&](int i, int k) {           // k = step parity (compile-time after unrolling)
-        unsigned char *slot = ring + (size_t) (i & (RING - 1)) * SLOT_BYTES;
+    auto issue_running = [&](int i, int k, int sl) {   // k = step parity (compile-time after unrolling), sl = ring slot
+        if (X == 6) return;
+        unsigned char *slot = ring + (size_t) sl * SLOT_BYTES;
         const bool last = (i >= d.NX - 1);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             if (uhas[s2]) {
                 const char *g = up_run[k][s2];
+                if (EXP == 10) g -= 24LL * plane * (i & ~3);
                 if (last) g = g > u_last ? u_last : g;
                 glds16(g, slot + 1024 * (wave + TY * s2));
                 up_run[k][s2] += 48LL * plane;         // two planes of 24 * plane bytes
@@ -194,6 +203,7 @@ __global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, 
         }
         if (ehas) {
             const char *g = ep_run[k];
+            if (EXP == 10) g -= 8LL * elayer * (i & ~3);
             if (i >= d.nx - 1) {                       // last layers: clamp the layer index and the address
                 const long long off = (long long) (d.nx - 1) * elayer + ego - ((epar0 + ((d.nx - 1) & epar)) & 1);
                 g = reinterpret_cast<const char *>(E + off);
@@ -227,7 +237,7 @@ __global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, 
             const double p = acc[0][c] - acc[2][c], q = acc[1][c] - acc[3][c];
             const double r = acc[0][c] + acc[2][c], t = acc[1][c] + acc[3][c];
             wa[c] = p - q;
-            if (EXP == 1 || EXP >= 3) { wa[c] += (p + q) + (r - t) + (r + t); continue; }
+            if (X == 1 || X >= 3) { wa[c] += (p + q) + (r - t) + (r + t); continue; }
             // the two terms owed to the z-neighbour move one lane up (DPP), only the sum owed to the y-neighbour (next wave)
             // goes through LDS: 3 instead of 9 doubles written and read per thread and plane
             wa[c] += lane_below(p + q);
@@ -235,14 +245,15 @@ __global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, 
         }
     };
     auto emit_plane = [&](int i, const double wa[3], int buf) {
-        if (!out_ok) return;
+        if (!out_ok || X == 5) return;
         const double *sX = sS + buf * SS_DOUBLES;
-        const long long n = (long long) i * plane + (long long) ej * d.NZ + ek;
+        const long long n = (long long) (EXP == 9 ? (i & 1) : i) * plane + (long long) ej * d.NZ + ek;
         double w[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            w[c] = (EXP == 1 || EXP >= 3) ? wa[c] : wa[c] + sX[(c * TY + ty - 1) * TZ + tz];
-        out[3 * n] = w[0]; out[3 * n + 1] = w[1]; out[3 * n + 2] = w[2];
+            w[c] = (X == 1 || X >= 3) ? wa[c] : wa[c] + sX[(c * TY + ty - 1) * TZ + tz];
+        if (NT) { __builtin_nontemporal_store(w[0], &out[3 * n]); __builtin_nontemporal_store(w[1], &out[3 * n + 1]); __builtin_nontemporal_store(w[2], &out[3 * n + 2]); }
+        else { out[3 * n] = w[0]; out[3 * n + 1] = w[1]; out[3 * n + 2] = w[2]; }
     };
 
     double fold[4][3], carry[4][3];
@@ -259,13 +270,13 @@ __global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, 
     auto process = [&](double Ee, const double *su, const int q[4], int buf, double wa[3]) {
         if (!elem_ok) Ee = 0.0;
         double fnew[4][3];
-        if (EXP == 4) {
+        if (X >= 4) {
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) fnew[qq][c] = Ee + qq + c;
         } else face_modes_at(fnew, su, q[0], q[1], q[2], q[3]);
-        if (EXP >= 2) {
+        if (X >= 2) {
             double acc2[4][3];
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq)
@@ -322,21 +333,21 @@ __global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, 
     const int i_start = p0 > 0 ? p0 - 1 : 0;
     const int i_end = p1 + 1 < d.NX - 1 ? p1 + 1 : d.NX - 1;
 
-    // ---- prologue: planes i_start .. i_start+3 issued, all retired once ---------------------------
-    issue_plane(i_start);
-    if (i_start + 1 <= i_end) issue_plane(i_start + 1);
-    if (i_start + 2 <= i_end) issue_plane(i_start + 2);
-    if (i_start + 3 <= i_end) issue_plane(i_start + 3);
+    // ---- prologue: planes i_start .. i_start+RING-1 issued, all retired once ---------------------------
+    // ring slot of plane i is (i - i_start) mod RING
+#pragma unroll
+    for (int r = 0; r < RING; ++r)
+        if (i_start + r <= i_end) issue_plane(i_start + r, r);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     {
-        const double *su = reinterpret_cast<const double *>(ring + (size_t) (i_start & (RING - 1)) * SLOT_BYTES);
+        const double *su = reinterpret_cast<const double *>(ring);
         face_modes(fold, su, i_start);
     }
     auto e_offset = [&](int i) { return oE0 + ((erpar + (i & epar)) & 1); };
-    double Eprev = reinterpret_cast<const double *>(ring + (size_t) (i_start & (RING - 1)) * SLOT_BYTES)[e_offset(i_start)];
+    double Eprev = reinterpret_cast<const double *>(ring)[e_offset(i_start)];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                      // slot i_start may now be overwritten (plane i_start+4)
+    __builtin_amdgcn_s_barrier();                      // slot 0 may now be overwritten (plane i_start+RING)
 
     // read offsets for the two step parities (the alignment shift alternates with the plane when 3*plane is odd)
     int qoff[2][4], eoff2[2];
@@ -347,13 +358,15 @@ __global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, 
         qoff[k][0] = o00 + s0r; qoff[k][1] = o01 + s0r; qoff[k][2] = o10 + s1r; qoff[k][3] = o11 + s1r;
         eoff2[k] = oE0 + ((erpar + (i & epar)) & 1);
     }
-    init_running(i_start + 4);
-    const bool has_stores = ty >= 1 && ej < d.NY;
+    init_running(i_start + RING);
+    const bool has_stores = X != 5 && ty >= 1 && ej < d.NY;
 
-    int buf = 0, phase = 0;
+    int buf = 0, phase = 0, cur = 1 % RING;          // cur = ring slot of the plane consumed by the next phase
     auto run_phase = [&](int ii, int k) {
-        if (ii + 3 <= i_end) issue_running(ii + 3, k); // slot (ii+3)&3 held plane ii-1: every wave passed a barrier after reading it
-        const double *su = reinterpret_cast<const double *>(ring + (size_t) (ii & (RING - 1)) * SLOT_BYTES);
+        // the slot of plane ii + PD held plane ii - 1: every wave passed a barrier after reading it
+        if (ii + PD <= i_end) issue_running(ii + PD, k, cur == 0 ? RING - 1 : cur - 1);
+        const double *su = reinterpret_cast<const double *>(ring + (size_t) cur * SLOT_BYTES);
+        cur = cur + 1 == RING ? 0 : cur + 1;
         double wa[3];
         const double Enext = su[eoff2[k]];             // modulus of layer ii, used in the next phase
         process(Eprev, su, qoff[k], buf, wa);
@@ -361,7 +374,7 @@ __global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, 
         if (ii + 1 <= i_end) {
             // counted wait: after plane ii+1's DMA this wave issued the stores of phases ii-2 and ii-1 and the DMA of
             // planes ii+2 and ii+3; outside that steady state (start / end of the chunk) drain everything
-            const bool steady = (phase >= 2) && (ii + 3 <= i_end) && (ii - 3 >= p0);
+            const bool steady = (phase >= PD - 1) && (ii + PD <= i_end) && (ii - PD >= p0);
             if (cnt == 2) wait_plane<2>(has_stores, steady); else wait_plane<3>(has_stores, steady);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -407,6 +420,12 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
         VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
         VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
         VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
         attr = true;
     }
     // last admissible (aligned) piece: the one holding the last byte of each array
@@ -418,6 +437,12 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
         case 2: VFEM_DMA_LAUNCH(2); break;
         case 3: VFEM_DMA_LAUNCH(3); break;
         case 4: VFEM_DMA_LAUNCH(4); break;
+        case 5: VFEM_DMA_LAUNCH(5); break;
+        case 6: VFEM_DMA_LAUNCH(6); break;
+        case 7: VFEM_DMA_LAUNCH(7); break;
+        case 8: VFEM_DMA_LAUNCH(8); break;
+        case 9: VFEM_DMA_LAUNCH(9); break;
+        case 10: VFEM_DMA_LAUNCH(10); break;
         default: VFEM_DMA_LAUNCH(0);
     }
     VFEM_HIP(hipGetLastError());
