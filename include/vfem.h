@@ -40,7 +40,8 @@ const char *vfem_last_error(void);
 int  vfem_device_count(void);                 /* number of visible HIP devices (0 => no GPU) */
 int  vfem_set_device(int device);
 int  vfem_version(void);
-int  vfem_debug_set(int key, int value);   /* tuning/diagnostic knobs: 0 apply planes-in-flight (2..4), 1 apply memory skeleton, 2 GS variant */
+int  vfem_debug_set(int key, int value);   /* tuning/diagnostic knobs: 0 apply planes-in-flight (2..4), 1 apply ablation variant, 2 GS variant,
+                                              6 degree-2 apply (0 marching, 1 dense gather, 2 pencil), 7 apply x-chunks */
 
 /* ---- raw device memory helpers (for callers without their own HIP allocator) ---- */
 int vfem_malloc(void **ptr, size_t bytes);

@@ -14,6 +14,7 @@
 // pieces never straddle the 16-byte-aligned end of an allocation, so nothing outside the caller's buffers is read;
 // a row image starts at node max(k0, 0) so that no address precedes the array.
 #include "vfem_internal.h"
+#include <type_traits>
 
 namespace vfem {
 
@@ -34,6 +35,13 @@ constexpr int SLOT_BYTES = U_INSTR * 1024 + E_INSTR * 1024;   // 18432
 #endif
 constexpr int RING = VFEM_DMA_RING;     // planes staged per block; plane ii + RING - 1 is requested while plane ii is consumed
 constexpr int PD = RING - 1;
+#ifndef VFEM_DMA_WAVES
+#define VFEM_DMA_WAVES 2
+#endif
+constexpr int NW = VFEM_DMA_WAVES;      // waves that only issue the LDS-DMA (0: every compute wave issues its share and waits on it)
+constexpr int NQ = U_INSTR + E_INSTR;   // DMA instructions per plane
+constexpr int NI = NW > 0 ? (NQ + NW - 1) / NW : 0;      // per DMA wave
+static_assert(NW == 0 || NI * PD <= 63, "the planes in flight of one DMA wave must fit the 6-bit vmcnt");
 constexpr int SS_DOUBLES = 3 * TY * TZ;     // one scatter buffer (per component the sum owed to the next row in y)
 constexpr size_t LDS_BYTES = (size_t) RING * SLOT_BYTES + 2 * SS_DOUBLES * sizeof(double);
 static_assert(LDS_BYTES <= 160 * 1024, "ring + scatter buffers must fit the 160 KB of LDS of a CU");
@@ -67,13 +75,14 @@ __device__ __forceinline__ double lane_below(double v) {
 }
 
 template <int EXP>
-__global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, const double *__restrict__ E,
+__global__ void __launch_bounds__(64 * (dma::TY + dma::NW)) k_apply_dma(Dims d, DmArgs2 dm, const double *__restrict__ E,
                                                       const double *__restrict__ u, double *__restrict__ out,
                                                       int planes_per_chunk, const char *u_last, const char *e_last,
                                                       int plane_lo, int plane_hi) {
     using namespace dma;
     // 7 / 8: variants 6 / 0 with non-temporal stores; 9: variant 4 storing to two planes only; 10: variant 4 loading four planes only
-    constexpr int X = (EXP == 8) ? 0 : (EXP == 7 ? 6 : (EXP >= 9 ? 4 : EXP));
+    // 11: variant 6 (stores only) with row-contiguous 16-byte stores of meaningless values (timing of the store pattern)
+    constexpr int X = (EXP == 8) ? 0 : ((EXP == 7 || EXP == 11) ? 6 : (EXP >= 9 ? 4 : EXP));
     constexpr bool NT = EXP == 7 || EXP == 8;
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char *ring = smem;
@@ -101,6 +110,85 @@ __global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, 
     const long long ubase8 = (long long) (reinterpret_cast<uintptr_t>(u) >> 3);
     const long long ebase8 = (long long) (reinterpret_cast<uintptr_t>(E) >> 3);
     const int ppar = (int) ((3 * plane) & 1), epar = (int) (elayer & 1);       // parity added per plane / element layer
+    const int i_start = p0 > 0 ? p0 - 1 : 0;
+    const int i_end = p1 + 1 < d.NX - 1 ? p1 + 1 : d.NX - 1;
+
+    // ---- DMA waves (ty >= TY): request the planes, retire them in order, keep in step with the barriers of the compute waves ----
+    // Stores and loads of one wave retire through the same in-order vmcnt, so a wave that does both waits for the (slow)
+    // completion of its older stores whenever it waits for a plane; waves that only load do not.
+    if (NW > 0 && ty >= TY) {
+        auto dma_loop = [&](auto Wc) {
+            constexpr int W = decltype(Wc)::value;
+            constexpr int Q0 = W * NI;
+            constexpr int N = (NQ - Q0) < NI ? (NQ - Q0) : NI;     // instructions of this wave per plane
+            long long go[N > 0 ? N : 1];        // double offset of this lane's piece from the plane / layer start
+            int par[N > 0 ? N : 1];             // parity of the row start at plane 0
+#pragma unroll
+            for (int t = 0; t < N; ++t) {
+                const int q = Q0 + t;
+                if (q < U_INSTR) {              // pieces [64 q, 64 q + 64) of the (TY+1) x 98 piece image of the node plane
+                    const int P = 64 * q + tz;
+                    int r = P / 98, c = P - r * 98;
+                    if (r > TY) { r = TY; c = 97; }
+                    int jj = j0 + r;
+                    jj = jj < 0 ? 0 : (jj > d.NY - 1 ? d.NY - 1 : jj);
+                    const long long rs = 3LL * ((long long) jj * d.NZ + k0u);
+                    go[t] = rs + 2LL * c;
+                    par[t] = (int) ((ubase8 + rs) & 1);
+                } else {                        // pieces of the TY x 33 piece image of the element layer
+                    const int P = 64 * (q - U_INSTR) + tz;
+                    int r = P / 33, c = P - r * 33;
+                    if (r > TY - 1) { r = TY - 1; c = 32; }
+                    int jj = j0 + r;
+                    jj = jj < 0 ? 0 : (jj > d.ny - 1 ? d.ny - 1 : jj);
+                    const long long rs = (long long) jj * d.nz + k0u;
+                    go[t] = rs + 2LL * c;
+                    par[t] = (int) ((ebase8 + rs) & 1);
+                }
+            }
+            auto issue = [&](int i, int sl) {   // node plane i + element layer min(i, nx-1) -> ring slot sl
+                if (X == 6) return;
+                unsigned char *slot = ring + (size_t) sl * SLOT_BYTES;
+                const int ia = EXP == 10 ? (i & 3) : i;
+                const int il = ia < d.nx ? ia : d.nx - 1;
+                const int ip = ia & ppar, ie = il & epar;
+                const long long ub = 3LL * ia * plane, eb = (long long) il * elayer;
+#pragma unroll
+                for (int t = 0; t < N; ++t) {
+                    const int q = Q0 + t;
+                    const char *g;
+                    if (q < U_INSTR) {          // aligned piece: one double below when (row start + plane offset) is odd
+                        g = reinterpret_cast<const char *>(u + (ub + go[t] - ((par[t] + ip) & 1)));
+                        g = g > u_last ? u_last : g;
+                    } else {
+                        g = reinterpret_cast<const char *>(E + (eb + go[t] - ((par[t] + ie) & 1)));
+                        g = g > e_last ? e_last : g;
+                    }
+                    glds16(g, slot + 1024 * q);
+                }
+            };
+#pragma unroll
+            for (int r = 0; r < RING; ++r)
+                if (i_start + r <= i_end) issue(i_start + r, r);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+            int cur = 1 % RING;
+            for (int ii = i_start + 1; ii <= i_end; ++ii) {
+                const bool more = ii + PD <= i_end;
+                if (more) issue(ii + PD, cur == 0 ? RING - 1 : cur - 1);
+                cur = cur + 1 == RING ? 0 : cur + 1;
+                // plane ii + 1 must have landed before the barrier; planes ii+2 .. ii+PD were requested after it
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * N) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (p1 == d.NX - 1) __builtin_amdgcn_s_barrier();
+        };
+        if (ty == TY) dma_loop(std::integral_constant<int, 0>{});
+        else dma_loop(std::integral_constant<int, (NW > 1 ? 1 : 0)>{});
+        return;
+    }
     // u: instruction j moves pieces [64 j, 64 j + 64) of the (TY+1) x 98 piece image; this wave owns j = wave, wave + TY
     long long ugo[2];          // double offset (from plane start) of this lane's row start + 2 q
     int upar[2];               // parity of (ubase8 + row start) at plane 0
@@ -108,7 +196,7 @@ __global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, 
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int j = wave + TY * s;
-        uhas[s] = j < U_INSTR;
+        uhas[s] = NW == 0 && j < U_INSTR;
         const int P = 64 * j + tz;
         int r = P / 98, q = P - r * 98;
         if (r > TY) { r = TY; q = 97; }
@@ -121,7 +209,7 @@ __global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, 
     // E: instruction e moves pieces [64 e, 64 e + 64) of the TY x 33 piece image (32 + 1 for the shift);
     // the E instructions go first to the waves that own a single u instruction (from the top), then to the waves below them
     const int eidx = (TY - 1 - wave) < E_INSTR ? (TY - 1 - wave) : -1;
-    const bool ehas = eidx >= 0;
+    const bool ehas = NW == 0 && eidx >= 0;
     long long ego = 0;
     int epar0 = 0;
     const int k0e = k0u;                               // element columns start at max(k0, 0) as well
@@ -252,6 +340,15 @@ __global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, 
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             w[c] = (X == 1 || X >= 3) ? wa[c] : wa[c] + sX[(c * TY + ty - 1) * TZ + tz];
+        if (EXP == 11) {
+            const long long n0 = (long long) i * plane + (long long) ej * d.NZ + (k0 + 1);     // first output node of the row
+            double *row = out + 3 * n0;
+            int nd = 3 * (d.NZ - (k0 + 1)); nd = nd > 189 ? 189 : nd;                          // doubles in the row
+            const int g0 = 2 * (tz - 1), g1 = 128 + 2 * (tz - 1);
+            if (g0 + 1 < nd) { row[g0] = w[0]; row[g0 + 1] = w[1]; }
+            if (g1 + 1 < nd) { row[g1] = w[2]; row[g1 + 1] = w[0]; }
+            return;
+        }
         if (NT) { __builtin_nontemporal_store(w[0], &out[3 * n]); __builtin_nontemporal_store(w[1], &out[3 * n + 1]); __builtin_nontemporal_store(w[2], &out[3 * n + 2]); }
         else { out[3 * n] = w[0]; out[3 * n + 1] = w[1]; out[3 * n + 2] = w[2]; }
     };
@@ -330,9 +427,6 @@ __global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, 
         scatter_face(acc, wa, buf);
     };
 
-    const int i_start = p0 > 0 ? p0 - 1 : 0;
-    const int i_end = p1 + 1 < d.NX - 1 ? p1 + 1 : d.NX - 1;
-
     // ---- prologue: planes i_start .. i_start+RING-1 issued, all retired once ---------------------------
     // ring slot of plane i is (i - i_start) mod RING
 #pragma unroll
@@ -375,7 +469,7 @@ __global__ void __launch_bounds__(64 * dma::TY) k_apply_dma(Dims d, DmArgs2 dm, 
             // counted wait: after plane ii+1's DMA this wave issued the stores of phases ii-2 and ii-1 and the DMA of
             // planes ii+2 and ii+3; outside that steady state (start / end of the chunk) drain everything
             const bool steady = (phase >= PD - 1) && (ii + PD <= i_end) && (ii - PD >= p0);
-            if (cnt == 2) wait_plane<2>(has_stores, steady); else wait_plane<3>(has_stores, steady);
+            if (NW == 0) { if (cnt == 2) wait_plane<2>(has_stores, steady); else wait_plane<3>(has_stores, steady); }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -412,7 +506,7 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
     if (np >= 1024) nchunks = 16;
     if (g_dma_chunks > 0 && np >= 4 * g_dma_chunks) nchunks = g_dma_chunks;
     const int ppc = (np + nchunks - 1) / nchunks;
-    dim3 blk(TZ, TY, 1), grd((np + ppc - 1) / ppc, (d.NZ + TZ - 2) / (TZ - 1), (d.NY + TY - 2) / (TY - 1));
+    dim3 blk(TZ, TY + NW, 1), grd((np + ppc - 1) / ppc, (d.NZ + TZ - 2) / (TZ - 1), (d.NY + TY - 2) / (TY - 1));
     static bool attr = false;
     if (!attr) {
         VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
@@ -425,6 +519,7 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
         VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
         VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
         VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
         VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
         attr = true;
     }
@@ -443,6 +538,7 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
         case 8: VFEM_DMA_LAUNCH(8); break;
         case 9: VFEM_DMA_LAUNCH(9); break;
         case 10: VFEM_DMA_LAUNCH(10); break;
+        case 11: VFEM_DMA_LAUNCH(11); break;
         default: VFEM_DMA_LAUNCH(0);
     }
     VFEM_HIP(hipGetLastError());

@@ -274,6 +274,241 @@ void launch_apply_q2_pencil(int nx, int ny, int nz, const double *tab, const dou
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Marching kernel: the pencil kernel turned into an x-march.
+//
+// A wave owns (ey, a chunk of 63 elements in z) and walks ex through one x-chunk.  The node plane an element shares with its
+// successor in x never leaves the wave: its raw values (`keep`) are the a = 0 inputs of the next step and its output
+// contributions (`carry`) are added to the next step's a = 0 rows before those are stored, so per step only six u rows are
+// read and six finished out rows are written, and only the y direction still needs colours (2 launches instead of 4; the
+// second one read-modify-writes the two rows per plane it shares with its y-neighbours).  Lane 0 recomputes the last element of
+// the z-chunk below (its top-plane contributions reach lane 1 by the same one-lane shift as inside a chunk), and an x-chunk
+// that does not start at the domain face first runs the element in front of it for its carry only -- no exchange between waves.
+// The loads of step ex+1 (six u rows, the rows to be read-modify-written, the modulus) are issued before the arithmetic of step ex.
+// Traffic per voxel: 6 u rows + 6 out-row writes + 2 out-row reads (average over the colours) = 680 B against 393 B algorithmic.
+// ------------------------------------------------------------------------------------------------------
+constexpr int Q2M_ZS = 63;                                   // elements a wave completes per step
+
+__device__ __forceinline__ const double *q2_row(const double *base, const DimsQ2 &d, int X, int Y) {
+    const long long ro = 3LL * (((long long) X * d.NY + Y) * d.NZ);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) (ro & 0xffffffffLL));
+    const int hi = __builtin_amdgcn_readfirstlane((int) (ro >> 32));
+    return base + (((long long) hi << 32) | (long long) lo);
+}
+
+// in-place element product in reflection-mode space: v <- Ee * K0 v (81 values, node-major 3 components)
+__device__ __forceinline__ void q2_element_product(double (&v)[81], const double *tab, double Ee) {
+    static_for<27>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, g = t / 3, c = t % 3;
+        const double v0 = v[3 * (3 * g) + c], v2 = v[3 * (3 * g + 2) + c];
+        v[3 * (3 * g) + c] = v0 + v2; v[3 * (3 * g + 2) + c] = v2 - v0;
+    });
+    static_for<27>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, g = t / 3, c = t % 3, a = g / 3, cz = g % 3;
+        const double v0 = v[3 * (9 * a + cz) + c], v2 = v[3 * (9 * a + 6 + cz) + c];
+        v[3 * (9 * a + cz) + c] = v0 + v2; v[3 * (9 * a + 6 + cz) + c] = v2 - v0;
+    });
+    static_for<27>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, g = t / 3, c = t % 3;
+        const double v0 = v[3 * g + c], v2 = v[3 * (18 + g) + c];
+        v[3 * g + c] = v0 + v2; v[3 * (18 + g) + c] = v2 - v0;
+    });
+    static_for<8>([&](auto pc) {
+        constexpr int P = decltype(pc)::value, n = Q2C.n[P];
+        double z[12];
+        static_for<n>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            d8_t c0;
+            d4_t c1;
+            sload12(tab, (Q2C.rowbase[P] + i) * 96, c0, c1);
+            double acc = 0.0;
+            static_for<n>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                acc = fma(j < 8 ? c0[j < 8 ? j : 0] : c1[j < 8 ? 0 : j - 8], v[Q2C.idx[P][j]], acc);
+            });
+            z[i] = acc;
+            asm volatile("" : "+v"(z[i]));
+        });
+        static_for<n>([&](auto ic) { constexpr int i = decltype(ic)::value; v[Q2C.idx[P][i]] = Ee * z[i]; });
+    });
+    static_for<27>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, g = t / 3, c = t % 3;
+        const double zs = v[3 * g + c], za = v[3 * (18 + g) + c];
+        v[3 * g + c] = zs - za; v[3 * (18 + g) + c] = zs + za;
+    });
+    static_for<27>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, g = t / 3, c = t % 3, a = g / 3, cz = g % 3;
+        const double zs = v[3 * (9 * a + cz) + c], za = v[3 * (9 * a + 6 + cz) + c];
+        v[3 * (9 * a + cz) + c] = zs - za; v[3 * (9 * a + 6 + cz) + c] = zs + za;
+    });
+    static_for<27>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, g = t / 3, c = t % 3;
+        const double zs = v[3 * (3 * g) + c], za = v[3 * (3 * g + 2) + c];
+        v[3 * (3 * g) + c] = zs - za; v[3 * (3 * g + 2) + c] = zs + za;
+    });
+}
+
+__global__ void __launch_bounds__(256) k_apply_q2_march(DimsQ2 d, const double *__restrict__ tab, const double *__restrict__ E,
+                                                        const double *__restrict__ u, double *__restrict__ out, int cy, int xsteps) {
+    __shared__ double lds[4][Q2_BUF];
+    __shared__ double ldso[4][4 * 384];                       // partial sums already in `out`: rows (rx, ry) = (0,0) (0,2) (1,0) (1,2)
+    __shared__ double ldsk[4][27 * 64];                       // `carry`: contributions to the node plane shared with the next step
+    const int lane = threadIdx.x, wy = threadIdx.y;
+    const int ey = 2 * (blockIdx.y * 4 + wy) + cy;
+    if (ey >= d.ny) return;                                   // wave-uniform; no block-level barrier below
+    double *carry = ldsk[wy] + lane;                          // element t of this lane at carry[64 t]
+    const int xa = blockIdx.z * xsteps;
+    const int xb = xa + xsteps < d.nx ? xa + xsteps : d.nx;
+    double *buf = lds[wy], *obuf = ldso[wy];
+    const int zb = Q2M_ZS * blockIdx.x - 1;                   // element of lane 0 (-1 in the first chunk: a dummy with zero modulus)
+    const int ez = zb + lane;
+    const bool elem_ok = ez >= 0 && ez < d.nz;
+    const int ezc = ez < 0 ? 0 : (ez > d.nz - 1 ? d.nz - 1 : ez);
+    const long long rowlen = 3LL * d.NZ;
+    const long long seg = 6LL * zb;                           // first double of the chunk inside a node row (-6 in the first chunk)
+    int qa[7];                                                // this lane's doubles of a row segment (absolute inside the row, clamped)
+#pragma unroll
+    for (int s7 = 0; s7 < 7; ++s7) {
+        long long q = seg + lane + 64 * s7;
+        q = q < 0 ? 0 : (q > rowlen - 1 ? rowlen - 1 : q);
+        qa[s7] = (int) q;
+    }
+    // rows shared with a y-neighbour hold that neighbour's partial sum when it ran in the earlier launch (cy = 0 runs first)
+    const bool rmw0 = cy == 1, rmw2 = cy == 1 && ey + 1 < d.ny;
+
+    double v[81], keep[27], pre[6][7], pre_o[4][6], Enext = 0.0;
+    auto rows_to_regs = [&](auto &dst, const double *rowp) {
+#pragma unroll
+        for (int s7 = 0; s7 < 7; ++s7) dst[s7] = rowp[qa[s7]];
+    };
+    auto issue_loads = [&](int ex, bool with_rmw) {
+        static_for<6>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            rows_to_regs(pre[r], q2_row(u, d, 2 * ex + 1 + r / 3, 2 * ey + r % 3));
+        });
+        Enext = E[((long long) ex * d.ny + ey) * d.nz + ezc];
+    };
+    // one row segment -> the nine values (3 nodes x 3 components) of every lane's element
+    auto transpose_in = [&](const double (&src)[7], double *dst9) {
+#pragma unroll
+        for (int s7 = 0; s7 < 7; ++s7) buf[lane + 64 * s7] = src[s7];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 9; ++q) dst9[q] = buf[6 * lane + q];
+        __builtin_amdgcn_wave_barrier();
+    };
+    // store one finished row: bottom and middle node of lanes 1..63; `add9` = the lane's 9 values of the row
+    auto store_row = [&](int X, int ry, const double *add9, bool rmw, const double *old) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) buf[6 * lane + q] = add9[q];
+        __builtin_amdgcn_wave_barrier();
+        double *rowp = const_cast<double *>(q2_row(out, d, X, 2 * ey + ry));
+#pragma unroll
+        for (int s6 = 0; s6 < 6; ++s6) {
+            const int q = lane + 64 * s6;
+            const long long qabs = seg + q;
+            if (q >= 6 && qabs < rowlen - 3) {                // lane 0 belongs to the chunk below; the final node plane is written apart
+                const double add = buf[q];
+                rowp[qabs] = rmw ? old[q] + add : add;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (ez == d.nz - 1) {                                 // the last element of the pencil also owns the final node plane (z = 2 nz)
+            double *np = rowp + 3LL * 2 * d.nz;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) np[c] = rmw ? np[c] + add9[6 + c] : add9[6 + c];
+        }
+    };
+
+    const int e0 = xa > 0 ? xa - 1 : xa;
+    {   // raw values of the first node plane
+        double first[3][7];
+        static_for<3>([&](auto rc) { constexpr int r = decltype(rc)::value; rows_to_regs(first[r], q2_row(u, d, 2 * e0, 2 * ey + r)); });
+        static_for<3>([&](auto rc) { constexpr int r = decltype(rc)::value; transpose_in(first[r], &keep[9 * r]); });
+    }
+#pragma unroll
+    for (int t = 0; t < 27; ++t) carry[64 * t] = 0.0;
+    issue_loads(e0, e0 >= xa);
+
+    for (int ex = e0; ex < xb; ++ex) {
+        const bool store = ex >= xa;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) v[t] = keep[t];
+        static_for<6>([&](auto rc) { constexpr int r = decltype(rc)::value; transpose_in(pre[r], &v[27 + 9 * r]); });
+        const double Ee = elem_ok ? Enext : 0.0;
+        if (ex + 1 < xb) issue_loads(ex + 1, true);
+#pragma unroll
+        for (int t = 0; t < 27; ++t) keep[t] = v[54 + t];
+        if (store) {                                          // partial sums of the earlier colour: requested now, parked in LDS after the arithmetic
+            static_for<4>([&](auto rc) {
+                constexpr int r = decltype(rc)::value, rx = r / 2, ry = 2 * (r % 2);
+                if (ry == 0 ? rmw0 : rmw2) {
+                    const double *rowp = q2_row(out, d, 2 * ex + rx, 2 * ey + ry);
+#pragma unroll
+                    for (int s6 = 0; s6 < 6; ++s6) pre_o[r][s6] = rowp[qa[s6]];
+                }
+            });
+        }
+
+        q2_element_product(v, tab, Ee);
+
+        // node plane shared with the next element in z: one lane up (lane 0 is the element of the chunk below, its rows are not stored)
+        static_for<27>([&](auto tc) {
+            constexpr int t = decltype(tc)::value, g = t / 3, c = t % 3;
+            const double up = __shfl_up(v[3 * (3 * g + 2) + c], 1);
+            v[3 * (3 * g) + c] += lane == 0 ? 0.0 : up;
+        });
+        // node plane shared with the previous element in x: what that step left; this step's last plane waits for the next one
+#pragma unroll
+        for (int t = 0; t < 27; ++t) { v[t] += carry[64 * t]; carry[64 * t] = v[54 + t]; }
+        if (store) {
+            static_for<4>([&](auto rc) {
+                constexpr int r = decltype(rc)::value, ry = 2 * (r % 2);
+                if (ry == 0 ? rmw0 : rmw2) {
+#pragma unroll
+                    for (int s6 = 0; s6 < 6; ++s6) obuf[r * 384 + lane + 64 * s6] = pre_o[r][s6];
+                }
+            });
+            __builtin_amdgcn_wave_barrier();
+            static_for<6>([&](auto rc) {
+                constexpr int g = decltype(rc)::value, rx = g / 3, ry = g % 3;
+                const bool rmw = ry == 0 ? rmw0 : (ry == 2 ? rmw2 : false);
+                store_row(2 * ex + rx, ry, &v[9 * g], rmw, obuf + (2 * rx + ry / 2) * 384);
+            });
+        }
+    }
+    if (xb == d.nx) {                                         // the domain face: the last node plane is complete as it is
+        static_for<3>([&](auto rc) {
+            constexpr int ry = decltype(rc)::value;
+            const bool rmw = ry == 0 ? rmw0 : (ry == 2 ? rmw2 : false);
+            if (rmw) {
+                const double *rowp = q2_row(out, d, 2 * d.nx, 2 * ey + ry);
+#pragma unroll
+                for (int s6 = 0; s6 < 6; ++s6) obuf[lane + 64 * s6] = rowp[qa[s6]];
+                __builtin_amdgcn_wave_barrier();
+            }
+            double last9[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) last9[q] = carry[64 * (9 * ry + q)];
+            store_row(2 * d.nx, ry, last9, rmw, obuf);
+        });
+    }
+}
+
+void launch_apply_q2_march(int nx, int ny, int nz, const double *tab, const double *E, const double *u, double *out, hipStream_t s) {
+    DimsQ2 d{nx, ny, nz, 2 * nx + 1, 2 * ny + 1, 2 * nz + 1};
+    const int nchunk = (nz + Q2M_ZS - 1) / Q2M_ZS;
+    int nxc = nx >= 256 ? 8 : (nx >= 64 ? 4 : (nx >= 16 ? 2 : 1));
+    const int xsteps = (nx + nxc - 1) / nxc;
+    nxc = (nx + xsteps - 1) / xsteps;
+    for (int cy = 0; cy < 2; ++cy) {
+        if (cy > ny - 1) continue;
+        const int cnty = (ny - 1 - cy) / 2 + 1;
+        k_apply_q2_march<<<dim3(nchunk, (cnty + 3) / 4, nxc), dim3(64, 4, 1), 0, s>>>(d, tab, E, u, out, cy, xsteps);
+    }
+    VFEM_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------
 // One colour of the 27-colour block Gauss-Seidel sweep on the finest degree-2 level (MG.hh:193-340 with Degrees = 2,2,2):
 // one thread per node of the colour (colour = local node index; per axis nodes start at the local index and advance by one
 // element for the mid node, by two for a boundary node).  All nodes of a colour have the same local index in each of their

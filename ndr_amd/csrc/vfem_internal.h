@@ -126,6 +126,7 @@ void launch_sum(long long n, const double *a, double *scratch, double *out, hipS
 
 void launch_apply_q2(int nx, int ny, int nz, const double *K0, const double *E, const double *u, double *out, hipStream_t s);
 void launch_apply_q2_pencil(int nx, int ny, int nz, const double *mode_table, const double *E, const double *u, double *out, hipStream_t s);
+void launch_apply_q2_march(int nx, int ny, int nz, const double *mode_table, const double *E, const double *u, double *out, hipStream_t s);
 void launch_gs_sweep_q2_level0(int nx, int ny, int nz, const double *K0, const double *E, double *u, const double *b,
                                const uint8_t *mask, int forward, hipStream_t s);
 void launch_q2_residual_fix(long long nn, const double *b, const uint8_t *mask, int mode, double *out, hipStream_t s);

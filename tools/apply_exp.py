@@ -12,7 +12,7 @@ g = torch.Generator(device="cuda").manual_seed(88)
 tps.setElementDensities(torch.rand(tps.numElements(), dtype=torch.float64, device="cuda", generator=g))
 u = torch.randn((tps.numNodes(), 3), dtype=torch.float64, device="cuda", generator=g)
 out = torch.empty_like(u)
-names = {0: "production", 1: "no scatter LDS", 2: "no Dm compute", 3: "no compute, no scatter", 4: "no compute/scatter/u reads", 5: "DMA loads + barriers only", 6: "stores + barriers only", 7: "stores only, non-temporal", 8: "production, non-temporal stores", 9: "skeleton, stores to 2 planes", 10: "skeleton, loads from 4 planes"}
+names = {0: "production", 1: "no scatter LDS", 2: "no Dm compute", 3: "no compute, no scatter", 4: "no compute/scatter/u reads", 5: "DMA loads + barriers only", 6: "stores + barriers only", 7: "stores only, non-temporal", 8: "production, non-temporal stores", 9: "skeleton, stores to 2 planes", 10: "skeleton, loads from 4 planes", 11: "stores only, row-contiguous 16 B"}
 ref = None
 for exp in [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4, 0]:
     lib.vfem_debug_set(1, exp)
