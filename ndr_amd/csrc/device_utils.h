@@ -42,10 +42,34 @@ __device__ __forceinline__ void sload12(const double *p, int byte_off, d8_t &a, 
 }
 
 
+// Split form of sload12 for software pipelining: the request leaves the load in flight, so the destination registers must
+// stay allocated (and untouched) until sload12_wait, which takes them as read-write operands.  That holds only while the
+// allocator does not spill them: a kernel using the pair must show no SGPR spill of these values (tools/check_sload_pipeline.py
+// scans the ISA for any instruction that touches the destination registers between a request and its wait).
+// `order` is a value the arithmetic that should overlap the load starts from: tying it to the request keeps the
+// scheduler from sinking the request below that arithmetic.
+__device__ __forceinline__ void sload12_issue(const double *p, int byte_off, d8_t &a, d4_t &b, double &order) {
+    asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx8 %1, %3, %5"
+                 : "=&s"(a), "=&s"(b), "+v"(order) : "s"(p), "s"(byte_off), "s"(byte_off + 64));
+}
+__device__ __forceinline__ void sload12_wait(d8_t &a, d4_t &b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b));
+}
+
+
 // one row (24 doubles) of a wave-uniform table, requested and awaited inside one asm statement (see sload12)
 __device__ __forceinline__ void sload24(const double *p, int byte_off, d8_t &a, d8_t &b, d8_t &c) {
     asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %5\n\ts_load_dwordx16 %2, %3, %6\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(a), "=&s"(b), "=&s"(c) : "s"(p), "s"(byte_off), "s"(byte_off + 64), "s"(byte_off + 128));
+}
+
+
+// value held by the previous lane of the wave (lane 0 receives 0): DPP wave shift, two 32-bit moves per double, no LDS
+__device__ __forceinline__ double lane_below(double v) {
+    const unsigned long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned) (b & 0xffffffffull), 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned) (b >> 32), 0x138, 0xf, 0xf, true);
+    return __longlong_as_double(((unsigned long long) hi << 32) | lo);
 }
 
 

@@ -14,6 +14,7 @@
 // pieces never straddle the 16-byte-aligned end of an allocation, so nothing outside the caller's buffers is read;
 // a row image starts at node max(k0, 0) so that no address precedes the array.
 #include "vfem_internal.h"
+#include "device_utils.h"
 #include <type_traits>
 
 namespace vfem {
@@ -64,14 +65,6 @@ __device__ __forceinline__ void wait_plane(bool has_stores, bool steady) {
     if (!steady) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
     if (has_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * (CNT + 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * CNT) : "memory");
-}
-
-// value held by the previous lane of the wave (lane 0 receives 0): DPP wave shift, two 32-bit moves per double, no LDS
-__device__ __forceinline__ double lane_below(double v) {
-    const unsigned long long b = __double_as_longlong(v);
-    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned) (b & 0xffffffffull), 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned) (b >> 32), 0x138, 0xf, 0xf, true);
-    return __longlong_as_double(((unsigned long long) hi << 32) | lo);
 }
 
 template <int EXP>

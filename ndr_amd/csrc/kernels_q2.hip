@@ -279,12 +279,13 @@ void launch_apply_q2_pencil(int nx, int ny, int nz, const double *tab, const dou
 // A wave owns (ey, a chunk of 63 elements in z) and walks ex through one x-chunk.  The node plane an element shares with its
 // successor in x never leaves the wave: its raw values (`keep`) are the a = 0 inputs of the next step and its output
 // contributions (`carry`) are added to the next step's a = 0 rows before those are stored, so per step only six u rows are
-// read and six finished out rows are written, and only the y direction still needs colours (2 launches instead of 4; the
-// second one read-modify-writes the two rows per plane it shares with its y-neighbours).  Lane 0 recomputes the last element of
+// read and at most six finished out rows are written.  The four waves of a block own four consecutive element rows in y: a wave
+// hands the rows it shares with the wave above to that wave through LDS (one block barrier per step), so only blocks still need
+// colours in y (2 launches; the second one read-modify-writes the two rows per plane it shares with the blocks next to it).  Lane 0 recomputes the last element of
 // the z-chunk below (its top-plane contributions reach lane 1 by the same one-lane shift as inside a chunk), and an x-chunk
 // that does not start at the domain face first runs the element in front of it for its carry only -- no exchange between waves.
 // The loads of step ex+1 (six u rows, the rows to be read-modify-written, the modulus) are issued before the arithmetic of step ex.
-// Traffic per voxel: 6 u rows + 6 out-row writes + 2 out-row reads (average over the colours) = 680 B against 393 B algorithmic.
+// Traffic per voxel: 4.5 u rows (shared rows once per block) + 4.5 out-row writes + 0.5 out-row reads = 464 B against 393 B algorithmic.
 // ------------------------------------------------------------------------------------------------------
 constexpr int Q2M_ZS = 63;                                   // elements a wave completes per step
 
@@ -296,7 +297,13 @@ __device__ __forceinline__ const double *q2_row(const double *base, const DimsQ2
 }
 
 // in-place element product in reflection-mode space: v <- Ee * K0 v (81 values, node-major 3 components)
+constexpr int q2_row_class(int r) { int P = 0; while (P < 7 && r >= Q2C.rowbase[P + 1]) ++P; return P; }
+
+// TABLE 0: one scalar-load round trip per coefficient row; 1: rows read from LDS; 2: scalar loads, the next row requested
+// while the current one is multiplied (the wave runs alone on its SIMD, nothing else hides the round trip)
+template <int TABLE>
 __device__ __forceinline__ void q2_element_product(double (&v)[81], const double *tab, double Ee) {
+    constexpr bool LDS_TABLE = TABLE == 1;
     static_for<27>([&](auto tc) {
         constexpr int t = decltype(tc)::value, g = t / 3, c = t % 3;
         const double v0 = v[3 * (3 * g) + c], v2 = v[3 * (3 * g + 2) + c];
@@ -312,21 +319,51 @@ __device__ __forceinline__ void q2_element_product(double (&v)[81], const double
         const double v0 = v[3 * g + c], v2 = v[3 * (18 + g) + c];
         v[3 * g + c] = v0 + v2; v[3 * (18 + g) + c] = v2 - v0;
     });
-    static_for<8>([&](auto pc) {
-        constexpr int P = decltype(pc)::value, n = Q2C.n[P];
+    if constexpr (TABLE == 2) {
+        d8_t A0, B0;
+        d4_t A1, B1;
         double z[12];
-        static_for<n>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            d8_t c0;
-            d4_t c1;
-            sload12(tab, (Q2C.rowbase[P] + i) * 96, c0, c1);
+        sload12_issue(tab, 0, A0, A1, v[0]);
+        auto one_row = [&](auto rc, d8_t &c0, d4_t &c1, d8_t &n0, d4_t &n1) {
+            constexpr int r = decltype(rc)::value, P = q2_row_class(r), n = Q2C.n[P], i = r - Q2C.rowbase[P];
+            sload12_wait(c0, c1);
             double acc = 0.0;
+            if constexpr (r + 1 < Q2_TABLE_ROWS) sload12_issue(tab, (r + 1) * 96, n0, n1, acc);
             static_for<n>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 acc = fma(j < 8 ? c0[j < 8 ? j : 0] : c1[j < 8 ? 0 : j - 8], v[Q2C.idx[P][j]], acc);
             });
             z[i] = acc;
             asm volatile("" : "+v"(z[i]));
+            if constexpr (i == n - 1)
+                static_for<n>([&](auto ic) { constexpr int ii = decltype(ic)::value; v[Q2C.idx[P][ii]] = Ee * z[ii]; });
+        };
+        static_for<Q2_TABLE_ROWS>([&](auto rc) {
+            if constexpr (decltype(rc)::value % 2 == 0) one_row(rc, A0, A1, B0, B1);
+            else one_row(rc, B0, B1, A0, A1);
+        });
+    } else
+    static_for<8>([&](auto pc) {
+        constexpr int P = decltype(pc)::value, n = Q2C.n[P];
+        double z[12];
+        static_for<n>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            double acc = 0.0;
+            if constexpr (LDS_TABLE) {                       // same address in every lane (broadcast); the compiler pipelines the reads
+                const double *row = tab + (Q2C.rowbase[P] + i) * 12;
+                static_for<n>([&](auto jc) { constexpr int j = decltype(jc)::value; acc = fma(row[j], v[Q2C.idx[P][j]], acc); });
+                z[i] = acc;
+            } else {
+                d8_t c0;
+                d4_t c1;
+                sload12(tab, (Q2C.rowbase[P] + i) * 96, c0, c1);
+                static_for<n>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    acc = fma(j < 8 ? c0[j < 8 ? j : 0] : c1[j < 8 ? 0 : j - 8], v[Q2C.idx[P][j]], acc);
+                });
+                z[i] = acc;
+                asm volatile("" : "+v"(z[i]));
+            }
         });
         static_for<n>([&](auto ic) { constexpr int i = decltype(ic)::value; v[Q2C.idx[P][i]] = Ee * z[i]; });
     });
@@ -347,14 +384,22 @@ __device__ __forceinline__ void q2_element_product(double (&v)[81], const double
     });
 }
 
+constexpr int Q2M_OB = 448;                                   // doubles per parked row segment (7 x 64)
+
+template <int EXP>      // 0 production; timing ablations (wrong results): 1 no element product, 2 no row stores, 3 no row loads
 __global__ void __launch_bounds__(256) k_apply_q2_march(DimsQ2 d, const double *__restrict__ tab, const double *__restrict__ E,
-                                                        const double *__restrict__ u, double *__restrict__ out, int cy, int xsteps) {
+                                                        const double *__restrict__ u, double *__restrict__ out, int cb, int xsteps) {
     __shared__ double lds[4][Q2_BUF];
-    __shared__ double ldso[4][4 * 384];                       // partial sums already in `out`: rows (rx, ry) = (0,0) (0,2) (1,0) (1,2)
+    // sums a row already holds when this wave stores it: [wave][2 par + rx] for the rows ry = 0 (what the wave below left, or, for
+    // wave 0 of a block of the second colour, what the block below wrote to `out`), [wave][4 + rx] for the rows ry = 2 of wave 3
+    __shared__ double ldso[4][6 * Q2M_OB];
     __shared__ double ldsk[4][27 * 64];                       // `carry`: contributions to the node plane shared with the next step
     const int lane = threadIdx.x, wy = threadIdx.y;
-    const int ey = 2 * (blockIdx.y * 4 + wy) + cy;
-    if (ey >= d.ny) return;                                   // wave-uniform; no block-level barrier below
+    const int B = 2 * blockIdx.y + cb;                        // block of four consecutive element rows in y
+    if (4 * B >= d.ny) return;                                // block-uniform
+    const int ey = 4 * B + wy;
+    const bool active = ey < d.ny;                            // idle waves only keep the barriers company
+    const int eyc = active ? ey : d.ny - 1;
     double *carry = ldsk[wy] + lane;                          // element t of this lane at carry[64 t]
     const int xa = blockIdx.z * xsteps;
     const int xb = xa + xsteps < d.nx ? xa + xsteps : d.nx;
@@ -372,20 +417,25 @@ __global__ void __launch_bounds__(256) k_apply_q2_march(DimsQ2 d, const double *
         q = q < 0 ? 0 : (q > rowlen - 1 ? rowlen - 1 : q);
         qa[s7] = (int) q;
     }
-    // rows shared with a y-neighbour hold that neighbour's partial sum when it ran in the earlier launch (cy = 0 runs first)
-    const bool rmw0 = cy == 1, rmw2 = cy == 1 && ey + 1 < d.ny;
+    // who else adds to this wave's shared rows: the waves of a block hand their ry = 2 rows to the wave above through LDS; across
+    // blocks the second colour (cb = 1, launched after cb = 0) reads what its neighbours wrote to `out`
+    const bool from_below = wy >= 1;                          // rows ry = 0: the wave below (always active when this one is)
+    const bool rmw0 = wy == 0 && cb == 1;                     // rows ry = 0 of wave 0: block B - 1 ran in the first launch
+    const bool hand_up = active && wy < 3 && ey + 1 < d.ny;   // rows ry = 2 go to the wave above instead of to memory
+    const bool rmw2 = wy == 3 && cb == 1 && ey + 1 < d.ny;    // rows ry = 2 of wave 3: block B + 1 ran in the first launch
 
-    double v[81], keep[27], pre[6][7], pre_o[4][6], Enext = 0.0;
+    double v[81], keep[27], pre[6][7], pre_o[2][7], Enext = 0.0;
     auto rows_to_regs = [&](auto &dst, const double *rowp) {
 #pragma unroll
         for (int s7 = 0; s7 < 7; ++s7) dst[s7] = rowp[qa[s7]];
     };
-    auto issue_loads = [&](int ex, bool with_rmw) {
+    auto issue_loads = [&](int ex) {
+        if (EXP == 3) { Enext = E[((long long) ex * d.ny + eyc) * d.nz + ezc]; return; }
         static_for<6>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
-            rows_to_regs(pre[r], q2_row(u, d, 2 * ex + 1 + r / 3, 2 * ey + r % 3));
+            rows_to_regs(pre[r], q2_row(u, d, 2 * ex + 1 + r / 3, 2 * eyc + r % 3));
         });
-        Enext = E[((long long) ex * d.ny + ey) * d.nz + ezc];
+        Enext = E[((long long) ex * d.ny + eyc) * d.nz + ezc];
     };
     // one row segment -> the nine values (3 nodes x 3 components) of every lane's element
     auto transpose_in = [&](const double (&src)[7], double *dst9) {
@@ -396,101 +446,129 @@ __global__ void __launch_bounds__(256) k_apply_q2_march(DimsQ2 d, const double *
         for (int q = 0; q < 9; ++q) dst9[q] = buf[6 * lane + q];
         __builtin_amdgcn_wave_barrier();
     };
-    // store one finished row: bottom and middle node of lanes 1..63; `add9` = the lane's 9 values of the row
-    auto store_row = [&](int X, int ry, const double *add9, bool rmw, const double *old) {
+    // hand a row to the wave above: bottom and middle node of every lane, and the final node plane from the last element
+    auto deposit_row = [&](double *dst, const double *add9) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dst[6 * lane + q] = add9[q];
+        if (ez == d.nz - 1) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dst[6 * lane + 6 + c] = add9[6 + c];
+        }
+    };
+    // store one finished row: bottom and middle node of lanes 1..63; `add9` = the lane's 9 values of the row, `old` = parked sums
+    auto store_row = [&](int X, int ry, const double *add9, bool has_old, const double *old) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) buf[6 * lane + q] = add9[q];
         __builtin_amdgcn_wave_barrier();
-        double *rowp = const_cast<double *>(q2_row(out, d, X, 2 * ey + ry));
+        double *rowp = const_cast<double *>(q2_row(out, d, X, 2 * eyc + ry));
+        double w6[6];                                         // all LDS reads first, then the stores
+#pragma unroll
+        for (int s6 = 0; s6 < 6; ++s6) w6[s6] = buf[lane + 64 * s6];
+        if (has_old) {
+#pragma unroll
+            for (int s6 = 0; s6 < 6; ++s6) w6[s6] += old[lane + 64 * s6];
+        }
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int s6 = 0; s6 < 6; ++s6) {
             const int q = lane + 64 * s6;
             const long long qabs = seg + q;
-            if (q >= 6 && qabs < rowlen - 3) {                // lane 0 belongs to the chunk below; the final node plane is written apart
-                const double add = buf[q];
-                rowp[qabs] = rmw ? old[q] + add : add;
-            }
+            if (q >= 6 && qabs < rowlen - 3) rowp[qabs] = w6[s6];   // lane 0 belongs to the chunk below; the final node plane is written apart
         }
-        __builtin_amdgcn_wave_barrier();
         if (ez == d.nz - 1) {                                 // the last element of the pencil also owns the final node plane (z = 2 nz)
             double *np = rowp + 3LL * 2 * d.nz;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) np[c] = rmw ? np[c] + add9[6 + c] : add9[6 + c];
+            for (int c = 0; c < 3; ++c) np[c] = has_old ? old[6 * lane + 6 + c] + add9[6 + c] : add9[6 + c];
         }
     };
 
     const int e0 = xa > 0 ? xa - 1 : xa;
-    {   // raw values of the first node plane
+    if (active) {   // raw values of the first node plane
         double first[3][7];
         static_for<3>([&](auto rc) { constexpr int r = decltype(rc)::value; rows_to_regs(first[r], q2_row(u, d, 2 * e0, 2 * ey + r)); });
         static_for<3>([&](auto rc) { constexpr int r = decltype(rc)::value; transpose_in(first[r], &keep[9 * r]); });
+#pragma unroll
+        for (int t = 0; t < 27; ++t) carry[64 * t] = 0.0;
+        issue_loads(e0);
     }
-#pragma unroll
-    for (int t = 0; t < 27; ++t) carry[64 * t] = 0.0;
-    issue_loads(e0, e0 >= xa);
 
+    int par = 0;
     for (int ex = e0; ex < xb; ++ex) {
-        const bool store = ex >= xa;
+        const bool store = ex >= xa;                          // block-uniform
+        if (active) {
 #pragma unroll
-        for (int t = 0; t < 27; ++t) v[t] = keep[t];
-        static_for<6>([&](auto rc) { constexpr int r = decltype(rc)::value; transpose_in(pre[r], &v[27 + 9 * r]); });
-        const double Ee = elem_ok ? Enext : 0.0;
-        if (ex + 1 < xb) issue_loads(ex + 1, true);
+            for (int t = 0; t < 27; ++t) v[t] = keep[t];
+            static_for<6>([&](auto rc) { constexpr int r = decltype(rc)::value; transpose_in(pre[r], &v[27 + 9 * r]); });
+            const double Ee = elem_ok ? Enext : 0.0;
+            if (ex + 1 < xb) issue_loads(ex + 1);
 #pragma unroll
-        for (int t = 0; t < 27; ++t) keep[t] = v[54 + t];
-        if (store) {                                          // partial sums of the earlier colour: requested now, parked in LDS after the arithmetic
-            static_for<4>([&](auto rc) {
-                constexpr int r = decltype(rc)::value, rx = r / 2, ry = 2 * (r % 2);
-                if (ry == 0 ? rmw0 : rmw2) {
-                    const double *rowp = q2_row(out, d, 2 * ex + rx, 2 * ey + ry);
-#pragma unroll
-                    for (int s6 = 0; s6 < 6; ++s6) pre_o[r][s6] = rowp[qa[s6]];
-                }
+            for (int t = 0; t < 27; ++t) keep[t] = v[54 + t];
+            if (store && (rmw0 || rmw2)) {                    // sums of the first colour: requested now, parked in LDS after the arithmetic
+                static_for<2>([&](auto rc) {
+                    constexpr int rx = decltype(rc)::value;
+                    rows_to_regs(pre_o[rx], q2_row(out, d, 2 * ex + rx, 2 * ey + (rmw0 ? 0 : 2)));
+                });
+            }
+
+            if (EXP != 1) q2_element_product<2>(v, tab, Ee);
+            else { v[0] *= Ee; }
+
+            // node plane shared with the next element in z: one lane up (lane 0 is the element of the chunk below, its rows are not stored)
+            static_for<27>([&](auto tc) {
+                constexpr int t = decltype(tc)::value, g = t / 3, c = t % 3;
+                v[3 * (3 * g) + c] += lane_below(v[3 * (3 * g + 2) + c]);
             });
+            // node plane shared with the previous element in x: what that step left; this step's last plane waits for the next one
+#pragma unroll
+            for (int t = 0; t < 27; ++t) { v[t] += carry[64 * t]; carry[64 * t] = v[54 + t]; }
+            if (store) {
+                if (rmw0 || rmw2) {
+                    static_for<2>([&](auto rc) {
+                        constexpr int rx = decltype(rc)::value;
+                        double *dst = obuf + (rmw0 ? 2 * par + rx : 4 + rx) * Q2M_OB;
+#pragma unroll
+                        for (int s7 = 0; s7 < 7; ++s7) dst[lane + 64 * s7] = pre_o[rx][s7];
+                    });
+                }
+                if (hand_up) {
+                    deposit_row(ldso[wy + 1] + (2 * par + 0) * Q2M_OB, &v[9 * 2]);
+                    deposit_row(ldso[wy + 1] + (2 * par + 1) * Q2M_OB, &v[9 * 5]);
+                }
+            }
         }
-
-        q2_element_product(v, tab, Ee);
-
-        // node plane shared with the next element in z: one lane up (lane 0 is the element of the chunk below, its rows are not stored)
-        static_for<27>([&](auto tc) {
-            constexpr int t = decltype(tc)::value, g = t / 3, c = t % 3;
-            const double up = __shfl_up(v[3 * (3 * g + 2) + c], 1);
-            v[3 * (3 * g) + c] += lane == 0 ? 0.0 : up;
-        });
-        // node plane shared with the previous element in x: what that step left; this step's last plane waits for the next one
-#pragma unroll
-        for (int t = 0; t < 27; ++t) { v[t] += carry[64 * t]; carry[64 * t] = v[54 + t]; }
         if (store) {
-            static_for<4>([&](auto rc) {
-                constexpr int r = decltype(rc)::value, ry = 2 * (r % 2);
-                if (ry == 0 ? rmw0 : rmw2) {
-#pragma unroll
-                    for (int s6 = 0; s6 < 6; ++s6) obuf[r * 384 + lane + 64 * s6] = pre_o[r][s6];
-                }
-            });
-            __builtin_amdgcn_wave_barrier();
-            static_for<6>([&](auto rc) {
-                constexpr int g = decltype(rc)::value, rx = g / 3, ry = g % 3;
-                const bool rmw = ry == 0 ? rmw0 : (ry == 2 ? rmw2 : false);
-                store_row(2 * ex + rx, ry, &v[9 * g], rmw, obuf + (2 * rx + ry / 2) * 384);
-            });
+            __syncthreads();                                  // the rows handed up are in place (double-buffered by step parity)
+            if (active && EXP == 2) { if (v[5] == 1.2345) out[0] = v[7]; }
+            if (active && EXP != 2) {
+                static_for<6>([&](auto rc) {
+                    constexpr int g = decltype(rc)::value, rx = g / 3, ry = g % 3;
+                    if (ry == 0) store_row(2 * ex + rx, 0, &v[9 * g], from_below || rmw0, obuf + (2 * par + rx) * Q2M_OB);
+                    else if (ry == 1) store_row(2 * ex + rx, 1, &v[9 * g], false, obuf);
+                    else if (!hand_up) store_row(2 * ex + rx, 2, &v[9 * g], rmw2, obuf + (4 + rx) * Q2M_OB);
+                });
+            }
+            par ^= 1;
         }
     }
     if (xb == d.nx) {                                         // the domain face: the last node plane is complete as it is
-        static_for<3>([&](auto rc) {
-            constexpr int ry = decltype(rc)::value;
-            const bool rmw = ry == 0 ? rmw0 : (ry == 2 ? rmw2 : false);
-            if (rmw) {
-                const double *rowp = q2_row(out, d, 2 * d.nx, 2 * ey + ry);
+        double last[27];
+        if (active) {
 #pragma unroll
-                for (int s6 = 0; s6 < 6; ++s6) obuf[lane + 64 * s6] = rowp[qa[s6]];
-                __builtin_amdgcn_wave_barrier();
+            for (int t = 0; t < 27; ++t) last[t] = carry[64 * t];
+            if (rmw0 || rmw2) {
+                const double *rowp = q2_row(out, d, 2 * d.nx, 2 * ey + (rmw0 ? 0 : 2));
+                double *dst = obuf + (rmw0 ? 2 * par : 4) * Q2M_OB;
+#pragma unroll
+                for (int s7 = 0; s7 < 7; ++s7) dst[lane + 64 * s7] = rowp[qa[s7]];
             }
-            double last9[9];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) last9[q] = carry[64 * (9 * ry + q)];
-            store_row(2 * d.nx, ry, last9, rmw, obuf);
-        });
+            if (hand_up) deposit_row(ldso[wy + 1] + (2 * par) * Q2M_OB, &last[18]);
+        }
+        __syncthreads();
+        if (active) {
+            store_row(2 * d.nx, 0, &last[0], from_below || rmw0, obuf + (2 * par) * Q2M_OB);
+            store_row(2 * d.nx, 1, &last[9], false, obuf);
+            if (!hand_up) store_row(2 * d.nx, 2, &last[18], rmw2, obuf + 4 * Q2M_OB);
+        }
     }
 }
 
@@ -500,10 +578,18 @@ void launch_apply_q2_march(int nx, int ny, int nz, const double *tab, const doub
     int nxc = nx >= 256 ? 8 : (nx >= 64 ? 4 : (nx >= 16 ? 2 : 1));
     const int xsteps = (nx + nxc - 1) / nxc;
     nxc = (nx + xsteps - 1) / xsteps;
-    for (int cy = 0; cy < 2; ++cy) {
-        if (cy > ny - 1) continue;
-        const int cnty = (ny - 1 - cy) / 2 + 1;
-        k_apply_q2_march<<<dim3(nchunk, (cnty + 3) / 4, nxc), dim3(64, 4, 1), 0, s>>>(d, tab, E, u, out, cy, xsteps);
+    const int nblk = (ny + 3) / 4;                            // blocks of four element rows; even blocks first, then the odd ones
+    for (int cb = 0; cb < 2; ++cb) {
+        const int cnt = (nblk - cb + 1) / 2;
+        if (cnt <= 0) continue;
+        extern int g_apply_skeleton;
+        const dim3 grd(nchunk, cnt, nxc), blk(64, 4, 1);
+        switch (g_apply_skeleton) {
+            case 1: k_apply_q2_march<1><<<grd, blk, 0, s>>>(d, tab, E, u, out, cb, xsteps); break;
+            case 2: k_apply_q2_march<2><<<grd, blk, 0, s>>>(d, tab, E, u, out, cb, xsteps); break;
+            case 3: k_apply_q2_march<3><<<grd, blk, 0, s>>>(d, tab, E, u, out, cb, xsteps); break;
+            default: k_apply_q2_march<0><<<grd, blk, 0, s>>>(d, tab, E, u, out, cb, xsteps);
+        }
     }
     VFEM_HIP(hipGetLastError());
 }

@@ -1,0 +1,46 @@
+"""Scans a kernel's ISA (hipcc -S output) for the split scalar-load pattern of device_utils.h (sload12_issue / sload12_wait):
+between an s_load and the next `s_waitcnt lgkmcnt(0)` no instruction may read or write the load's destination SGPRs
+(the compiler regards them as defined, so a spill or a copy there would move stale data and free the registers).
+usage: check_sload_pipeline.py file.s kernel_name_substring"""
+import re
+import sys
+
+path, name = sys.argv[1], sys.argv[2]
+lines = open(path).read().split("\n")
+start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\S*%s\S*:" % re.escape(name), l))
+end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+rng = re.compile(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b")
+
+
+def sregs(text):
+    out = set()
+    for m in rng.finditer(text):
+        if m.group(1) is not None:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+inflight, bad, loads, windows = set(), 0, 0, 0
+for i in range(start + 1, end):
+    ins = lines[i].split(";")[0].strip()
+    if not ins or ins.endswith(":") or ins.startswith("."):
+        continue
+    if ins.startswith("s_load_dword"):
+        ops = ins.split(None, 1)[1].split(",")
+        used = sregs(",".join(ops[1:]))
+        if used & inflight:
+            print("line %d reads in-flight registers: %s" % (i + 1, ins)); bad += 1
+        inflight |= sregs(ops[0])
+        loads += 1
+        continue
+    if ins.startswith("s_waitcnt") and ("lgkmcnt(0)" in ins):
+        if inflight:
+            windows += 1
+        inflight = set()
+        continue
+    if inflight and (sregs(ins) & inflight):
+        print("line %d touches in-flight registers %s: %s" % (i + 1, sorted(sregs(ins) & inflight), ins)); bad += 1
+print("%s: %d scalar loads, %d request..wait windows, %d violations" % (name, loads, windows, bad))
+sys.exit(1 if bad else 0)

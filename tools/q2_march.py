@@ -35,6 +35,13 @@ def run(ne, impls, reps):
 if sys.argv[1] == "check":
     for ne in ((3, 2, 5), (4, 4, 4), (5, 7, 64), (17, 6, 63), (16, 5, 130), (33, 9, 70), (70, 3, 3)):
         run(ne, (1, 2, 0), 1)
+elif sys.argv[1] == "exp":
+    n = int(sys.argv[2])
+    for exp in (0, 1, 2, 3, 0):
+        lib.vfem_debug_set(1, exp)
+        print("ablation", exp, {0: "production", 1: "no element product", 2: "no row stores", 3: "no row loads"}[exp])
+        run((n, n, n), (0,), 5)
+    lib.vfem_debug_set(1, 0)
 else:
     n = int(sys.argv[1])
-    run((n, n, n), (2, 0), 5)
+    run((n, n, n), (0,) if len(sys.argv) > 2 else (2, 0), 5)
