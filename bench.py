@@ -164,7 +164,7 @@ def degree2_rate(ne=(512, 512, 512), reps=3):
     return {"grid": "%dx%dx%d" % tuple(ne), "nodes": t.numNodes(), "seconds": dt, "gvoxel_per_s": nvox / dt / 1e9,
             "algorithmic_GBs": ab / dt / 1e9, "frac_of_8TBs": ab / dt / 1e9 / HBM_PEAK_GBS,
             "algorithmic_bytes_per_voxel": ab / nvox,
-            "note": "pencil kernel: reflection-mode blocks (855 of 6561 multiply-adds), 4 colour launches, 1104 B/voxel moved"}
+            "note": "marching kernel: reflection-mode blocks (855 of 6561 multiply-adds), x-march with in-block y hand-off, 2 colour launches, ~464 B/voxel moved"}
 
 
 def degree2_pcg_rate(n=128, levels=5):
@@ -194,7 +194,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--grid", type=int, nargs=3, default=[512, 512, 512])
     ap.add_argument("--no-cg", action="store_true", help="skip the CG-MG side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
