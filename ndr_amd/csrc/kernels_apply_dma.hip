@@ -1,12 +1,15 @@
 // k_apply_dma: the production stiffness apply with LDS-DMA staging.
 //
-// Same algorithm and tiling as k_apply_fast (kernels_apply.hip: mode-space element matrix, lanes = z, 8 waves = 8
+// Same algorithm and tiling as k_apply_fast (kernels_apply.hip: mode-space element matrix, lanes = z, TY waves = TY
 // element rows, block marches along x, one barrier per plane), but the node planes and the element moduli are
 // brought in by `global_load_lds_dwordx4` straight into a 4-deep LDS ring instead of through registers:
 //   * no VGPRs and no ds_write instructions are spent on staging,
 //   * three planes stay in flight behind a *counted* `s_waitcnt vmcnt(N)` + raw `s_barrier` (hipcc drains every
 //     ordinary load to vmcnt(0) once per plane in the register-staged version, which is what bounded it:
 //     its memory skeleton alone ran at 3 TB/s whatever the prefetch depth),
+//   * the DMA is issued and retired by NW dedicated waves (ty >= TY) that do no arithmetic and no stores: `vmcnt`
+//     retires in issue order, so a wave that both loads and stores waits for its own older stores whenever it waits
+//     for a plane; the compute waves never wait on `vmcnt` at all (NW = 0 builds the earlier shared form),
 //   * a plane is read one phase after the wait+barrier that retires it (MI355X_MICROARCH.md, two-waves item 7).
 // A DMA piece is 16 bytes on the absolute 16-byte grid of memory: a tile row (65 nodes = 1560 B) starts on an 8-byte
 // boundary, so its image starts at the aligned address at or 8 bytes below it and the consumer adds that one-double
