@@ -51,13 +51,21 @@ __device__ __forceinline__ long long g_node_flat(const GDims &d, const int idx[3
     for (int a = 1; a < d.N; ++a) n = n * d.nn[a] + idx[a];
     return n;
 }
+template <int N>
+__device__ __forceinline__ long long g_node_flat_n(const GDims &d, const int idx[3]) {
+    long long n = idx[0];
+#pragma unroll
+    for (int a = 1; a < N; ++a) n = n * d.nn[a] + idx[a];
+    return n;
+}
 
 // S[r] = sum over incident elements e, element dofs q of scale_e * K_e[N*ln + r][q] * u_e[q]   (complete in every lane)
 // M[r][c] = sum_e scale_e * K_e[N*ln + r][N*ln + c]
+template <int N, int p>       // dimension and degree at compile time: the index arithmetic below folds to shifts and constants
 __device__ __forceinline__ void g_gather(const GDims &d, const double *__restrict__ K, long long kstride,
                                          const double *__restrict__ scale, const double *__restrict__ u, const int idx[3],
                                          int lane, double S[3], double M[9]) {
-    const int N = d.N, p = d.p, q1 = p + 1, ke = d.ke;
+    constexpr int q1 = p + 1, ke = N * (N == 3 ? q1 * q1 * q1 : q1 * q1);
     int cnt[3] = {1, 1, 1}, el[3][2], lo[3][2];
     for (int a = 0; a < N; ++a) {
         const int r = idx[a] % p, e = idx[a] / p;
@@ -91,16 +99,28 @@ __device__ __forceinline__ void g_gather(const GDims &d, const double *__restric
                 }
                 const double sc = scale ? scale[e] : 1.0;
                 const double *Kp = K + e * kstride + (long long) (N * ln) * ke;
+                double kv[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};       // this lane's entries of the node's N rows
                 for (int t = 0; t < 2; ++t) {
                     if (qn[t] < 0) continue;
                     int g[3];
                     for (int a = 0; a < N; ++a) g[a] = ebase[a] + qoff[t][a];
-                    const double uv = sc * u[N * g_node_flat(d, g) + qc[t]];
+                    const double uv = sc * u[N * g_node_flat_n<N>(d, g) + qc[t]];
                     const int q = lane + 64 * t;
-                    for (int r = 0; r < N; ++r) sp[r] = fma(Kp[r * ke + q], uv, sp[r]);
+                    for (int r = 0; r < N; ++r) { kv[t][r] = Kp[r * ke + q]; sp[r] = fma(kv[t][r], uv, sp[r]); }
                 }
-                for (int r = 0; r < N; ++r)
-                    for (int c = 0; c < N; ++c) M[3 * r + c] = fma(sc, Kp[r * ke + N * ln + c], M[3 * r + c]);
+                // diagonal block: entries N*ln + c of the same rows, already held by lane (N*ln + c) mod 64 -- the element and the
+                // local node are the same in every lane of the wave, so the source lane is uniform (v_readlane, no further loads)
+                for (int c = 0; c < N; ++c) {
+                    const int qd = __builtin_amdgcn_readfirstlane(N * ln + c);
+                    for (int r = 0; r < N; ++r) {
+                        const double src = qd < 64 ? kv[0][r] : kv[1][r];
+                        const unsigned long long bits = __double_as_longlong(src);
+                        const unsigned lo = __builtin_amdgcn_readlane((unsigned) (bits & 0xffffffffull), qd & 63);
+                        const unsigned hi = __builtin_amdgcn_readlane((unsigned) (bits >> 32), qd & 63);
+                        const double kd = __longlong_as_double(((unsigned long long) hi << 32) | lo);
+                        M[3 * r + c] = fma(sc, kd, M[3 * r + c]);
+                    }
+                }
             }
     for (int r = 0; r < 3; ++r) {
         double v = r < N ? sp[r] : 0.0;
@@ -111,6 +131,7 @@ __device__ __forceinline__ void g_gather(const GDims &d, const double *__restric
 }
 
 // mode 0: out = K u;  1: out = zeroDirichlet(b - K u);  2: out = zeroDirichlet(K u)
+template <int N, int p>
 __global__ void __launch_bounds__(256) kg_apply(GDims d, const double *__restrict__ K, long long kstride,
                                                 const double *__restrict__ scale, const double *__restrict__ u,
                                                 const double *__restrict__ b, const uint8_t *__restrict__ mask, int mode,
@@ -119,20 +140,21 @@ __global__ void __launch_bounds__(256) kg_apply(GDims d, const double *__restric
     const long long n = (long long) blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= d.nnodes) return;
     int idx[3] = {0, 0, 0};
-    { long long m = n; for (int a = d.N - 1; a >= 0; --a) { idx[a] = (int) (m % d.nn[a]); m /= d.nn[a]; } }
+    { long long m = n; for (int a = N - 1; a >= 0; --a) { idx[a] = (int) (m % d.nn[a]); m /= d.nn[a]; } }
     double S[3], M[9];
-    g_gather(d, K, kstride, scale, u, idx, lane, S, M);
-    if (lane < d.N) {
+    g_gather<N, p>(d, K, kstride, scale, u, idx, lane, S, M);
+    if (lane < N) {
         double v = S[lane];
-        if (mode == 1) v = b[d.N * n + lane] - v;
+        if (mode == 1) v = b[N * n + lane] - v;
         if (mode != 0 && mask && ((mask[n] >> lane) & 1)) v = 0.0;
-        out[d.N * n + lane] = v;
+        out[N * n + lane] = v;
     }
 }
 
 struct GColor { int start[3], inc[3], cnt[3]; long long total; };
 
 // one colour of smoothingMulticoloredGS (MG.hh:285-340) with m_smoothNode's component-sequential solve (MG.hh:254-264)
+template <int N, int p>
 __global__ void __launch_bounds__(256) kg_gs_color(GDims d, GColor col, const double *__restrict__ K, long long kstride,
                                                    const double *__restrict__ scale, double *__restrict__ u,
                                                    const double *__restrict__ b, const uint8_t *__restrict__ mask, int forward) {
@@ -140,12 +162,11 @@ __global__ void __launch_bounds__(256) kg_gs_color(GDims d, GColor col, const do
     const long long w = (long long) blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= col.total) return;
     int idx[3] = {0, 0, 0};
-    { long long m = w; for (int a = d.N - 1; a >= 0; --a) { idx[a] = col.start[a] + (int) (m % col.cnt[a]) * col.inc[a]; m /= col.cnt[a]; } }
+    { long long m = w; for (int a = N - 1; a >= 0; --a) { idx[a] = col.start[a] + (int) (m % col.cnt[a]) * col.inc[a]; m /= col.cnt[a]; } }
     double S[3], M[9];
-    g_gather(d, K, kstride, scale, u, idx, lane, S, M);
+    g_gather<N, p>(d, K, kstride, scale, u, idx, lane, S, M);
     if (lane == 0) {
-        const long long n = g_node_flat(d, idx);
-        const int N = d.N;
+        const long long n = g_node_flat_n<N>(d, idx);
         const uint8_t dc = mask ? mask[n] : 0;
         double bms[3], diff[3] = {0.0, 0.0, 0.0};
         for (int r = 0; r < N; ++r) bms[r] = b[N * n + r] - S[r];
@@ -478,7 +499,11 @@ static inline hipStream_t GS(void *s) { return (hipStream_t) s; }
 
 static void g_apply(const GDims &d, const double *K, long long kstride, const double *scale, const double *u,
                     const double *b, const uint8_t *mask, int mode, double *out, hipStream_t s) {
-    kg_apply<<<dim3((unsigned) ((d.nnodes + 3) / 4)), dim3(256), 0, s>>>(d, K, kstride, scale, u, b, mask, mode, out);
+    const dim3 grd((unsigned) ((d.nnodes + 3) / 4)), blk(256);
+    if (d.N == 3 && d.p == 2) kg_apply<3, 2><<<grd, blk, 0, s>>>(d, K, kstride, scale, u, b, mask, mode, out);
+    else if (d.N == 3) kg_apply<3, 1><<<grd, blk, 0, s>>>(d, K, kstride, scale, u, b, mask, mode, out);
+    else if (d.p == 2) kg_apply<2, 2><<<grd, blk, 0, s>>>(d, K, kstride, scale, u, b, mask, mode, out);
+    else kg_apply<2, 1><<<grd, blk, 0, s>>>(d, K, kstride, scale, u, b, mask, mode, out);
     VFEM_HIP(hipGetLastError());
 }
 
@@ -525,7 +550,12 @@ static void gmg_smooth(vfem_gmg *mg, int l, double *u, const double *b, int forw
         }
         for (int a = d.N; a < 3; ++a) { col.start[a] = 0; col.inc[a] = 1; col.cnt[a] = 1; }
         if (col.total == 0) continue;
-        kg_gs_color<<<dim3((unsigned) ((col.total + 3) / 4)), dim3(256), 0, s>>>(d, col, K, ks, scale, u, b, mg->lv[l].mask.p, forward);
+        const dim3 grd((unsigned) ((col.total + 3) / 4)), blk(256);
+        const uint8_t *mk = mg->lv[l].mask.p;
+        if (d.N == 3 && d.p == 2) kg_gs_color<3, 2><<<grd, blk, 0, s>>>(d, col, K, ks, scale, u, b, mk, forward);
+        else if (d.N == 3) kg_gs_color<3, 1><<<grd, blk, 0, s>>>(d, col, K, ks, scale, u, b, mk, forward);
+        else if (d.p == 2) kg_gs_color<2, 2><<<grd, blk, 0, s>>>(d, col, K, ks, scale, u, b, mk, forward);
+        else kg_gs_color<2, 1><<<grd, blk, 0, s>>>(d, col, K, ks, scale, u, b, mk, forward);
     }
     VFEM_HIP(hipGetLastError());
 }
