@@ -602,23 +602,27 @@ void launch_apply_q2_march(int nx, int ny, int nz, const double *tab, const doub
 // ------------------------------------------------------------------------------------------------------
 struct Q2Color { int start[3], inc[3], cnt[3]; };
 
+template <int PX, int PY, int PZ>      // node parities of the colour (odd = mid node of one element) at compile time: the slot loops unroll
 __global__ void __launch_bounds__(256) k_gs_q2_level0(DimsQ2 d, Q2Color col, const double *__restrict__ K0, const double *__restrict__ E,
                                                       double *__restrict__ u, const double *__restrict__ b,
                                                       const uint8_t *__restrict__ mask, int forward) {
     const int c = blockIdx.x * 64 + threadIdx.x, bq = blockIdx.y * 4 + threadIdx.y, a = blockIdx.z;
     if (c >= col.cnt[2] || bq >= col.cnt[1] || a >= col.cnt[0]) return;
     const int i = col.start[0] + a * col.inc[0], j = col.start[1] + bq * col.inc[1], k = col.start[2] + c * col.inc[2];
-    const int px = i & 1, py = j & 1, pz = k & 1;                 // wave-uniform (colour property)
-    const int nex = px ? 1 : 2, ney = py ? 1 : 2, nez = pz ? 1 : 2;
+    constexpr int px = PX, py = PY, pz = PZ;
+    constexpr int nex = px ? 1 : 2, ney = py ? 1 : 2, nez = pz ? 1 : 2;
     double S[3] = {0.0, 0.0, 0.0}, M[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) M[q] = 0.0;
+#pragma unroll
     for (int sx = 0; sx < nex; ++sx) {
         const int ex = px ? i / 2 : i / 2 - 1 + sx, lx = px ? 1 : (sx ? 0 : 2);
         if (ex < 0 || ex >= d.nx) continue;
+#pragma unroll
         for (int sy = 0; sy < ney; ++sy) {
             const int ey = py ? j / 2 : j / 2 - 1 + sy, ly = py ? 1 : (sy ? 0 : 2);
             if (ey < 0 || ey >= d.ny) continue;
+#pragma unroll
             for (int sz = 0; sz < nez; ++sz) {
                 const int ez = pz ? k / 2 : k / 2 - 1 + sz, lz = pz ? 1 : (sz ? 0 : 2);
                 if (ez < 0 || ez >= d.nz) continue;
@@ -626,7 +630,9 @@ __global__ void __launch_bounds__(256) k_gs_q2_level0(DimsQ2 d, Q2Color col, con
                 const double Ee = E[((long long) ex * d.ny + ey) * d.nz + ez];
                 const double *r0 = K0 + (3 * ln) * 81, *r1 = r0 + 81, *r2 = r1 + 81;
                 double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
                 for (int ma = 0; ma < 3; ++ma)
+#pragma unroll
                     for (int mb = 0; mb < 3; ++mb) {
                         const long long rowbase = ((long long) (2 * ex + ma) * d.NY + (2 * ey + mb)) * d.NZ + 2 * ez;
 #pragma unroll
@@ -674,7 +680,19 @@ void launch_gs_sweep_q2_level0(int nx, int ny, int nz, const double *K0, const d
             empty = empty || col.cnt[a] == 0;
         }
         if (empty) continue;
-        k_gs_q2_level0<<<dim3((col.cnt[2] + 63) / 64, (col.cnt[1] + 3) / 4, col.cnt[0]), dim3(64, 4, 1), 0, s>>>(d, col, K0, E, u, b, mask, forward);
+        const dim3 grd((col.cnt[2] + 63) / 64, (col.cnt[1] + 3) / 4, col.cnt[0]), blk(64, 4, 1);
+#define VFEM_Q2GS(X, Y, Z) k_gs_q2_level0<X, Y, Z><<<grd, blk, 0, s>>>(d, col, K0, E, u, b, mask, forward)
+        switch (4 * (l[0] & 1) + 2 * (l[1] & 1) + (l[2] & 1)) {
+            case 0: VFEM_Q2GS(0, 0, 0); break;
+            case 1: VFEM_Q2GS(0, 0, 1); break;
+            case 2: VFEM_Q2GS(0, 1, 0); break;
+            case 3: VFEM_Q2GS(0, 1, 1); break;
+            case 4: VFEM_Q2GS(1, 0, 0); break;
+            case 5: VFEM_Q2GS(1, 0, 1); break;
+            case 6: VFEM_Q2GS(1, 1, 0); break;
+            default: VFEM_Q2GS(1, 1, 1);
+        }
+#undef VFEM_Q2GS
     }
     VFEM_HIP(hipGetLastError());
 }
