@@ -276,18 +276,19 @@ __global__ void __launch_bounds__(256) kg_coarsen_first(GDims f, GDims c, const 
 }
 
 // deeper levels: Ke_c = sum_f I_f^T Ke_f I_f with I_f = phi_f (x) Id_N; one block per coarse element
+template <int N, int p>      // dimension and degree at compile time (entry indices fold to constants); weights of the child in LDS
 __global__ void __launch_bounds__(256) kg_coarsen_next(GDims f, GDims c, const double *__restrict__ phi,
                                                        const double *__restrict__ Kef, double *__restrict__ Kec) {
     extern __shared__ double g_sm[];
-    const int N = c.N, ke = c.ke, npe = c.npe, kk = ke * ke, nch = 1 << N;
-    double *A = g_sm, *T = g_sm + kk;
+    constexpr int q1 = p + 1, npe = N == 3 ? q1 * q1 * q1 : q1 * q1, ke = N * npe, kk = ke * ke, nch = 1 << N;
+    double *A = g_sm, *T = g_sm + kk, *ph = g_sm + 2 * kk;            // ph[fine_n * npe + coarse_n]
     const long long ec = blockIdx.x;
     for (int q = threadIdx.x; q < kk; q += blockDim.x) Kec[ec * kk + q] = 0.0;
     for (int fi = 0; fi < nch; ++fi) {
         const double *Kf = Kef + g_child(f, c, ec, fi) * kk;
-        const double *ph = phi + (long long) fi * npe * npe;          // ph[fine_n * npe + coarse_n]
         __syncthreads();
         for (int q = threadIdx.x; q < kk; q += blockDim.x) A[q] = Kf[q];
+        for (int q = threadIdx.x; q < npe * npe; q += blockDim.x) ph[q] = phi[(long long) fi * npe * npe + q];
         __syncthreads();
         // T[i][(m,b)] = sum_qn A[i][(qn,b)] ph[qn][m]
         for (int q = threadIdx.x; q < kk; q += blockDim.x) {
@@ -588,10 +589,19 @@ static void gmg_update(vfem_gmg *mg, hipStream_t s) {
         lv.Ke.alloc((size_t) lv.d.nelems * kk);
         if (l == 1) kg_coarsen_first<<<dim3((unsigned) lv.d.nelems), dim3(256), 0, s>>>(mg->lv[0].d, lv.d, mg->cK0.p, sim->E.p, lv.Ke.p);
         else {
-            const size_t lds = 2 * kk * sizeof(double);
+            const size_t lds = (2 * kk + (size_t) lv.d.npe * lv.d.npe) * sizeof(double);
             static bool attr = false;
-            if (!attr) { VFEM_HIP(hipFuncSetAttribute((const void *) kg_coarsen_next, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 81 * 81 * 8)); attr = true; }
-            kg_coarsen_next<<<dim3((unsigned) lv.d.nelems), dim3(256), lds, s>>>(mg->lv[l - 1].d, lv.d, mg->phi.p, mg->lv[l - 1].Ke.p, lv.Ke.p);
+            if (!attr) {
+                VFEM_HIP(hipFuncSetAttribute((const void *) kg_coarsen_next<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 81 * 81 + 27 * 27) * 8));
+                attr = true;
+            }
+            const dim3 grd((unsigned) lv.d.nelems), blk(256);
+            const GDims &fd = mg->lv[l - 1].d;
+            const double *Kf = mg->lv[l - 1].Ke.p;
+            if (N == 3 && sim->d.p == 2) kg_coarsen_next<3, 2><<<grd, blk, lds, s>>>(fd, lv.d, mg->phi.p, Kf, lv.Ke.p);
+            else if (N == 3) kg_coarsen_next<3, 1><<<grd, blk, lds, s>>>(fd, lv.d, mg->phi.p, Kf, lv.Ke.p);
+            else if (sim->d.p == 2) kg_coarsen_next<2, 2><<<grd, blk, lds, s>>>(fd, lv.d, mg->phi.p, Kf, lv.Ke.p);
+            else kg_coarsen_next<2, 1><<<grd, blk, lds, s>>>(fd, lv.d, mg->phi.p, Kf, lv.Ke.p);
         }
         VFEM_HIP(hipGetLastError());
     }
