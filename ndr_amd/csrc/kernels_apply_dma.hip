@@ -329,20 +329,23 @@ __global__ void __launch_bounds__(64 * (dma::TY + dma::NW)) k_apply_dma(Dims d, 
         }
     };
     auto emit_plane = [&](int i, const double wa[3], int buf) {
-        if (!out_ok || X == 5) return;
+        if (X == 5) return;
+        if (EXP == 11 ? !(ty >= 1 && ej < d.NY) : !out_ok) return;
         const double *sX = sS + buf * SS_DOUBLES;
         const long long n = (long long) (EXP == 9 ? (i & 1) : i) * plane + (long long) ej * d.NZ + ek;
         double w[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             w[c] = (X == 1 || X >= 3) ? wa[c] : wa[c] + sX[(c * TY + ty - 1) * TZ + tz];
-        if (EXP == 11) {
+        if (EXP == 11) {      // timing only: the row written as contiguous 16-byte pieces (piece = lane, then 64 + lane), values meaningless
             const long long n0 = (long long) i * plane + (long long) ej * d.NZ + (k0 + 1);     // first output node of the row
             double *row = out + 3 * n0;
             int nd = 3 * (d.NZ - (k0 + 1)); nd = nd > 189 ? 189 : nd;                          // doubles in the row
-            const int g0 = 2 * (tz - 1), g1 = 128 + 2 * (tz - 1);
+            const int g0 = 2 * tz, g1 = 128 + 2 * tz;
             if (g0 + 1 < nd) { row[g0] = w[0]; row[g0 + 1] = w[1]; }
+            else if (g0 < nd) row[g0] = w[0];
             if (g1 + 1 < nd) { row[g1] = w[2]; row[g1 + 1] = w[0]; }
+            else if (g1 < nd) row[g1] = w[2];
             return;
         }
         if (NT) { __builtin_nontemporal_store(w[0], &out[3 * n]); __builtin_nontemporal_store(w[1], &out[3 * n + 1]); __builtin_nontemporal_store(w[2], &out[3 * n + 2]); }

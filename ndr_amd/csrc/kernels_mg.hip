@@ -506,10 +506,18 @@ __device__ __forceinline__ void stencil_node(const Dims &d, const double *__rest
     long long sbase, scnt;
     cm_index(d, i, j, k, sbase, scnt);
     (void) n;
-    for (int nb = 0; nb < 27; ++nb) {
-        const int di = nb / 9 - 1, dj = (nb / 3) % 3 - 1, dk = nb % 3 - 1;
-        const int ii = i + di, jj = j + dj, kk = k + dk;
-        if (ii < 0 || ii >= d.NX || jj < 0 || jj >= d.NY || kk < 0 || kk >= d.NZ) continue;
+    // branch-free: the stencil entries of neighbours outside the grid are stored as zeros (k_stencil_build), so such a
+    // neighbour is read at the clamped (existing) node and contributes exactly 0; without branches the loads of the 27
+    // blocks can be issued ahead of the arithmetic
+    static_for<27>([&](auto nbc) {
+        constexpr int nb = decltype(nbc)::value, di = nb / 9 - 1, dj = (nb / 3) % 3 - 1, dk = nb % 3 - 1;
+        int ii = i + di, jj = j + dj, kk = k + dk;
+        if (di < 0) ii = ii < 0 ? 0 : ii;
+        if (di > 0) ii = ii > d.NX - 1 ? d.NX - 1 : ii;
+        if (dj < 0) jj = jj < 0 ? 0 : jj;
+        if (dj > 0) jj = jj > d.NY - 1 ? d.NY - 1 : jj;
+        if (dk < 0) kk = kk < 0 ? 0 : kk;
+        if (dk > 0) kk = kk > d.NZ - 1 ? d.NZ - 1 : kk;
         const long long m = nidx(d, ii, jj, kk);
         const double u0 = u[3 * m], u1 = u[3 * m + 1], u2 = u[3 * m + 2];
         const double *a = St + sbase + (long long) nb * 9 * scnt;
@@ -522,7 +530,7 @@ __device__ __forceinline__ void stencil_node(const Dims &d, const double *__rest
 #pragma unroll
             for (int q = 0; q < 9; ++q) M[q] = A[q];
         }
-    }
+    });
 }
 
 template <bool RES>
