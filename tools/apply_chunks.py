@@ -14,7 +14,7 @@ tps.setElementDensities(torch.rand(tps.numElements(), dtype=torch.float64, devic
 u = torch.randn((tps.numNodes(), 3), dtype=torch.float64, device="cuda", generator=g)
 out = torch.empty_like(u)
 ref = None
-for nc in (8, 3, 4, 5, 6, 7, 9, 10, 12, 8):
+for nc in [int(a) for a in sys.argv[2:]] or (8, 3, 4, 5, 6, 7, 9, 10, 12, 8):
     lib.vfem_debug_set(7, nc)
     for _ in range(3): lib.vfem_sim_apply_k(tps._h, _ptr(u), _ptr(out), 0, _stream())
     torch.cuda.synchronize()
