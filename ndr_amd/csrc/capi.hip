@@ -22,6 +22,7 @@ namespace vfem {
 extern int g_apply_pd, g_apply_skeleton, g_gs_variant, g_apply_store, g_dma_chunks;
 }
 extern int g_q2_impl;
+int g_mlp_ablate = 0;       // vfem_debug_set(8, v): MLP forward timing ablations
 namespace vfem {
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
@@ -318,6 +319,7 @@ int vfem_debug_set(int key, int value) {
     else if (key == 3) vfem::g_apply_store = value;
     else if (key == 4) vfem::g_apply_impl = value;
     else if (key == 6) g_q2_impl = value;
+    else if (key == 8) g_mlp_ablate = value;
     else if (key == 7) vfem::g_dma_chunks = value;
     else return 1;
     return 0;
@@ -917,6 +919,7 @@ int vfem_mlp_load_weights(vfem_mlp *m, const float *B, const float *W1, const fl
 #include "mlp_args.h"
 static vfem::MlpArgs mlp_base_args(const vfem_mlp *m) {
     vfem::MlpArgs a{};
+    a.ablate = g_mlp_ablate;
     a.es = m->es; a.nn = m->nn; a.n_hidden = m->n_layers - 2; a.sigmoid = m->sigmoid;
     a.B = m->B.p; a.W1 = m->W1.p; a.Wh = m->Wh.p; a.bias = m->bias.p; a.wout = m->wout.p; a.bout = m->bout;
     return a;

@@ -78,36 +78,39 @@ struct APipe {
 
 // MLP_PD consecutive k-steps (one revolution of the ring) starting at k-step ks0 of the layer:
 // acc[t][c] (row tile t of this wave, voxel tile c) += W[n][k] X[v][k];  X image: xs[v * XSTRIDE + k_local], the first
-// k-step of this call sits at k_local0
-// `between(p)` runs right after the MFMAs of k-step p were issued: independent vector work placed there executes while the
-// matrix pipe is busy (the first layer generates the next chunk's Fourier features this way)
-template <int XSTRIDE, bool FULL, class Between>
-__device__ __forceinline__ void gemm_ring(f16_t acc[2][4], APipe<FULL> &ap, int ks0, const _Float16 *xs, int k_local0, int lane, Between &&between) {
+// k-step of this call sits at k_local0.
+// Operand (B) fragments alternate between two register sets at compile time -- no copies, so no MFMA-source hazards -- and
+// the fragments of the first k-step are handed in by the caller (`bpre`), which receives those of the next revolution
+// (image `xs_next`, offset `k_next`; null = none) in return: the LDS latency is never exposed between revolutions.
+template <int XSTRIDE>
+__device__ __forceinline__ void load_bfrags(h8_t (&b)[4], const _Float16 *xs, int k_local, int lane) {
     const int r = lane & 31, h = lane >> 5;
-    h8_t bcur[4], bnext[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) bcur[c] = *reinterpret_cast<const h8_t *>(xs + (c * 32 + r) * XSTRIDE + k_local0 + 8 * h);
+    for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const h8_t *>(xs + (c * 32 + r) * XSTRIDE + k_local + 8 * h);
+}
+
+template <int XSTRIDE, bool FULL>
+__device__ __forceinline__ void gemm_ring(f16_t acc[2][4], APipe<FULL> &ap, int ks0, const _Float16 *xs, int k_local0, int lane,
+                                          h8_t (&bpre)[4], const _Float16 *xs_next, int k_next) {
+    static_assert(MLP_PD % 2 == 0, "the two operand register sets alternate with the k-step parity");
+    h8_t balt[4];
 #pragma unroll
     for (int p = 0; p < MLP_PD; ++p) {
         const int ks = ks0 + p;
         if (FULL || ks < ap.total) {
-            if (p + 1 < MLP_PD && (FULL || ks + 1 < ap.total)) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    bnext[c] = *reinterpret_cast<const h8_t *>(xs + (c * 32 + r) * XSTRIDE + k_local0 + (p + 1) * 16 + 8 * h);
-            }
+            h8_t (&bc)[4] = (p & 1) ? balt : bpre;          // fragments of this k-step
+            h8_t (&bn)[4] = (p & 1) ? bpre : balt;          // filled for the next one
+            if (p + 1 < MLP_PD) { if (FULL || ks + 1 < ap.total) load_bfrags<XSTRIDE>(bn, xs, k_local0 + (p + 1) * 16, lane); }
+            else if (xs_next) load_bfrags<XSTRIDE>(bn, xs_next, k_next, lane);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 if (FULL || ap.on[t]) {
                     const h8_t afrag = ap.ring[p][t];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bcur[c], acc[t][c], 0, 0, 0);
+                    for (int c = 0; c < 4; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bc[c], acc[t][c], 0, 0, 0);
                 }
             }
             if (ks + MLP_PD < ap.total) ap.load(p, ks + MLP_PD);
-            between(p);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) bcur[c] = bnext[c];
         }
     }
 }
@@ -118,7 +121,12 @@ __device__ __forceinline__ void gemm_layer(f16_t acc[2][4], const _Float16 *W, i
                                            int lane) {
     APipe<FULL> ap;
     ap.init(W, ldw, wave, ntiles, lane, K / 16);
-    for (int ks0 = 0; ks0 < ap.total; ks0 += MLP_PD) gemm_ring<XSTRIDE, FULL>(acc, ap, ks0, xs, ks0 * 16, lane, [](int) {});
+    h8_t bpre[4];
+    load_bfrags<XSTRIDE>(bpre, xs, 0, lane);
+    for (int ks0 = 0; ks0 < ap.total; ks0 += MLP_PD) {
+        const bool more = ks0 + MLP_PD < ap.total;
+        gemm_ring<XSTRIDE, FULL>(acc, ap, ks0, xs, ks0 * 16, lane, bpre, more ? xs : nullptr, (ks0 + MLP_PD) * 16);
+    }
 }
 
 template <bool FULL>
@@ -158,14 +166,17 @@ __global__ void __launch_bounds__(512) k_mlp_forward(MlpArgs a) {
         const float x0 = xc[3 * v], x1 = xc[3 * v + 1], x2 = xc[3 * v + 2];
         {
             const int j = 4 * part;
+            // the 16 features of (chunk, fq) are all sines or all cosines (es is a multiple of 32) and their rows of B are
+            // contiguous: one wave-uniform base pointer, constant offsets -> a few wide scalar loads instead of one address
+            // computation per feature (the scalar unit was executing ~6 instructions per MFMA)
+            const int f0 = chunk * MLP_KC + fq * 16;                 // first feature index in [0, 2 es)
+            const bool is_cos = f0 >= a.es;
+            const float *Bp = a.B + 3 * (is_cos ? f0 - a.es : f0) + 3 * j;
+            const float ph = is_cos ? 0.25f : 0.f;                   // cos x = sin(x + 1/4 turn): one transcendental per feature
             h4_t o;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                const int f = chunk * MLP_KC + fq * 16 + j + jj;     // feature index in [0, 2 es)
-                const bool is_cos = f >= a.es;
-                const int fi = is_cos ? f - a.es : f;
-                // phase in revolutions; cos x = sin(x + 1/4 turn): one transcendental per feature
-                const float t = fmaf(x0, a.B[3 * fi], fmaf(x1, a.B[3 * fi + 1], fmaf(x2, a.B[3 * fi + 2], is_cos ? 0.25f : 0.f)));
+                const float t = fmaf(x0, Bp[3 * jj], fmaf(x1, Bp[3 * jj + 1], fmaf(x2, Bp[3 * jj + 2], ph)));   // phase in revolutions
                 const float fr = t - floorf(t);
                 o[jj] = (_Float16) __builtin_amdgcn_sinf(fr);
             }
@@ -185,17 +196,23 @@ __global__ void __launch_bounds__(512) k_mlp_forward(MlpArgs a) {
     if (nchunks > 1) make_features(1, 1);
     __syncthreads();
     static_assert(MLP_KC / 16 == MLP_PD, "one feature chunk = one revolution of the weight ring");
+    h8_t bpre1[4];
+    load_bfrags<MLP_FSTRIDE>(bpre1, F, 0, lane);
     for (int ch = 0, cur = 0, nxt = 2; ch < nchunks; ++ch) {
-        const bool more = ch + 2 < nchunks;
+        const bool more = ch + 2 < nchunks && a.ablate != 1;
+        // the buffer of chunk ch+1 is complete (written during iteration ch-1, a barrier ago): its first fragments are fetched
+        // at the end of this chunk's MFMAs
+        const int after = cur == 2 ? 0 : cur + 1;
+        const _Float16 *Fn = ch + 1 < nchunks ? F + after * (MLP_TM * MLP_FSTRIDE) : nullptr;
         if (wave < 4) {
             if (more) make_features(ch + 2, nxt);
-            gemm_ring<MLP_FSTRIDE, FULL>(acc, ap1, ch * MLP_PD, F + cur * (MLP_TM * MLP_FSTRIDE), 0, lane, [](int) {});
+            if (a.ablate != 3) gemm_ring<MLP_FSTRIDE, FULL>(acc, ap1, ch * MLP_PD, F + cur * (MLP_TM * MLP_FSTRIDE), 0, lane, bpre1, Fn, 0);
         } else {
-            gemm_ring<MLP_FSTRIDE, FULL>(acc, ap1, ch * MLP_PD, F + cur * (MLP_TM * MLP_FSTRIDE), 0, lane, [](int) {});
+            if (a.ablate != 3) gemm_ring<MLP_FSTRIDE, FULL>(acc, ap1, ch * MLP_PD, F + cur * (MLP_TM * MLP_FSTRIDE), 0, lane, bpre1, Fn, 0);
             if (more) make_features(ch + 2, nxt);
         }
         __syncthreads();
-        cur = cur == 2 ? 0 : cur + 1;
+        cur = after;
         nxt = nxt == 2 ? 0 : nxt + 1;
     }
 
@@ -238,7 +255,7 @@ __global__ void __launch_bounds__(512) k_mlp_forward(MlpArgs a) {
     save_layer(0);
 
     // ---- hidden layers ----------------------------------------------------------------------
-    for (int l = 0; l < a.n_hidden; ++l) {
+    for (int l = 0; l < (a.ablate == 2 ? 0 : a.n_hidden); ++l) {
         gemm_layer<MLP_HSTRIDE, FULL>(acc, (const _Float16 *) a.Wh + (long long) l * a.nn * a.nn, a.nn, a.nn, H, wave, ntiles, lane);
         __syncthreads();          // every wave finished reading H
         store_layer(a.bias + (l + 1) * a.nn);

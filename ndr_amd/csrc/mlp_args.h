@@ -22,6 +22,7 @@ struct MlpArgs {
     long long v_offset;
     void *save_act;
     long long act_rows;
+    int ablate;                             // timing ablations (wrong results): 1 no feature generation, 2 no hidden layers, 3 no layer-1 MFMAs
 };
 
 // backward pass of one voxel chunk (networks.MLP under torch.autograd in the reference, train_xdg.py:282-329)
