@@ -231,6 +231,26 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
 #pragma unroll
     for (int sl = 0; sl < 8; ++sl) { T[sl][0] = 0.0; T[sl][1] = 0.0; T[sl][2] = 0.0; }
 
+    // everything the epilogue needs from memory is requested here, before the row loop: left in the epilogue these were eleven
+    // dependent round trips (8 moduli one by one behind the coefficient loads, then b and the mask, then u) and the waves
+    // spent 58 % of their life in s_waitcnt (SQ_WAIT_ANY)
+    const int zc = node_ok ? z : d.NZ - 1;
+    const long long n = nidx(d, x, y, zc);
+    double Ev8[8], bv[3], uself[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+        const int di = (sl >> 2) & 1, dj = (sl >> 1) & 1, dk = sl & 1;
+        const int ex = x - 1 + di, ey = y - 1 + dj, ez = zc - 1 + dk;
+        const bool ok = ex >= 0 && ex < d.nx && ey >= 0 && ey < d.ny && ez >= 0 && ez < d.nz;
+        const int exc = ex < 0 ? 0 : (ex > d.nx - 1 ? d.nx - 1 : ex), eyc = ey < 0 ? 0 : (ey > d.ny - 1 ? d.ny - 1 : ey);
+        const int ezc = ez < 0 ? 0 : (ez > d.nz - 1 ? d.nz - 1 : ez);
+        const double Ev = E[eidx(d, exc, eyc, ezc)];              // unconditional load, masked afterwards
+        Ev8[sl] = ok ? Ev : 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bv[c] = b[3 * n + c];
+    const uint8_t mk = mask[n];
+
     double pre[7];
     auto issue = [&](int r9) {
         int gx = x + r9 / 3 - 1, gy = y + r9 % 3 - 1;
@@ -259,6 +279,11 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
 #pragma unroll
             for (int c = 0; c < 3; ++c) u3[n3][c] = buf[6 * lane + 3 * n3 + c];
         __builtin_amdgcn_wave_barrier();
+        if (r9 == 4) {                                  // this row holds the node itself (the middle one of the lane's three)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) uself[c] = u3[1][c];
+        }
+
         // elements touching row (dx,dy): (di,mx) with di-1+mx == dx, (dj,my) with dj-1+my == dy
 #pragma unroll
         for (int di = 0; di < 2; ++di)
@@ -313,13 +338,7 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
             const int h = 0;
             const int ln = g;                            // local index of the node in its element
             const int sl = 7 - ln;                       // slot (di,dj,dk) = complement of ln
-            const int di = (sl >> 2) & 1, dj = (sl >> 1) & 1, dk = sl & 1;
-            const int ex = x - 1 + di, ey = y - 1 + dj, ez = z - 1 + dk;
-            const bool ok = ex >= 0 && ex < d.nx && ey >= 0 && ey < d.ny && ez >= 0 && ez < d.nz;
-            const int exc = ex < 0 ? 0 : (ex > d.nx - 1 ? d.nx - 1 : ex), eyc = ey < 0 ? 0 : (ey > d.ny - 1 ? d.ny - 1 : ey);
-            const int ezc = ez < 0 ? 0 : (ez > d.nz - 1 ? d.nz - 1 : ez);
-            const double Ev = E[eidx(d, exc, eyc, ezc)];          // unconditional load, masked afterwards
-            const double Ee = ok ? Ev : 0.0;
+            const double Ee = Ev8[sl];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 S[r] = fma(Ee, T[sl][r], S[r]);
@@ -329,13 +348,12 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
         }
         asm volatile("" : "+v"(M[0]), "+v"(M[4]), "+v"(M[8]), "+v"(S[0]));
     }
-    const long long n = nidx(d, x, y, z);
     double bms[3], ud[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) bms[c] = b[3 * n + c] - S[c];
-    gs_solve(bms, M, mask[n], forward != 0, ud);
+    for (int c = 0; c < 3; ++c) bms[c] = bv[c] - S[c];
+    gs_solve(bms, M, mk, forward != 0, ud);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) u[3 * n + c] += ud[c];
+    for (int c = 0; c < 3; ++c) u[3 * n + c] = uself[c] + ud[c];      // the node's own value came through the staged row
 }
 
 
