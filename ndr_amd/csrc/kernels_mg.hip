@@ -519,7 +519,7 @@ __device__ __forceinline__ void cm_index(const Dims &d, int i, int j, int k, lon
 
 template <bool WITH_M>
 __device__ __forceinline__ void stencil_node(const Dims &d, const double *__restrict__ St, const double *__restrict__ u,
-                                             int i, int j, int k, long long n, double S[3], double M[9]) {
+                                             int i, int j, int k, long long n, double S[3], double M[9], double *uself = nullptr) {
     S[0] = S[1] = S[2] = 0.0;
     long long sbase, scnt;
     cm_index(d, i, j, k, sbase, scnt);
@@ -564,6 +564,7 @@ __device__ __forceinline__ void stencil_node(const Dims &d, const double *__rest
         if (WITH_M && nb == 13) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) M[q] = A[q];
+            if (uself) { uself[0] = u0; uself[1] = u1; uself[2] = u2; }      // the centre of the stencil is the node itself
         }
     });
 }
@@ -605,14 +606,20 @@ __global__ void __launch_bounds__(256) k_gs_color_stencil(Dims d, const double *
     const int i = 2 * blockIdx.z + cx;
     if (k >= d.NZ || j >= d.NY || i >= d.NX) return;
     const long long n = nidx(d, i, j, k);
+    // right-hand side and mask requested ahead of the stencil loads, the node's own value taken from the stencil centre: on the
+    // small levels a launch lasts little more than its chain of dependent round trips
+    double bv[3], uself[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bv[c] = b[3 * n + c];
+    const uint8_t mk = mask[n];
     double S[3], M[9];
-    stencil_node<true>(d, St, u, i, j, k, n, S, M);
+    stencil_node<true>(d, St, u, i, j, k, n, S, M, uself);
     double bms[3], ud[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) bms[c] = b[3 * n + c] - S[c];
-    gs_solve(bms, M, mask[n], forward != 0, ud);
+    for (int c = 0; c < 3; ++c) bms[c] = bv[c] - S[c];
+    gs_solve(bms, M, mk, forward != 0, ud);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) u[3 * n + c] += ud[c];
+    for (int c = 0; c < 3; ++c) u[3 * n + c] = uself[c] + ud[c];
 }
 
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
