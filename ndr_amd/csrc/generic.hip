@@ -130,6 +130,94 @@ __device__ __forceinline__ void g_gather(const GDims &d, const double *__restric
     }
 }
 
+// The same gather for the nodes of one Gauss-Seidel colour of a 3-D grid: all of them have the same local index per axis, so
+// the number of incident elements per axis (C = 1: mid node, 2: node on an element boundary) is a template parameter, the
+// element loops unroll completely and the loads of all incident elements can be in flight together (rolled, every element was
+// one more dependent round trip for the wave).  Elements that do not exist (grid faces) are read at the clamped neighbour
+// with scale 0.
+template <int p, int C0, int C1, int C2>
+__device__ __forceinline__ void g_gather_fixed3(const GDims &d, const double *__restrict__ K, long long kstride,
+                                                const double *__restrict__ scale, const double *__restrict__ u, const int idx[3],
+                                                int lane, double S[3], double M[9]) {
+    constexpr int N = 3, q1 = p + 1, ke = N * q1 * q1 * q1;
+    constexpr int CN[3] = {C0, C1, C2};
+    int el[3][2], lo[3][2];
+    bool okc[3][2];
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+        const int r = idx[a] % p, e = idx[a] / p;
+        if (CN[a] == 1) { el[a][0] = e; lo[a][0] = r; okc[a][0] = true; el[a][1] = e; lo[a][1] = r; okc[a][1] = false; }
+        else {
+            okc[a][0] = e - 1 >= 0;      el[a][0] = okc[a][0] ? e - 1 : 0;            lo[a][0] = p;
+            okc[a][1] = e < d.ne[a];     el[a][1] = okc[a][1] ? e : d.ne[a] - 1;      lo[a][1] = 0;
+        }
+    }
+    double sp[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 9; ++q) M[q] = 0.0;
+    int qn[2], qc[2], qoff[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int q = lane + 64 * t;
+        qn[t] = q < ke ? q / N : -1; qc[t] = q % N;
+        int m = qn[t] < 0 ? 0 : qn[t];
+#pragma unroll
+        for (int a = N - 1; a >= 0; --a) { qoff[t][a] = m % q1; m /= q1; }
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < C0; ++i0)
+#pragma unroll
+        for (int i1 = 0; i1 < C1; ++i1)
+#pragma unroll
+            for (int i2 = 0; i2 < C2; ++i2) {
+                const int sel[3] = {i0, i1, i2};
+                long long e = 0; int ln = 0; int ebase[3];
+                bool valid = true;
+#pragma unroll
+                for (int a = 0; a < N; ++a) {
+                    e = e * d.ne[a] + el[a][sel[a]];
+                    ln = ln * q1 + lo[a][sel[a]];
+                    ebase[a] = p * el[a][sel[a]];
+                    valid = valid && okc[a][sel[a]];
+                }
+                const double sv = scale ? scale[e] : 1.0;
+                const double sc = valid ? sv : 0.0;
+                const double *Kp = K + e * kstride + (long long) (N * ln) * ke;
+                double kv[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (qn[t] < 0) continue;
+                    int g[3];
+#pragma unroll
+                    for (int a = 0; a < N; ++a) g[a] = ebase[a] + qoff[t][a];
+                    const double uv = sc * u[N * g_node_flat_n<N>(d, g) + qc[t]];
+                    const int q = lane + 64 * t;
+#pragma unroll
+                    for (int r = 0; r < N; ++r) { kv[t][r] = Kp[r * ke + q]; sp[r] = fma(kv[t][r], uv, sp[r]); }
+                }
+#pragma unroll
+                for (int c = 0; c < N; ++c) {
+                    const int qd = __builtin_amdgcn_readfirstlane(N * ln + c);
+#pragma unroll
+                    for (int r = 0; r < N; ++r) {
+                        const double src = qd < 64 ? kv[0][r] : kv[1][r];
+                        const unsigned long long bits = __double_as_longlong(src);
+                        const unsigned lo32 = __builtin_amdgcn_readlane((unsigned) (bits & 0xffffffffull), qd & 63);
+                        const unsigned hi32 = __builtin_amdgcn_readlane((unsigned) (bits >> 32), qd & 63);
+                        const double kd = __longlong_as_double(((unsigned long long) hi32 << 32) | lo32);
+                        M[3 * r + c] = fma(sc, kd, M[3 * r + c]);
+                    }
+                }
+            }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double v = sp[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        S[r] = v;
+    }
+}
+
 // mode 0: out = K u;  1: out = zeroDirichlet(b - K u);  2: out = zeroDirichlet(K u)
 template <int N, int p>
 __global__ void __launch_bounds__(256) kg_apply(GDims d, const double *__restrict__ K, long long kstride,
@@ -152,6 +240,36 @@ __global__ void __launch_bounds__(256) kg_apply(GDims d, const double *__restric
 }
 
 struct GColor { int start[3], inc[3], cnt[3]; long long total; };
+
+// component-sequential solve of m_smoothNode (MG.hh:254-264) for the node the wave gathered
+__device__ __forceinline__ void g_relax(const GDims &d, int N, long long n, const double S[3], const double M[9], double *__restrict__ u,
+                                        const double *__restrict__ b, const uint8_t *__restrict__ mask, int forward) {
+    const uint8_t dc = mask ? mask[n] : 0;
+    double bms[3], diff[3] = {0.0, 0.0, 0.0};
+    for (int r = 0; r < N; ++r) bms[r] = b[N * n + r] - S[r];
+    for (int s = 0; s < N; ++s) {
+        const int i = forward ? s : N - 1 - s;
+        double acc = 0.0;
+        for (int c = 0; c < N; ++c) acc += M[3 * i + c] * diff[c];
+        const double fac = (double) (((dc >> i) & 1) == 0) / M[3 * i + i];
+        diff[i] = (bms[i] - acc) * fac;
+    }
+    for (int r = 0; r < N; ++r) u[N * n + r] += diff[r];
+}
+
+template <int p, int C0, int C1, int C2>
+__global__ void __launch_bounds__(256) kg_gs_color_fixed3(GDims d, GColor col, const double *__restrict__ K, long long kstride,
+                                                          const double *__restrict__ scale, double *__restrict__ u,
+                                                          const double *__restrict__ b, const uint8_t *__restrict__ mask, int forward) {
+    const int lane = threadIdx.x & 63;
+    const long long w = (long long) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= col.total) return;
+    int idx[3] = {0, 0, 0};
+    { long long m = w; for (int a = 2; a >= 0; --a) { idx[a] = col.start[a] + (int) (m % col.cnt[a]) * col.inc[a]; m /= col.cnt[a]; } }
+    double S[3], M[9];
+    g_gather_fixed3<p, C0, C1, C2>(d, K, kstride, scale, u, idx, lane, S, M);
+    if (lane == 0) g_relax(d, 3, g_node_flat_n<3>(d, idx), S, M, u, b, mask, forward);
+}
 
 // one colour of smoothingMulticoloredGS (MG.hh:285-340) with m_smoothNode's component-sequential solve (MG.hh:254-264)
 template <int N, int p>
@@ -553,7 +671,22 @@ static void gmg_smooth(vfem_gmg *mg, int l, double *u, const double *b, int forw
         if (col.total == 0) continue;
         const dim3 grd((unsigned) ((col.total + 3) / 4)), blk(256);
         const uint8_t *mk = mg->lv[l].mask.p;
-        if (d.N == 3 && d.p == 2) kg_gs_color<3, 2><<<grd, blk, 0, s>>>(d, col, K, ks, scale, u, b, mk, forward);
+        if (d.N == 3 && d.p == 2) {
+            // incident elements per axis: 1 for a mid node (local index 1), 2 for a node on an element boundary
+#define VFEM_GSF(A, B, C) kg_gs_color_fixed3<2, A, B, C><<<grd, blk, 0, s>>>(d, col, K, ks, scale, u, b, mk, forward)
+            const int key = (col.start[0] == 1 ? 0 : 4) + (col.start[1] == 1 ? 0 : 2) + (col.start[2] == 1 ? 0 : 1);
+            switch (key) {
+                case 0: VFEM_GSF(1, 1, 1); break;
+                case 1: VFEM_GSF(1, 1, 2); break;
+                case 2: VFEM_GSF(1, 2, 1); break;
+                case 3: VFEM_GSF(1, 2, 2); break;
+                case 4: VFEM_GSF(2, 1, 1); break;
+                case 5: VFEM_GSF(2, 1, 2); break;
+                case 6: VFEM_GSF(2, 2, 1); break;
+                default: VFEM_GSF(2, 2, 2);
+            }
+#undef VFEM_GSF
+        }
         else if (d.N == 3) kg_gs_color<3, 1><<<grd, blk, 0, s>>>(d, col, K, ks, scale, u, b, mk, forward);
         else if (d.p == 2) kg_gs_color<2, 2><<<grd, blk, 0, s>>>(d, col, K, ks, scale, u, b, mk, forward);
         else kg_gs_color<2, 1><<<grd, blk, 0, s>>>(d, col, K, ks, scale, u, b, mk, forward);
