@@ -17,12 +17,15 @@ nn = mg._nn(level)
 u = torch.randn((nn, 3), dtype=torch.float64, device="cuda", generator=g)
 b = torch.randn((nn, 3), dtype=torch.float64, device="cuda", generator=g)
 from ndr_amd.pyVoxelFEM import _ptr, _stream
-for variant in (0, 1):
+res = {}
+for variant in (0, 2, 1):
     lib.vfem_debug_set(2, variant)
     for rep in range(3):
+        uu = u.clone()
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        lib.vfem_mg_smooth(mg._h, level, _ptr(u), _ptr(b), 1, _stream())
+        lib.vfem_mg_smooth(mg._h, level, _ptr(uu), _ptr(b), 1, _stream())
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    print("level %d variant %d: %.3f ms per sweep" % (level, variant, dt * 1e3), flush=True)
+    res[variant] = uu
+    print("level %d variant %d: %.3f ms per sweep   max |diff| to variant 0: %.3e" % (level, variant, dt * 1e3, float((uu - res[0]).abs().max())), flush=True)
 lib.vfem_debug_set(2, 0)
