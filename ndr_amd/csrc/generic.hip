@@ -299,6 +299,86 @@ __global__ void __launch_bounds__(256) kg_gs_color(GDims d, GColor col, const do
     }
 }
 
+__device__ __forceinline__ long long g_child(const GDims &f, const GDims &c, long long ec, int fi);
+
+// The same triple product for 27-node elements with the interpolation applied axis by axis: phi_f = Px (x) Py (x) Pz with 3 x 3
+// factors P_a[l][c] = w[l + 2 bit_a(f)][c], so a 27-vector is contracted in three passes of 27 x 3 multiply-adds instead of
+// 27 x 27.  Thread t < 243 owns, in the first half, row i = t / 3 and component b = t % 3 of the child's matrix
+// (T[i][(m,b)] = sum_q A[i][(q,b)] phi[q][m]) and, in the second half, component a = t / 81 and column j = t % 81
+// (out[(n,a)][j] += sum_q phi[q][n] T[(q,a)][j]); its 27 results of the second half stay in registers across the eight children.
+__device__ __forceinline__ void q2_contract27(double (&v)[27], const double (&P)[3][3][3]) {
+    // P[axis][l][c]; v index = 9 qx + 3 qy + qz  ->  9 mx + 3 my + mz
+    double t[27];
+#pragma unroll
+    for (int g = 0; g < 9; ++g)            // z: groups of 3 consecutive entries
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t[3 * g + c] = v[3 * g] * P[2][0][c] + v[3 * g + 1] * P[2][1][c] + v[3 * g + 2] * P[2][2][c];
+#pragma unroll
+    for (int x = 0; x < 3; ++x)            // y: stride 3
+#pragma unroll
+        for (int z = 0; z < 3; ++z)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                v[9 * x + 3 * c + z] = t[9 * x + z] * P[1][0][c] + t[9 * x + 3 + z] * P[1][1][c] + t[9 * x + 6 + z] * P[1][2][c];
+#pragma unroll
+    for (int r = 0; r < 9; ++r)            // x: stride 9
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t[9 * c + r] = v[r] * P[0][0][c] + v[9 + r] * P[0][1][c] + v[18 + r] * P[0][2][c];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) v[q] = t[q];
+}
+
+__global__ void __launch_bounds__(256) kg_coarsen_next_q2(GDims f, GDims c, GWeights W, const double *__restrict__ Kef,
+                                                          double *__restrict__ Kec) {
+    extern __shared__ double g_sm[];
+    constexpr int ke = 81, kk = ke * ke;
+    double *A = g_sm, *T = g_sm + kk;
+    const long long ec = blockIdx.x;
+    const int t = threadIdx.x;
+    const bool act = t < 243;
+    const int i1 = t / 3, b1 = t % 3;          // first half
+    const int a2 = t / 81, j2 = t % 81;        // second half
+    double acc[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+    for (int fi = 0; fi < 8; ++fi) {
+        const double *Kf = Kef + g_child(f, c, ec, fi) * kk;
+        double P[3][3][3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const int bit = (fi >> ax) & 1;
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) P[ax][l][cc] = bit ? W.w[l + 2][cc] : W.w[l][cc];
+        }
+        __syncthreads();                        // the previous child's T is no longer read
+        for (int q = t; q < kk; q += 256) A[q] = Kf[q];
+        __syncthreads();
+        if (act) {
+            double v[27];
+#pragma unroll
+            for (int q = 0; q < 27; ++q) v[q] = A[i1 * ke + 3 * q + b1];
+            q2_contract27(v, P);
+#pragma unroll
+            for (int m = 0; m < 27; ++m) T[i1 * ke + 3 * m + b1] = v[m];
+        }
+        __syncthreads();
+        if (act) {
+            double v[27];
+#pragma unroll
+            for (int q = 0; q < 27; ++q) v[q] = T[(3 * q + a2) * ke + j2];
+            q2_contract27(v, P);
+#pragma unroll
+            for (int n = 0; n < 27; ++n) acc[n] += v[n];
+        }
+    }
+    if (act) {
+#pragma unroll
+        for (int n = 0; n < 27; ++n) Kec[ec * kk + (3 * n + a2) * ke + j2] = acc[n];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // grid transfers (MG.hh:116-161): thread per node of the level written
 // ------------------------------------------------------------------------------------------
@@ -731,7 +811,11 @@ static void gmg_update(vfem_gmg *mg, hipStream_t s) {
             const dim3 grd((unsigned) lv.d.nelems), blk(256);
             const GDims &fd = mg->lv[l - 1].d;
             const double *Kf = mg->lv[l - 1].Ke.p;
-            if (N == 3 && sim->d.p == 2) kg_coarsen_next<3, 2><<<grd, blk, lds, s>>>(fd, lv.d, mg->phi.p, Kf, lv.Ke.p);
+            if (N == 3 && sim->d.p == 2) {
+                static bool attr2 = false;
+                if (!attr2) { VFEM_HIP(hipFuncSetAttribute((const void *) kg_coarsen_next_q2, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 81 * 81 * 8)); attr2 = true; }
+                kg_coarsen_next_q2<<<grd, blk, 2 * kk * sizeof(double), s>>>(fd, lv.d, mg->W, Kf, lv.Ke.p);
+            }
             else if (N == 3) kg_coarsen_next<3, 1><<<grd, blk, lds, s>>>(fd, lv.d, mg->phi.p, Kf, lv.Ke.p);
             else if (sim->d.p == 2) kg_coarsen_next<2, 2><<<grd, blk, lds, s>>>(fd, lv.d, mg->phi.p, Kf, lv.Ke.p);
             else kg_coarsen_next<2, 1><<<grd, blk, lds, s>>>(fd, lv.d, mg->phi.p, Kf, lv.Ke.p);
