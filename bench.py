@@ -45,6 +45,7 @@ def time_apply(tps, u, steps, warmup, variant=0):
     from ndr_amd import _lib
     from ndr_amd.pyVoxelFEM import _ptr, _stream
     lib = _lib.load()
+    _lib.check(lib.vfem_sim_apply_k(tps._h, _ptr(u), _ptr(out), int(variant), _stream()))     # first touch of `out`, untimed
     for a, b in evs:
         a.record()
         _lib.check(lib.vfem_sim_apply_k(tps._h, _ptr(u), _ptr(out), int(variant), _stream()))
