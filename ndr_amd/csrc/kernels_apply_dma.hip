@@ -1,7 +1,7 @@
 // k_apply_dma: the production stiffness apply with LDS-DMA staging.
 //
-// Same algorithm and tiling as k_apply_fast (kernels_apply.hip: mode-space element matrix, lanes = z, TY waves = TY
-// element rows, block marches along x, one barrier per plane), but the node planes and the element moduli are
+// Same algorithm as k_apply_fast (kernels_apply.hip: mode-space element matrix, lanes = z, 12 waves of element rows; a second
+// tile shape of 4 x 16 lanes per wave covers the node columns left over by the 63-wide tiles, see dma::Cfg), block marches along x, one barrier per plane), but the node planes and the element moduli are
 // brought in by `global_load_lds_dwordx4` straight into a 4-deep LDS ring instead of through registers:
 //   * no VGPRs and no ds_write instructions are spent on staging,
 //   * three planes stay in flight behind a *counted* `s_waitcnt vmcnt(N)` + raw `s_barrier` (hipcc drains every
@@ -26,29 +26,42 @@ namespace dma {
 #ifndef VFEM_DMA_TY
 #define VFEM_DMA_TY 12
 #endif
-constexpr int TY = VFEM_DMA_TY, TZ = 64;    // TY waves = TY element rows per block (8: 87.5 % of the lanes emit; 12: 91.7 %)
-constexpr int ROW_D = 196;                  // doubles per staged node row (98 pieces)
-constexpr int U_PIECES = (TY + 1) * 98;
-constexpr int U_INSTR = (U_PIECES + 63) / 64;          // 64 pieces of 16 B per instruction (TY = 8: 14, TY = 12: 20)
-constexpr int E_INSTR = (TY * 33 + 63) / 64;           // TY rows x 33 pieces (32 + 1 for the alignment shift) (5 / 7)
-static_assert(U_INSTR <= 2 * TY && U_INSTR + E_INSTR <= 3 * TY && E_INSTR <= TY, "every wave issues 2 or 3 DMA instructions per plane");
-static_assert(U_INSTR + E_INSTR >= 2 * TY, "every wave issues at least 2 DMA instructions per plane (wait_plane counts on it)");
-constexpr int SLOT_BYTES = U_INSTR * 1024 + E_INSTR * 1024;   // 18432
 #ifndef VFEM_DMA_RING
 #define VFEM_DMA_RING 4
 #endif
-constexpr int RING = VFEM_DMA_RING;     // planes staged per block; plane ii + RING - 1 is requested while plane ii is consumed
-constexpr int PD = RING - 1;
 #ifndef VFEM_DMA_WAVES
 #define VFEM_DMA_WAVES 2
 #endif
-constexpr int NW = VFEM_DMA_WAVES;      // waves that only issue the LDS-DMA (0: every compute wave issues its share and waits on it)
-constexpr int NQ = U_INSTR + E_INSTR;   // DMA instructions per plane
-constexpr int NI = NW > 0 ? (NQ + NW - 1) / NW : 0;      // per DMA wave
-static_assert(NW == 0 || NI * PD <= 63, "the planes in flight of one DMA wave must fit the 6-bit vmcnt");
-constexpr int SS_DOUBLES = 3 * TY * TZ;     // one scatter buffer (per component the sum owed to the next row in y)
-constexpr size_t LDS_BYTES = (size_t) RING * SLOT_BYTES + 2 * SS_DOUBLES * sizeof(double);
-static_assert(LDS_BYTES <= 160 * 1024, "ring + scatter buffers must fit the 160 KB of LDS of a CU");
+constexpr int WAVES = VFEM_DMA_TY;      // compute waves per block (8: 87.5 % of the element rows emit; 12: 91.7 %)
+constexpr int RING = VFEM_DMA_RING;     // planes staged per block; plane ii + RING - 1 is requested while plane ii is consumed
+constexpr int PD = RING - 1;
+constexpr int NW = VFEM_DMA_WAVES;      // waves that only issue and retire the LDS-DMA
+static_assert(NW == 1 || NW == 2, "one or two DMA waves");
+
+// Tile shape.  A wave holds SUB element rows of TZ element columns (SUB * TZ = 64 lanes):
+//   Main  = 1 x 64: 12 element rows x 64 columns per block, 11 x 63 complete node columns;
+//   Strip = 4 x 16: 48 element rows x 16 columns, 47 x 15 node columns -- for the few node columns a row of 2^k + 1 nodes
+//           leaves over after the 63-wide tiles (9 of 513, 5 of 257): with the main shape that remainder was a ninth (fifth)
+//           z-tile of blocks marching every plane for 14 % (8 %) of a block's work.
+template <int SUB_, int TZ_>
+struct Cfg {
+    static_assert(SUB_ * TZ_ == 64, "a wave is 64 lanes");
+    static constexpr int SUB = SUB_, TZ = TZ_, TY = WAVES * SUB_;
+    static constexpr int PU = ((TZ + 1) * 24 + 8 + 15) / 16;       // 16-byte pieces per staged node row incl. the alignment shift (98 / 26)
+    static constexpr int PE = (TZ * 8 + 8 + 15) / 16;              // per staged element row (33 / 9)
+    static constexpr int ROW_D = 2 * PU, EROW_D = 2 * PE;           // doubles per staged row
+    static constexpr int U_INSTR = ((TY + 1) * PU + 63) / 64;       // 64 pieces per DMA instruction (20 / 20)
+    static constexpr int E_INSTR = (TY * PE + 63) / 64;             // (7 / 7)
+    static constexpr int NQ = U_INSTR + E_INSTR;                    // DMA instructions per plane
+    static constexpr int NI = (NQ + NW - 1) / NW;                   // per DMA wave
+    static_assert(NI * PD <= 63, "the planes in flight of one DMA wave must fit the 6-bit vmcnt");
+    static constexpr int SLOT_BYTES = NQ * 1024;
+    static constexpr int SS_DOUBLES = 3 * TY * TZ;                  // one scatter buffer (per component the sum owed to the next row in y)
+    static constexpr size_t LDS_BYTES = (size_t) RING * SLOT_BYTES + 2 * SS_DOUBLES * sizeof(double);
+    static_assert(LDS_BYTES <= 160 * 1024, "ring + scatter buffers must fit the 160 KB of LDS of a CU");
+};
+using Main = Cfg<1, 64>;
+using Strip = Cfg<4, 16>;
 }  // namespace dma
 
 struct DmArgs2 { double v[36]; };
@@ -60,34 +73,27 @@ __device__ __forceinline__ void glds16(const void *g, void *l) {
                                      (__attribute__((address_space(3))) void *) l, 16, 0, 0);
 }
 
-template <int CNT>   // CNT = LDS-DMA instructions this wave issues per plane (2 or 3)
-__device__ __forceinline__ void wait_plane(bool has_stores, bool steady) {
-    // retire the DMA of the oldest plane in flight (vmcnt retires in issue order); in the steady state PD - 1 newer planes
-    // (CNT instructions each) and the two output stores (dwordx4 + dwordx2) of each of the last PD - 1 phases were issued after it
+template <int EXP, class C>
+__device__ __forceinline__ void apply_tile(const Dims &d, const DmArgs2 &dm, const double *__restrict__ E,
+                                           const double *__restrict__ u, double *__restrict__ out,
+                                           int planes_per_chunk, const char *u_last, const char *e_last,
+                                           int plane_lo, int plane_hi, int kz_origin, int ztile, int ytile) {
     using namespace dma;
-    if (!steady) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-    if (has_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * (CNT + 2)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * CNT) : "memory");
-}
-
-template <int EXP>
-__global__ void __launch_bounds__(64 * (dma::TY + dma::NW)) k_apply_dma(Dims d, DmArgs2 dm, const double *__restrict__ E,
-                                                      const double *__restrict__ u, double *__restrict__ out,
-                                                      int planes_per_chunk, const char *u_last, const char *e_last,
-                                                      int plane_lo, int plane_hi) {
-    using namespace dma;
-    // 7 / 8: variants 6 / 0 with non-temporal stores; 9: variant 4 storing to two planes only; 10: variant 4 loading four planes only
-    // 11: variant 6 (stores only) with row-contiguous 16-byte stores of meaningless values (timing of the store pattern)
+    constexpr int TY = C::TY, TZ = C::TZ, PU = C::PU, PE = C::PE, ROW_D = C::ROW_D, EROW_D = C::EROW_D;
+    constexpr int U_INSTR = C::U_INSTR, NQ = C::NQ, NI = C::NI, SLOT_BYTES = C::SLOT_BYTES, SS_DOUBLES = C::SS_DOUBLES;
+    // ablations (vfem_debug_set(1, n), wrong results): 1 no LDS scatter, 2 no mode-space arithmetic, 3 neither, 4 memory skeleton,
+    // 5 DMA + barriers only, 6 stores + barriers only, 7 / 8: variants 6 / 0 with non-temporal stores, 9: variant 4 storing to two
+    // planes only, 10: variant 4 loading four planes only, 11: variant 6 with row-contiguous 16-byte stores
     constexpr int X = (EXP == 8) ? 0 : ((EXP == 7 || EXP == 11) ? 6 : (EXP >= 9 ? 4 : EXP));
     constexpr bool NT = EXP == 7 || EXP == 8;
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char *ring = smem;
     double *sS = reinterpret_cast<double *>(smem + (size_t) RING * SLOT_BYTES);
 
-    const int tz = threadIdx.x, ty = threadIdx.y;      // ty is wave-uniform (64 x 8 block)
-    const int wave = ty;
-    const int k0 = blockIdx.y * (TZ - 1) - 1;
-    const int j0 = blockIdx.z * (TY - 1) - 1;
+    const int lane = threadIdx.x, wave = threadIdx.y;
+    const int tz = lane % TZ, ty = wave * C::SUB + lane / TZ;     // element column / row inside the tile (compute waves)
+    const int k0 = kz_origin + ztile * (TZ - 1) - 1;
+    const int j0 = ytile * (TY - 1) - 1;
     const int p0 = plane_lo + blockIdx.x * planes_per_chunk;      // output planes [p0, p1] of [plane_lo, plane_hi]
     int p1 = p0 + planes_per_chunk - 1;
     if (p1 > plane_hi) p1 = plane_hi;
@@ -95,13 +101,8 @@ __global__ void __launch_bounds__(64 * (dma::TY + dma::NW)) k_apply_dma(Dims d, 
     const int k0u = k0 < 0 ? 0 : k0;                   // first node column held by a staged row image
     const int cshift = k0u - k0;                       // 0, or 1 in the first z tile
 
-    const int ej = j0 + ty, ek = k0 + tz;
-    const bool elem_ok = ej >= 0 && ej < d.ny && ek >= 0 && ek < d.nz;
-    const bool out_ok = ty >= 1 && tz >= 1 && ej < d.NY && ek < d.NZ;
     const long long plane = (long long) d.NY * d.NZ;
     const long long elayer = (long long) d.ny * d.nz;
-
-    // ---- DMA descriptors of this wave -----------------------------------------------------------
     // addresses in units of doubles from address 0, so that parities are those of the absolute 16-byte grid
     const long long ubase8 = (long long) (reinterpret_cast<uintptr_t>(u) >> 3);
     const long long ebase8 = (long long) (reinterpret_cast<uintptr_t>(E) >> 3);
@@ -109,10 +110,10 @@ __global__ void __launch_bounds__(64 * (dma::TY + dma::NW)) k_apply_dma(Dims d, 
     const int i_start = p0 > 0 ? p0 - 1 : 0;
     const int i_end = p1 + 1 < d.NX - 1 ? p1 + 1 : d.NX - 1;
 
-    // ---- DMA waves (ty >= TY): request the planes, retire them in order, keep in step with the barriers of the compute waves ----
+    // ---- DMA waves (wave >= WAVES): request the planes, retire them in order, keep in step with the barriers of the compute waves ----
     // Stores and loads of one wave retire through the same in-order vmcnt, so a wave that does both waits for the (slow)
     // completion of its older stores whenever it waits for a plane; waves that only load do not.
-    if (NW > 0 && ty >= TY) {
+    if (wave >= WAVES) {
         auto dma_loop = [&](auto Wc) {
             constexpr int W = decltype(Wc)::value;
             constexpr int Q0 = W * NI;
@@ -122,19 +123,19 @@ __global__ void __launch_bounds__(64 * (dma::TY + dma::NW)) k_apply_dma(Dims d, 
 #pragma unroll
             for (int t = 0; t < N; ++t) {
                 const int q = Q0 + t;
-                if (q < U_INSTR) {              // pieces [64 q, 64 q + 64) of the (TY+1) x 98 piece image of the node plane
-                    const int P = 64 * q + tz;
-                    int r = P / 98, c = P - r * 98;
-                    if (r > TY) { r = TY; c = 97; }
+                if (q < U_INSTR) {              // pieces [64 q, 64 q + 64) of the (TY+1) x PU piece image of the node plane
+                    const int P = 64 * q + lane;
+                    int r = P / PU, c = P - r * PU;
+                    if (r > TY) { r = TY; c = PU - 1; }
                     int jj = j0 + r;
                     jj = jj < 0 ? 0 : (jj > d.NY - 1 ? d.NY - 1 : jj);
                     const long long rs = 3LL * ((long long) jj * d.NZ + k0u);
                     go[t] = rs + 2LL * c;
                     par[t] = (int) ((ubase8 + rs) & 1);
-                } else {                        // pieces of the TY x 33 piece image of the element layer
-                    const int P = 64 * (q - U_INSTR) + tz;
-                    int r = P / 33, c = P - r * 33;
-                    if (r > TY - 1) { r = TY - 1; c = 32; }
+                } else {                        // pieces of the TY x PE piece image of the element layer
+                    const int P = 64 * (q - U_INSTR) + lane;
+                    int r = P / PE, c = P - r * PE;
+                    if (r > TY - 1) { r = TY - 1; c = PE - 1; }
                     int jj = j0 + r;
                     jj = jj < 0 ? 0 : (jj > d.ny - 1 ? d.ny - 1 : jj);
                     const long long rs = (long long) jj * d.nz + k0u;
@@ -181,45 +182,15 @@ __global__ void __launch_bounds__(64 * (dma::TY + dma::NW)) k_apply_dma(Dims d, 
             }
             if (p1 == d.NX - 1) __builtin_amdgcn_s_barrier();
         };
-        if (ty == TY) dma_loop(std::integral_constant<int, 0>{});
+        if (wave == WAVES) dma_loop(std::integral_constant<int, 0>{});
         else dma_loop(std::integral_constant<int, (NW > 1 ? 1 : 0)>{});
         return;
     }
-    // u: instruction j moves pieces [64 j, 64 j + 64) of the (TY+1) x 98 piece image; this wave owns j = wave, wave + TY
-    long long ugo[2];          // double offset (from plane start) of this lane's row start + 2 q
-    int upar[2];               // parity of (ubase8 + row start) at plane 0
-    bool uhas[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int j = wave + TY * s;
-        uhas[s] = NW == 0 && j < U_INSTR;
-        const int P = 64 * j + tz;
-        int r = P / 98, q = P - r * 98;
-        if (r > TY) { r = TY; q = 97; }
-        int jj = j0 + r;
-        jj = jj < 0 ? 0 : (jj > d.NY - 1 ? d.NY - 1 : jj);
-        const long long rs = 3LL * ((long long) jj * d.NZ + k0u);
-        ugo[s] = rs + 2LL * q;
-        upar[s] = (int) ((ubase8 + rs) & 1);
-    }
-    // E: instruction e moves pieces [64 e, 64 e + 64) of the TY x 33 piece image (32 + 1 for the shift);
-    // the E instructions go first to the waves that own a single u instruction (from the top), then to the waves below them
-    const int eidx = (TY - 1 - wave) < E_INSTR ? (TY - 1 - wave) : -1;
-    const bool ehas = NW == 0 && eidx >= 0;
-    long long ego = 0;
-    int epar0 = 0;
-    const int k0e = k0u;                               // element columns start at max(k0, 0) as well
-    {
-        const int P = 64 * (eidx < 0 ? 0 : eidx) + tz;
-        int r = P / 33, q = P - r * 33;
-        if (r > TY - 1) { r = TY - 1; q = 32; }
-        int jj = j0 + r;
-        jj = jj < 0 ? 0 : (jj > d.ny - 1 ? d.ny - 1 : jj);
-        const long long rs = (long long) jj * d.nz + k0e;
-        ego = rs + 2LL * q;
-        epar0 = (int) ((ebase8 + rs) & 1);
-    }
-    const int cnt = (uhas[1] ? 2 : 1) + (ehas ? 1 : 0);          // TY = 8: 2,2,2,3,3,3,2,2
+
+    // ---- compute waves ------------------------------------------------------------------------------
+    const int ej = j0 + ty, ek = k0 + tz;
+    const bool elem_ok = ej >= 0 && ej < d.ny && ek >= 0 && ek < d.nz;
+    const bool out_ok = ty >= 1 && tz >= 1 && ej < d.NY && ek < d.NZ;
     // parities of the rows this thread consumes (node rows ty, ty+1; element row ty)
     int rpar[2], erpar;
 #pragma unroll
@@ -230,73 +201,8 @@ __global__ void __launch_bounds__(64 * (dma::TY + dma::NW)) k_apply_dma(Dims d, 
     }
     {
         int jj = ej < 0 ? 0 : (ej > d.ny - 1 ? d.ny - 1 : ej);
-        erpar = (int) ((ebase8 + (long long) jj * d.nz + k0e) & 1);
+        erpar = (int) ((ebase8 + (long long) jj * d.nz + k0u) & 1);
     }
-
-    auto issue_plane = [&](int i, int sl) {            // node plane i + element layer min(i, nx-1) -> ring slot sl
-        if (X == 6) return;
-        unsigned char *slot = ring + (size_t) sl * SLOT_BYTES;
-        const int ip = i & ppar;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if (uhas[s]) {
-                // aligned piece: one double below the row start when (row start + plane offset) is odd
-                const long long off = 3LL * i * plane + ugo[s] - ((upar[s] + ip) & 1);
-                const char *g = reinterpret_cast<const char *>(u + off);
-                g = g > u_last ? u_last : g;
-                glds16(g, slot + 1024 * (wave + TY * s));
-            }
-        }
-        if (ehas) {
-            const int il = i < d.nx ? i : d.nx - 1;
-            const long long off = (long long) il * elayer + ego - ((epar0 + (il & epar)) & 1);
-            const char *g = reinterpret_cast<const char *>(E + off);
-            g = g > e_last ? e_last : g;
-            glds16(g, slot + U_INSTR * 1024 + 1024 * eidx);
-        }
-    };
-
-    // steady-state issue: per instruction slot two running pointers (planes of even / odd step parity), each advanced
-    // by two plane strides per use; the alignment shift alternates with the plane only when a plane holds an odd number
-    // of doubles, so it is folded into the two pointers once.  Only the last plane of the grid needs the end clamp.
-    const char *up_run[2][2];
-    const char *ep_run[2];
-    auto init_running = [&](int i_first) {            // i_first = plane issued by the first loop phase (step parity 0)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int i = i_first + k;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-                up_run[k][s2] = reinterpret_cast<const char *>(u + (3LL * i * plane + ugo[s2] - ((upar[s2] + (i & ppar)) & 1)));
-            ep_run[k] = reinterpret_cast<const char *>(E + ((long long) i * elayer + ego - ((epar0 + (i & epar)) & 1)));
-        }
-    };
-    auto issue_running = [&](int i, int k, int sl) {   // k = step parity (compile-time after unrolling), sl = ring slot
-        if (X == 6) return;
-        unsigned char *slot = ring + (size_t) sl * SLOT_BYTES;
-        const bool last = (i >= d.NX - 1);
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            if (uhas[s2]) {
-                const char *g = up_run[k][s2];
-                if (EXP == 10) g -= 24LL * plane * (i & ~3);
-                if (last) g = g > u_last ? u_last : g;
-                glds16(g, slot + 1024 * (wave + TY * s2));
-                up_run[k][s2] += 48LL * plane;         // two planes of 24 * plane bytes
-            }
-        }
-        if (ehas) {
-            const char *g = ep_run[k];
-            if (EXP == 10) g -= 8LL * elayer * (i & ~3);
-            if (i >= d.nx - 1) {                       // last layers: clamp the layer index and the address
-                const long long off = (long long) (d.nx - 1) * elayer + ego - ((epar0 + ((d.nx - 1) & epar)) & 1);
-                g = reinterpret_cast<const char *>(E + off);
-                g = g > e_last ? e_last : g;
-            }
-            glds16(g, slot + U_INSTR * 1024 + 1024 * eidx);
-            ep_run[k] += 16LL * elayer;
-        }
-    };
 
     // ---- per-thread read offsets into a slot (doubles) ----------------------------------------
     int c0 = tz - cshift, c1 = tz + 1 - cshift;
@@ -304,7 +210,7 @@ __global__ void __launch_bounds__(64 * (dma::TY + dma::NW)) k_apply_dma(Dims d, 
     const int o00 = ty * ROW_D + 3 * c0, o01 = ty * ROW_D + 3 * c1;
     const int o10 = (ty + 1) * ROW_D + 3 * c0, o11 = (ty + 1) * ROW_D + 3 * c1;
     int ce = tz - cshift; ce = ce < 0 ? 0 : ce;
-    const int oE0 = (U_INSTR * 1024) / 8 + ty * 66 + ce;       // element rows hold 33 pieces = 66 doubles
+    const int oE0 = (U_INSTR * 1024) / 8 + ty * EROW_D + ce;
 
     auto face_modes_at = [&](double f[4][3], const double *su, int q00, int q01, int q10, int q11) {
 #pragma unroll
@@ -322,8 +228,9 @@ __global__ void __launch_bounds__(64 * (dma::TY + dma::NW)) k_apply_dma(Dims d, 
             const double r = acc[0][c] + acc[2][c], t = acc[1][c] + acc[3][c];
             wa[c] = p - q;
             if (X == 1 || X >= 3) { wa[c] += (p + q) + (r - t) + (r + t); continue; }
-            // the two terms owed to the z-neighbour move one lane up (DPP), only the sum owed to the y-neighbour (next wave)
-            // goes through LDS: 3 instead of 9 doubles written and read per thread and plane
+            // the two terms owed to the z-neighbour move one lane up (DPP), only the sum owed to the y-neighbour (next row)
+            // goes through LDS: 3 instead of 9 doubles written and read per thread and plane.  In the strip shape lane tz = 0
+            // of a sub-row receives the last lane of the sub-row below: harmless, its column is never emitted.
             wa[c] += lane_below(p + q);
             sX[(c * TY + ty) * TZ + tz] = (r - t) + lane_below(r + t);
         }
@@ -426,12 +333,8 @@ __global__ void __launch_bounds__(64 * (dma::TY + dma::NW)) k_apply_dma(Dims d, 
         scatter_face(acc, wa, buf);
     };
 
-    // ---- prologue: planes i_start .. i_start+RING-1 issued, all retired once ---------------------------
+    // ---- prologue: planes i_start .. i_start+RING-1 were requested by the DMA waves and are retired once ------------------
     // ring slot of plane i is (i - i_start) mod RING
-#pragma unroll
-    for (int r = 0; r < RING; ++r)
-        if (i_start + r <= i_end) issue_plane(i_start + r, r);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     {
         const double *su = reinterpret_cast<const double *>(ring);
@@ -451,30 +354,19 @@ __global__ void __launch_bounds__(64 * (dma::TY + dma::NW)) k_apply_dma(Dims d, 
         qoff[k][0] = o00 + s0r; qoff[k][1] = o01 + s0r; qoff[k][2] = o10 + s1r; qoff[k][3] = o11 + s1r;
         eoff2[k] = oE0 + ((erpar + (i & epar)) & 1);
     }
-    init_running(i_start + RING);
-    const bool has_stores = X != 5 && ty >= 1 && ej < d.NY;
 
-    int buf = 0, phase = 0, cur = 1 % RING;          // cur = ring slot of the plane consumed by the next phase
+    int buf = 0, cur = 1 % RING;          // cur = ring slot of the plane consumed by the next phase
     auto run_phase = [&](int ii, int k) {
-        // the slot of plane ii + PD held plane ii - 1: every wave passed a barrier after reading it
-        if (ii + PD <= i_end) issue_running(ii + PD, k, cur == 0 ? RING - 1 : cur - 1);
         const double *su = reinterpret_cast<const double *>(ring + (size_t) cur * SLOT_BYTES);
         cur = cur + 1 == RING ? 0 : cur + 1;
         double wa[3];
         const double Enext = su[eoff2[k]];             // modulus of layer ii, used in the next phase
         process(Eprev, su, qoff[k], buf, wa);
         Eprev = Enext;
-        if (ii + 1 <= i_end) {
-            // counted wait: after plane ii+1's DMA this wave issued the stores of phases ii-2 and ii-1 and the DMA of
-            // planes ii+2 and ii+3; outside that steady state (start / end of the chunk) drain everything
-            const bool steady = (phase >= PD - 1) && (ii + PD <= i_end) && (ii - PD >= p0);
-            if (NW == 0) { if (cnt == 2) wait_plane<2>(has_stores, steady); else wait_plane<3>(has_stores, steady); }
-        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();                  // the DMA waves arrive here once plane ii + 1 has landed
         if (ii - 1 >= p0) emit_plane(ii - 1, wa, buf);
         buf ^= 1;
-        ++phase;
     };
     for (int ii = i_start + 1; ii <= i_end; ii += 2) {
         run_phase(ii, 0);
@@ -488,6 +380,26 @@ __global__ void __launch_bounds__(64 * (dma::TY + dma::NW)) k_apply_dma(Dims d, 
         emit_plane(d.NX - 1, wa, buf);
     }
 }
+
+// One launch for both tile shapes: blocks with blockIdx.y < n_main are main tiles; blockIdx.y == n_main is the strip over the
+// last node columns (origin `strip_origin`), which needs fewer y tiles -- the surplus blocks leave at once.  (As a launch of
+// its own the strip's few blocks marched alone at the end and gave back half of what they save.)
+template <int EXP>
+__global__ void __launch_bounds__(64 * (dma::WAVES + dma::NW)) k_apply_dma(Dims d, DmArgs2 dm, const double *__restrict__ E,
+                                                      const double *__restrict__ u, double *__restrict__ out,
+                                                      int planes_per_chunk, const char *u_last, const char *e_last,
+                                                      int plane_lo, int plane_hi, int n_main, int strip_origin, int strip_ytiles, int strip_ppc) {
+    if ((int) blockIdx.y < n_main) {
+        if ((int) blockIdx.z * (dma::Main::TY - 1) > d.NY - 1) return;      // the grid's z extent covers the main shape's y tiles
+        apply_tile<EXP, dma::Main>(d, dm, E, u, out, planes_per_chunk, u_last, e_last, plane_lo, plane_hi, 0, (int) blockIdx.y, (int) blockIdx.z);
+    } else {
+        if (EXP != 0 || (int) blockIdx.z >= strip_ytiles) return;
+        // the strip may use longer x-chunks than the main tiles (fewer, longer blocks); chunks beyond its last plane leave inside
+        if (EXP == 0) apply_tile<0, dma::Strip>(d, dm, E, u, out, strip_ppc, u_last, e_last, plane_lo, plane_hi, strip_origin, 0, (int) blockIdx.z);
+    }
+}
+
+int g_dma_strip = 1;         // vfem_debug_set(9, 0): tile the whole row with the main shape (no strip launch)
 
 bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, const double *E_alloc_end, const double *u,
                       double *out, hipStream_t s, int plane_lo, int plane_hi) {
@@ -505,27 +417,32 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
     if (np >= 1024) nchunks = 16;
     if (g_dma_chunks > 0 && np >= 4 * g_dma_chunks) nchunks = g_dma_chunks;
     const int ppc = (np + nchunks - 1) / nchunks;
-    dim3 blk(TZ, TY + NW, 1), grd((np + ppc - 1) / ppc, (d.NZ + TZ - 2) / (TZ - 1), (d.NY + TY - 2) / (TY - 1));
-    static bool attr = false;
-    if (!attr) {
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
-        attr = true;
-    }
+    const unsigned gx = (unsigned) ((np + ppc - 1) / ppc);
     // last admissible (aligned) piece: the one holding the last byte of each array
     auto last_piece = [](const char *end) { return reinterpret_cast<const char *>((reinterpret_cast<uintptr_t>(end) - 1) & ~(uintptr_t) 15); };
     extern int g_apply_skeleton;
-#define VFEM_DMA_LAUNCH(X) k_apply_dma<X><<<grd, blk, LDS_BYTES, s>>>(d, dm, E, u, out, ppc, last_piece(u_end), last_piece(e_end), plane_lo, plane_hi)
+    // z tiling: 63 node columns per main tile; a remainder of at most 15 columns goes to the strip shape (47 x 15 per block)
+    const int wz = Main::TZ - 1;
+    int n_main = (d.NZ + wz - 1) / wz, rem = 0;
+    if (g_dma_strip && g_apply_skeleton == 0 && d.NZ > wz) {
+        const int r = d.NZ - wz * (d.NZ / wz);
+        if (r > 0 && r <= Strip::TZ - 1) { n_main = d.NZ / wz; rem = r; }
+    }
+    const int ytiles = (d.NY + Main::TY - 2) / (Main::TY - 1), strip_ytiles = rem > 0 ? (d.NY + Strip::TY - 2) / (Strip::TY - 1) : 0;
+    const dim3 grd(gx, (unsigned) (n_main + (rem > 0 ? 1 : 0)), (unsigned) ytiles), blk(64, WAVES + NW, 1);
+    // the strip's blocks are few: with x-chunks twice as long the launch at 512^3 fits 12 rounds of 256 blocks instead of 12.1
+    const int strip_ppc = (g_dma_strip == 2 || gx < 2) ? ppc : 2 * ppc;
+    static_assert(Main::LDS_BYTES == Strip::LDS_BYTES, "both tile shapes use the same dynamic LDS size");
+    const char *ul = last_piece(u_end), *el = last_piece(e_end);
+#define VFEM_DMA_LAUNCH(X)                                                                                                   \
+    do {                                                                                                                     \
+        static bool attr = false;                                                                                            \
+        if (!attr) {                                                                                                         \
+            VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) Main::LDS_BYTES)); \
+            attr = true;                                                                                                     \
+        }                                                                                                                    \
+        k_apply_dma<X><<<grd, blk, Main::LDS_BYTES, s>>>(d, dm, E, u, out, ppc, ul, el, plane_lo, plane_hi, n_main, wz * n_main, strip_ytiles, strip_ppc); \
+    } while (0)
     switch (g_apply_skeleton) {
         case 1: VFEM_DMA_LAUNCH(1); break;
         case 2: VFEM_DMA_LAUNCH(2); break;
@@ -540,6 +457,7 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
         case 11: VFEM_DMA_LAUNCH(11); break;
         default: VFEM_DMA_LAUNCH(0);
     }
+#undef VFEM_DMA_LAUNCH
     VFEM_HIP(hipGetLastError());
     return true;
 }

@@ -43,6 +43,31 @@ def test_apply_k(ne, dom, variant):
     assert relerr(got, ref) < TOL_OP
 
 
+@pytest.mark.parametrize("ne", [(9, 70, 64), (6, 50, 77), (5, 13, 78), (4, 95, 126), (7, 48, 140)])
+def test_apply_k_tile_shapes_agree(ne):
+    """z remainders of 2, 15, 16 (no strip), 1 and 15 node columns: the apply with the strip tile shape (4 x 16 lanes, default),
+    with the strip at the main tiles' chunk length and with main tiles only are bitwise the same, and match the oracle"""
+    from ndr_amd import _lib
+    from ndr_amd.pyVoxelFEM import _ptr, _stream
+    lib = _lib.load()
+    dom = ([0, 0, 0], [0.7, 1.3, 1.0])
+    rho = seeded_density(ne, 21)
+    t, o = make_hip(ne, dom, None, rho), make_oracle(ne, dom, None, rho)
+    u = np.random.default_rng(4).standard_normal((o.num_nodes, 3))
+    ud = torch.as_tensor(u, device="cuda")
+    res = {}
+    try:
+        for mode in (1, 2, 0):
+            lib.vfem_debug_set(9, mode)
+            out = torch.empty_like(ud)
+            _lib.check(lib.vfem_sim_apply_k(t._h, _ptr(ud), _ptr(out), 0, _stream()))
+            res[mode] = out
+    finally:
+        lib.vfem_debug_set(9, 1)
+    assert torch.equal(res[1], res[0]) and torch.equal(res[2], res[0])
+    assert relerr(res[1].cpu().numpy(), o.apply_k(u)) < 1e-12
+
+
 def test_apply_k_linearity_and_symmetry_large():
     """size-independent properties at a size the oracle would not finish quickly: <Ku,v> = <u,Kv>."""
     import torch
