@@ -9,7 +9,7 @@
 //     its memory skeleton alone ran at 3 TB/s whatever the prefetch depth),
 //   * the DMA is issued and retired by NW dedicated waves (ty >= TY) that do no arithmetic and no stores: `vmcnt`
 //     retires in issue order, so a wave that both loads and stores waits for its own older stores whenever it waits
-//     for a plane; the compute waves never wait on `vmcnt` at all (NW = 0 builds the earlier shared form),
+//     for a plane; the compute waves never wait on `vmcnt` at all,
 //   * a plane is read one phase after the wait+barrier that retires it (MI355X_MICROARCH.md, two-waves item 7).
 // A DMA piece is 16 bytes on the absolute 16-byte grid of memory: a tile row (65 nodes = 1560 B) starts on an 8-byte
 // boundary, so its image starts at the aligned address at or 8 bytes below it and the consumer adds that one-double
