@@ -60,7 +60,10 @@ struct Cfg {
     static constexpr size_t LDS_BYTES = (size_t) RING * SLOT_BYTES + 2 * SS_DOUBLES * sizeof(double);
     static_assert(LDS_BYTES <= 160 * 1024, "ring + scatter buffers must fit the 160 KB of LDS of a CU");
 };
-using Main = Cfg<1, 64>;
+#ifndef VFEM_DMA_MAIN_SUB
+#define VFEM_DMA_MAIN_SUB 1
+#endif
+using Main = Cfg<VFEM_DMA_MAIN_SUB, 64 / VFEM_DMA_MAIN_SUB>;
 using Strip = Cfg<4, 16>;
 }  // namespace dma
 
