@@ -97,3 +97,23 @@ def test_region_parser_matches_reference_semantics(tmp_path):
     bad.write_text('{"regions": [{"type": "traction", "value": [0,0,0], "box%": {"minCorner": [0,0,0], "maxCorner": [1,1,1]}}]}')
     with pytest.raises(RuntimeError):
         _parse_regions(str(bad))
+
+
+def test_pipelined_scalar_loads_are_hazard_free(tmp_path):
+    """k_apply_q2_march leaves scalar loads in flight across compiler-generated code (sload12_issue / sload12_wait); that is
+    only safe while no instruction touches the destination SGPRs before the wait.  Compile the kernel to ISA (cross-compile,
+    no GPU needed) and scan it."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "ndr_amd", "csrc", "kernels_q2.hip")
+    asm = str(tmp_path / "q2.s")
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=on", "-S", "--cuda-device-only",
+                           src, "-o", asm], stderr=subprocess.DEVNULL)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_sload_pipeline.py"), asm, "k_apply_q2_marchILi0"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert " 0 violations" in out.stdout and "84 request..wait windows" in out.stdout, out.stdout
