@@ -42,7 +42,8 @@ int  vfem_set_device(int device);
 int  vfem_version(void);
 int  vfem_debug_set(int key, int value);   /* tuning/diagnostic knobs: 0 apply planes-in-flight (2..4), 1 apply ablation variant, 2 GS variant,
                                               6 degree-2 apply (0 marching, 1 dense gather, 2 pencil), 7 apply x-chunks,
-                                              8 MLP forward ablation, 9 apply z-remainder strip (0 off, 1 on, 2 on with the main chunk length) */
+                                              8 MLP forward ablation, 9 apply z-remainder strip (0 off, 1 on, 2 on with the main chunk length),
+                                              10 level-0 Gauss-Seidel: fused z-colour pairs (1) or one launch per colour (0) */
 
 /* ---- raw device memory helpers (for callers without their own HIP allocator) ---- */
 int vfem_malloc(void **ptr, size_t bytes);

@@ -19,7 +19,7 @@
 
 namespace vfem {
 
-extern int g_apply_pd, g_apply_skeleton, g_gs_variant, g_apply_store, g_dma_chunks, g_dma_strip;
+extern int g_apply_pd, g_apply_skeleton, g_gs_variant, g_apply_store, g_dma_chunks, g_dma_strip, g_gs_pair;
 }
 extern int g_q2_impl;
 int g_mlp_ablate = 0;       // vfem_debug_set(8, v): MLP forward timing ablations
@@ -322,6 +322,7 @@ int vfem_debug_set(int key, int value) {
     else if (key == 8) g_mlp_ablate = value;
     else if (key == 7) vfem::g_dma_chunks = value;
     else if (key == 9) vfem::g_dma_strip = value;
+    else if (key == 10) vfem::g_gs_pair = value;
     else return 1;
     return 0;
 }

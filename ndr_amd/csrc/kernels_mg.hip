@@ -202,18 +202,14 @@ void build_gs_table(const double *K0, double *tab /* 72*12 */) {
     }
 }
 
-__global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__restrict__ tab, const double *__restrict__ E,
-                                                     double *__restrict__ u, const double *__restrict__ b,
-                                                     const uint8_t *__restrict__ mask, int cx, int cy, int cz, int forward) {
-    __shared__ double rowbuf[4][GS_ROWBUF];
-    const int lane = threadIdx.x, wy = threadIdx.y;
-    const int l0 = blockIdx.x * 64;
-    const int x = 2 * blockIdx.z + cx;
-    const int y = 2 * (blockIdx.y * 4 + wy) + cy;
-    if (y >= d.NY || x >= d.NX) return;                 // wave-uniform; no block-level barrier below
+// one z-segment (64 colour nodes from colour index l0) of the colour row (x, y): the work of one wave
+__device__ __forceinline__ void gs_row_segment_mf0(const Dims &d, const double *__restrict__ tab, const double *__restrict__ E,
+                                                   double *__restrict__ u, const double *__restrict__ b,
+                                                   const uint8_t *__restrict__ mask, int x, int y, int l0, int cz, int forward,
+                                                   double *buf) {
+    const int lane = threadIdx.x;
     const int z = 2 * (l0 + lane) + cz;
     const int zlo = 2 * l0 + cz - 1;                    // first node of the staged segment
-    double *buf = rowbuf[wy];
     const bool node_ok = z < d.NZ;
 
     // staged doubles q = lane + 64 s; loads are unconditional with the offset clamped into the row: values
@@ -356,6 +352,47 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
     for (int c = 0; c < 3; ++c) u[3 * n + c] = uself[c] + ud[c];      // the node's own value came through the staged row
 }
 
+__global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__restrict__ tab, const double *__restrict__ E,
+                                                     double *__restrict__ u, const double *__restrict__ b,
+                                                     const uint8_t *__restrict__ mask, int cx, int cy, int cz, int forward) {
+    __shared__ double rowbuf[4][GS_ROWBUF];
+    const int x = 2 * blockIdx.z + cx;
+    const int y = 2 * (blockIdx.y * 4 + threadIdx.y) + cy;
+    if (y >= d.NY || x >= d.NX) return;                 // wave-uniform; no block-level barrier below
+    gs_row_segment_mf0(d, tab, E, u, b, mask, x, y, blockIdx.x * 64, cz, forward, rowbuf[threadIdx.y]);
+}
+
+// Both z colours of the rows (cx, cy) in one launch: a wave owns its row over the whole z extent and relaxes, segment by segment,
+// first the nodes of colour c1 and then those of the other colour between them -- the same arithmetic as two launches of
+// k_gs_rows_mf0 (bitwise the same result), but the nine node rows of a segment are fetched from HBM once for both colours (the
+// second time they come from L2): the sweep is bound by the HBM traffic of its passes over u and E.  No other wave of the launch
+// reads this row (rows of equal parity are two apart), and the order A(s+1) before B(s) (even colour first) resp. A(s), B(s)
+// (odd colour first) keeps every first-colour update ahead of the second-colour updates that read it and behind none.
+__global__ void __launch_bounds__(256) k_gs_rows_mf0_pair(Dims d, const double *__restrict__ tab, const double *__restrict__ E,
+                                                          double *__restrict__ u, const double *__restrict__ b,
+                                                          const uint8_t *__restrict__ mask, int cx, int cy, int c1, int forward) {
+    __shared__ double rowbuf[4][GS_ROWBUF];
+    const int x = 2 * blockIdx.z + cx;
+    const int y = 2 * (blockIdx.y * 4 + threadIdx.y) + cy;
+    if (y >= d.NY || x >= d.NX) return;                 // wave-uniform; no block-level barrier below
+    double *buf = rowbuf[threadIdx.y];
+    const int c2 = 1 - c1;
+    const int nA = ((d.NZ - 1 - c1) / 2 + 1 + 63) / 64, nB = d.NZ - 1 - c2 < 0 ? 0 : ((d.NZ - 1 - c2) / 2 + 1 + 63) / 64;
+    const int lag = c1 == 0 ? 1 : 0;                    // even colour first: the last node of B(s) needs the first node of A(s+1)
+    const int steps = nA > nB + lag ? nA : nB + lag;
+    for (int s = 0; s < steps; ++s) {
+        if (s < nA) gs_row_segment_mf0(d, tab, E, u, b, mask, x, y, 64 * s, c1, forward, buf);
+        if (s - lag >= 0 && s - lag < nB) {
+            // the first-colour values this wave has just stored are read back below (same wave, in order; the fence makes the
+            // stores complete before the loads are issued)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            gs_row_segment_mf0(d, tab, E, u, b, mask, x, y, 64 * (s - lag), c2, forward, buf);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+    }
+}
+
 
 
 // ------------------------------------------------------------------------------------------
@@ -481,6 +518,8 @@ bool coarsened_matrices_are_mirror_images(const double *cK0 /* 8 x 576, host */)
 
 int g_mf1_sym = 0;     // set by the hierarchy when coarsened_matrices_are_mirror_images() holds
 
+int g_gs_pair = 1;       // vfem_debug_set(10, 0): the two z colours of a row in separate launches
+
 void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *gs_tab, const double *E, double *u,
                         const double *b, const uint8_t *mask, int forward, int xparity, int first, int count, hipStream_t s) {
     for (int ci = first; ci < first + count; ++ci) {
@@ -489,6 +528,12 @@ void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const doubl
         if (cx > d.NX - 1) continue;
         const int cntx = (d.NX - 1 - cx) / 2 + 1, cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
         dim3 blk(64, 4, 1), grd((cntz + 63) / 64, (cnty + 3) / 4, cntx);
+        if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab && g_gs_pair && ((ci - first) % 2 == 0) && ci % 2 == 0 && ci + 1 < first + count && d.NZ >= 3) {
+            // colours 2m and 2m+1 of the sweep order differ in cz only: one launch, the wave walks its row through both
+            k_gs_rows_mf0_pair<<<dim3(1, (cnty + 3) / 4, cntx), blk, 0, s>>>(d, gs_tab, E, u, b, mask, cx, cy, cz, forward);
+            ++ci;
+            continue;
+        }
         if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab) k_gs_rows_mf0<<<grd, blk, 0, s>>>(d, gs_tab, E, u, b, mask, cx, cy, cz, forward);
         else if (kind == OP_MF0) k_gs_color_mf<0><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
         else if (g_mf1_sym && g_gs_variant == 0 && gs_tab) k_gs_color_mf1_sym<<<grd, blk, 0, s>>>(d, K, gs_tab, E, u, b, mask, cx, cy, cz, forward);

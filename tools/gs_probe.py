@@ -17,6 +17,21 @@ nn = mg._nn(level)
 u = torch.randn((nn, 3), dtype=torch.float64, device="cuda", generator=g)
 b = torch.randn((nn, 3), dtype=torch.float64, device="cuda", generator=g)
 from ndr_amd.pyVoxelFEM import _ptr, _stream
+if level == 0:
+    base = None
+    for pair in (1, 0, 1, 0):
+        lib.vfem_debug_set(10, pair)
+        for fwd in (1, 0):
+            for rep in range(3):
+                uu = u.clone()
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                lib.vfem_mg_smooth(mg._h, level, _ptr(uu), _ptr(b), fwd, _stream())
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            if base is None: base = {}
+            base.setdefault(fwd, uu)
+            print("level 0 fused z-colour pairs %d forward %d: %.3f ms per sweep   max |diff| to first: %.3e" % (pair, fwd, dt * 1e3, float((uu - base[fwd]).abs().max())), flush=True)
+    lib.vfem_debug_set(10, 1)
 res = {}
 for variant in (0, 2, 1):
     lib.vfem_debug_set(2, variant)
