@@ -406,14 +406,12 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0_pair(Dims d, const double *
 // f the rows are the rows rho = li ^ f of cK0[0]; the column permutation m -> m ^ f and the signs are resolved at
 // compile time (register renaming, per-component partial sums).  Register footprint as the general kernel.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 4) k_gs_color_mf1_sym(Dims d, const double *__restrict__ K0c, const double *__restrict__ Dtab,
-                                                             const double *__restrict__ E, double *__restrict__ u,
-                                                             const double *__restrict__ b, const uint8_t *__restrict__ mask, int cx,
-                                                             int cy, int cz, int forward) {
-    const int k = 2 * (blockIdx.x * 64 + threadIdx.x) + cz;
-    const int j = 2 * (blockIdx.y * 4 + threadIdx.y) + cy;
-    const int i = 2 * blockIdx.z + cx;
-    if (k >= d.NZ || j >= d.NY || i >= d.NX) return;
+// relaxation of one level-1 node (i, j, k) with the mirror-symmetric child matrices: the work of one lane
+__device__ __forceinline__ void gs_node_mf1_sym(const Dims &d, const double *__restrict__ K0c, const double *__restrict__ Dtab,
+                                                const double *__restrict__ E, double *__restrict__ u,
+                                                const double *__restrict__ b, const uint8_t *__restrict__ mask, int i, int j, int k,
+                                                int forward) {
+    if (k >= d.NZ) return;
     const long long nyf = 2LL * d.ny, nzf = 2LL * d.nz;
     const long long sx = (long long) d.NY * d.NZ, sy = d.NZ;
     double S[3] = {0.0, 0.0, 0.0}, M[9];
@@ -489,6 +487,17 @@ __global__ void __launch_bounds__(256, 4) k_gs_color_mf1_sym(Dims d, const doubl
     gs_solve(bms, M, mask[n], forward != 0, ud);
 #pragma unroll
     for (int c = 0; c < 3; ++c) u[3 * n + c] += ud[c];
+}
+
+__global__ void __launch_bounds__(256, 4) k_gs_color_mf1_sym(Dims d, const double *__restrict__ K0c, const double *__restrict__ Dtab,
+                                                             const double *__restrict__ E, double *__restrict__ u,
+                                                             const double *__restrict__ b, const uint8_t *__restrict__ mask, int cx,
+                                                             int cy, int cz, int forward) {
+    const int k = 2 * (blockIdx.x * 64 + threadIdx.x) + cz;
+    const int j = 2 * (blockIdx.y * 4 + threadIdx.y) + cy;
+    const int i = 2 * blockIdx.z + cx;
+    if (j >= d.NY || i >= d.NX) return;
+    gs_node_mf1_sym(d, K0c, Dtab, E, u, b, mask, i, j, k, forward);
 }
 
 // diagonal blocks of cK0[0] for k_gs_color_mf1_sym: 8 groups of 12 doubles (9 used)

@@ -17,7 +17,7 @@ nn = mg._nn(level)
 u = torch.randn((nn, 3), dtype=torch.float64, device="cuda", generator=g)
 b = torch.randn((nn, 3), dtype=torch.float64, device="cuda", generator=g)
 from ndr_amd.pyVoxelFEM import _ptr, _stream
-if level == 0:
+if level in (0, 1):
     base = None
     for pair in (1, 0, 1, 0):
         lib.vfem_debug_set(10, pair)
@@ -30,7 +30,7 @@ if level == 0:
                 dt = time.perf_counter() - t0
             if base is None: base = {}
             base.setdefault(fwd, uu)
-            print("level 0 fused z-colour pairs %d forward %d: %.3f ms per sweep   max |diff| to first: %.3e" % (pair, fwd, dt * 1e3, float((uu - base[fwd]).abs().max())), flush=True)
+            print("level %d fused z-colour pairs %d forward %d: %.3f ms per sweep   max |diff| to first: %.3e" % (level, pair, fwd, dt * 1e3, float((uu - base[fwd]).abs().max())), flush=True)
     lib.vfem_debug_set(10, 1)
 res = {}
 for variant in (0, 2, 1):
