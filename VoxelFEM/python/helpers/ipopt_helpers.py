@@ -1,56 +1,29 @@
-"""Helper used by the reference drivers (VoxelFEM/python/helpers/ipopt_helpers.py:7-57): simulator set-up and the
-problem wrapper with its optimisation history.  The IPOPT branch itself is out of scope (cyipopt absent)."""
-import pyVoxelFEM
+"""Import shim for the reference drivers (they append VoxelFEM/python/helpers to sys.path and import these names,
+fem.py:13): simulator set-up and the object that carries the optimisation history.  IPOPT itself is out of scope
+(cyipopt absent), so `initializeIpoptProblem` returns no solver."""
+import pyVoxelFEM  # noqa: F401  (the shim next door: puts the repository root on sys.path)
+from ndr_amd.fem import initializeTensorProductSimulator  # noqa: F401,E402
 
 
 class optimizationHistory:
     def __init__(self):
-        self.objective = []
-        self.density = []
-        self.nondiscreteness = []
-
-
-def initializeTensorProductSimulator(orderFEM, domainCorners, numberElements, uniformDensity, E0, Emin, SIMPExp,
-                                     materialPath, bcsPath):
-    TPS = pyVoxelFEM.TensorProductSimulator(orderFEM, domainCorners, numberElements)
-    TPS.readMaterial(materialPath)
-    TPS.setUniformDensities(uniformDensity)
-    TPS.applyDisplacementsAndLoadsFromFile(bcsPath)
-    TPS.E_0 = E0
-    TPS.E_min = Emin
-    TPS.gamma = SIMPExp
-    return TPS
+        self.objective, self.density, self.nondiscreteness = [], [], []
 
 
 class problemObjectWrapper:
-    def __init__(self, problem, previousHistory=[]):
-        self.history = optimizationHistory() if previousHistory == [] else previousHistory
+    """holder of the problem and its history; the drivers hang their adaptive-filter settings on it (fem.py:54-55)"""
+
+    def __init__(self, problem, previousHistory=None):
         self.problem = problem
+        self.history = previousHistory if previousHistory else optimizationHistory()
         self.recordingHistory = True
 
     def setRecording(self, recording):
         self.recordingHistory = recording
 
-    def objective(self, x):
-        self.problem.setVars(x)
-        return self.problem.evaluateObjective()
 
-    def gradient(self, x):
-        self.problem.setVars(x)
-        return self.problem.evaluateObjectiveGradient()
-
-    def constraints(self, x):
-        self.problem.setVars(x)
-        return self.problem.evaluateConstraints()
-
-    def jacobian(self, x):
-        self.problem.setVars(x)
-        return self.problem.evaluateConstraintsJacobian()
-
-
-def initializeIpoptProblem(TOP, previousHistory=[], recording=True):
-    """Returns (nlp, problemObj).  Only problemObj (history, adaptive-filter attributes) is used on the OC path
-    (fem.py:47,55,80); nlp is None because cyipopt is not available."""
-    problemObj = problemObjectWrapper(TOP, previousHistory)
-    problemObj.setRecording(recording)
-    return None, problemObj
+def initializeIpoptProblem(TOP, previousHistory=None, recording=True):
+    """(None, problemObj): only problemObj is used on the OC path (fem.py:47,55,80)"""
+    wrapper = problemObjectWrapper(TOP, previousHistory)
+    wrapper.setRecording(recording)
+    return None, wrapper

@@ -71,11 +71,48 @@ def spmv_rate(ne, steps=50):
             "algorithmic_GBs": ab / sec / 1e9, "frac_of_8TBs": ab / sec / 1e9 / HBM_PEAK_GBS}
 
 
-def cpu_baseline(sample_ne, seconds_budget=12.0):
+def host_description():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"cpu_model": model, "logical_cores": os.cpu_count() or 1,
+            "usable_cores": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)}
+
+
+def cpu_cg_mg(ne=(128, 64, 64), levels=3):
+    """the reference-algorithm CG-MG (the oracle: element-loop applyK with thread-private accumulators, 8-colour
+    Gauss-Seidel, the same FMG/PCG control flow and settings as the GPU leg) on config 2's grid, timed on the host with
+    (i) the reference drivers' thread cap, min(cores, 8) (train_voxelfem.py:38-39), and (ii) all usable cores (at most 64)."""
+    from oracle import vfem_oracle as vo
+    from helpers import BC_CANTILEVER, make_oracle, seeded_density
+    cores = host_description()["usable_cores"]
+    o = make_oracle(ne, ([0, 0, 0], [2, 1, 1]), BC_CANTILEVER, seeded_density(ne, 88))
+    f = o.build_load_vector()
+    out = {"grid": "%dx%dx%d" % tuple(ne), "levels": levels, "settings": "tol 1e-4, 1 FMG cycle per iteration, 2+2 symmetric sweeps, zero initial guess"}
+    for key, threads in (("policy_i_reference_cap", min(cores, 8)), ("policy_ii_all_cores", min(cores, 64))):
+        if key == "policy_ii_all_cores" and threads == min(cores, 8):
+            out[key] = "same as policy (i): the host offers %d cores" % cores
+            continue
+        mg = vo.OracleMG(o, levels, nthreads=threads)
+        t0 = time.perf_counter()
+        u = mg.pcg(np.zeros_like(f), f, 100, 1e-4, 1, 2, True)
+        dt = time.perf_counter() - t0
+        out[key] = {"threads": threads, "iterations": mg.last_iters, "seconds": dt, "iterations_per_s": mg.last_iters / dt,
+                    "compliance": float(np.sum(f * u)), "includes": "operator update (Galerkin element matrices) as in MG.hh:690-691"}
+    return out
+
+
+def cpu_baseline(sample_ne, seconds_budget=8.0):
     """The oracle's element-loop applyK (ParallelAssembly-style private accumulators) on the host cores."""
     from oracle import vfem_oracle as vo
     from helpers import make_oracle, seeded_density
-    cores = os.cpu_count() or 1
+    cores = host_description()["usable_cores"]
     threads = min(cores, 8)          # the reference drivers cap applyK at min(physical cores, 8) threads
     o = make_oracle(sample_ne, ([0, 0, 0], [1, 1, 1]), None, seeded_density(sample_ne, 88))
     u = np.random.default_rng(0).standard_normal((o.num_nodes, 3))
@@ -101,6 +138,21 @@ def cpu_baseline(sample_ne, seconds_budget=12.0):
             if time.perf_counter() - t0 > 5.0 or reps2 >= 50:
                 break
         res["all_cores"] = {"value": o.num_elems * reps2 / (time.perf_counter() - t0) / 1e9, "cores": many, "repetitions": reps2}
+    res["host"] = host_description()
+    # the metric's other grid, 256^3 (one repetition is ~1 s of CPU work), and the solve on config 2's grid
+    del o, u
+    ne256 = (256, 256, 256)
+    o = make_oracle(ne256, ([0, 0, 0], [1, 1, 1]), None, seeded_density(ne256, 88))
+    u = np.random.default_rng(0).standard_normal((o.num_nodes, 3))
+    o.apply_k(u, threads)
+    t0, reps3 = time.perf_counter(), 0
+    while reps3 < 2:
+        o.apply_k(u, threads)
+        reps3 += 1
+    res["spmv_256"] = {"value": o.num_elems * reps3 / (time.perf_counter() - t0) / 1e9, "unit": "GVoxel/s", "cores": threads,
+                       "sample": "256x256x256 Q1 fp64 applyK, %d repetitions" % reps3}
+    del o, u
+    res["cg_mg"] = cpu_cg_mg()
     return res
 
 
@@ -182,7 +234,7 @@ def degree2_rate(ne=(512, 512, 512), reps=3):
     return {"grid": "%dx%dx%d" % tuple(ne), "nodes": t.numNodes(), "seconds": dt, "gvoxel_per_s": nvox / dt / 1e9,
             "algorithmic_GBs": ab / dt / 1e9, "frac_of_8TBs": ab / dt / 1e9 / HBM_PEAK_GBS,
             "algorithmic_bytes_per_voxel": ab / nvox,
-            "note": "marching kernel: reflection-mode blocks (855 of 6561 multiply-adds), x-march with in-block y hand-off, 2 colour launches, ~464 B/voxel moved"}
+            "note": "marching kernel: reflection-mode blocks (855 of 6561 multiply-adds), x-march with in-block y hand-off, 2 colour launches; 527 B/voxel moved by the counters (profiles/r01_q2march512_pmc.json)"}
 
 
 def degree2_pcg_rate(n=128, levels=5):
@@ -208,6 +260,33 @@ def degree2_pcg_rate(n=128, levels=5):
             "compliance": float((f * u).sum())}
 
 
+def _rank_main(rank, world, port, argv):
+    """entry of a rank process started by `launch_ranks` (fresh interpreter, nothing has touched the GPU yet)"""
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    sys.argv = [sys.argv[0]] + list(argv)
+    main()
+
+
+def launch_ranks(world, argv):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (spawn context: fresh children, no exec, and this
+    parent never initialises the GPU), wait for them, return the worst exit code.  Rank 0 prints the JSON line."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, argv)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    code = 0
+    for pr in procs:
+        pr.join()
+        code = max(code, abs(pr.exitcode or 0))
+    return code
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,10 +300,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: start the ranks ourselves.  With fewer devices than ranks (one-GPU box) the ranks share the devices
+        # and torch.distributed runs on gloo -- a rehearsal of the same code path, not a measurement.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py "
-                             "--gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the voxel-FEM path has no CPU fallback")
@@ -313,6 +393,7 @@ def main():
             except RuntimeError as e:
                 result["degree2_spmv"].append({"grid": "%dx%dx%d" % q2ne, "error": str(e)})
     if not args.no_cpu:
+        torch.cuda.synchronize()
         result["cpu_baseline"] = cpu_baseline((160, 160, 160))
     print(json.dumps(result))
 

@@ -18,7 +18,8 @@
  *     and return; calls that return scalars to the host synchronise that stream.
  *   - grids: row-major, last axis fastest (NDVector.hh:284-292); nodal fields are
  *     [numNodes][3] doubles (TPS.hh:227); densities/gradients are [numElements] doubles.
- *   - only degree-1 hexahedral elements in 3-D are on the device path in this release.
+ *   - vfem_sim / vfem_mg are the tuned degree-1 3-D path (TensorProductSimulator<1,1,1>); vfem_gsim / vfem_gmg
+ *     cover the other instantiations (2-D, degree 2) with the same semantics.
  */
 #ifndef VFEM_H
 #define VFEM_H
@@ -30,20 +31,32 @@
 extern "C" {
 #endif
 
-typedef struct vfem_sim vfem_sim;   /* TensorProductSimulator<1,1,1>              (TPS.hh:219) */
-typedef struct vfem_mg  vfem_mg;    /* MultigridSolver<1,1,1>                      (MG.hh:11)   */
-typedef struct vfem_mlp vfem_mlp;
-typedef struct vfem_gsim vfem_gsim;   /* TensorProductSimulator<p,..,p>, N = 2 or 3, p = 1 or 2 (generic path) */
-typedef struct vfem_gmg vfem_gmg;     /* MultigridSolver<p,..,p> of the generic path */ /* TensorProductSimulator<2,2,2> (27-node hexahedra; unbound in the reference, VoxelFEM.cc:226-229) */   /* networks.MLP (Fourier features + ReLU MLP)  (networks.py:128) */
+typedef struct vfem_sim vfem_sim;     /* TensorProductSimulator<1,1,1>                            (TPS.hh:219) */
+typedef struct vfem_mg  vfem_mg;      /* MultigridSolver<1,1,1>                                    (MG.hh:11)   */
+typedef struct vfem_mlp vfem_mlp;     /* networks.MLP (Fourier features + ReLU MLP)                (networks.py:128) */
+typedef struct vfem_gsim vfem_gsim;   /* TensorProductSimulator<p,..,p>, N = 2 or 3, p = 1 or 2; <2,2,2> = 27-node hexahedra,
+                                         unbound in the reference (VoxelFEM.cc:226-229) */
+typedef struct vfem_gmg vfem_gmg;     /* MultigridSolver<p,..,p> of the generic path */
 
 const char *vfem_last_error(void);
 int  vfem_device_count(void);                 /* number of visible HIP devices (0 => no GPU) */
 int  vfem_set_device(int device);
 int  vfem_version(void);
-int  vfem_debug_set(int key, int value);   /* tuning/diagnostic knobs: 0 apply planes-in-flight (2..4), 1 apply ablation variant, 2 GS variant,
-                                              6 degree-2 apply (0 marching, 1 dense gather, 2 pencil), 7 apply x-chunks,
-                                              8 MLP forward ablation, 9 apply z-remainder strip (0 off, 1 on, 2 on with the main chunk length),
-                                              10 level-0 Gauss-Seidel: fused z-colour pairs (1) or one launch per colour (0) */
+
+/* Per-simulator choice between implementations that agree to rounding (cross-checks in tests/, tuning); the defaults are
+   the production kernels.  (Timing ablations that produce wrong results are not part of this library: they exist only in
+   the separate `make ablation` build used by tools/.) */
+enum {
+    VFEM_OPT_APPLY_PLANES = 0,   /* register-staged apply: node planes in flight, 2..4 */
+    VFEM_OPT_GS_VARIANT   = 2,   /* 0 production sweeps, 1 plain gather sweeps */
+    VFEM_OPT_APPLY_IMPL   = 4,   /* 0 LDS-DMA apply, 1 register-staged apply */
+    VFEM_OPT_Q2_IMPL      = 6,   /* vfem_gsim: degree-2 apply 0 marching, 1 dense gather, 2 pencil */
+    VFEM_OPT_DMA_CHUNKS   = 7,   /* x-chunks of the marching apply (0 = default) */
+    VFEM_OPT_DMA_STRIP    = 9,   /* z-remainder strip tiles: 0 off, 1 on, 2 on with the main chunk length */
+    VFEM_OPT_GS_PAIR      = 10,  /* level-0 Gauss-Seidel: fused z-colour pairs (1) or one launch per colour (0) */
+    VFEM_OPT_GS_FUSED     = 11,  /* level-0 Gauss-Seidel: all eight colours in one pass over u (1) */
+    VFEM_OPT_L1_STENCIL   = 12   /* level 1: stored symmetric-half stencil (1) or matrix-free Galerkin form (0) */
+};
 
 /* ---- raw device memory helpers (for callers without their own HIP allocator) ---- */
 int vfem_malloc(void **ptr, size_t bytes);
@@ -66,6 +79,7 @@ int vfem_sim_set_isotropic(vfem_sim *sim, double young, double poisson);
 /* E_0 / E_min / gamma properties (VoxelFEM.cc:77-79; TPS.hh:1170-1175) */
 int vfem_sim_set_simp(vfem_sim *sim, double E0, double Emin, double gamma);
 /* fullDensityElementStiffnessMatrix (TPS.hh:755): 24x24 doubles, row-major, to HOST */
+int vfem_sim_set_option(vfem_sim *sim, int key, int value);
 int vfem_sim_k0(const vfem_sim *sim, double *K0_host);
 
 /* dirichletMask / dirichletValues properties (TPS.hh:413-442): mask[numNodes] bit c = component c fixed;
@@ -175,6 +189,7 @@ int vfem_gsim_k0(const vfem_gsim *sim, double *K0_host);           /* ke x ke ro
 int vfem_gsim_set_dirichlet(vfem_gsim *sim, const uint8_t *mask_host, const double *values_host);
 int vfem_gsim_set_densities(vfem_gsim *sim, const double *rho, void *stream);
 int vfem_gsim_get_densities(const vfem_gsim *sim, double *rho, void *stream);
+int vfem_gsim_set_option(vfem_gsim *sim, int key, int value);
 int vfem_gsim_apply_k(const vfem_gsim *sim, const double *u, double *out, void *stream);              /* TPS.hh:905-952 */
 int vfem_gsim_compliance_gradient(const vfem_gsim *sim, const double *u, double *g, void *stream);    /* TPS.hh:730-751 */
 int vfem_gsim_compliance(const vfem_gsim *sim, const double *f, const double *u, double *value_host, void *stream);  /* 1/2 f.u */

@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvfem.so")
+# VFEM_LIB: another build of the same library (tools/ use the `make ablation` build for their timing experiments)
+LIB_PATH = os.environ.get("VFEM_LIB") or os.path.join(_HERE, "csrc", "libvfem.so")
 _lib = None
 
 RESIDUAL_CB = ctypes.CFUNCTYPE(None, c_void_p, c_int, c_double)
@@ -20,7 +21,6 @@ SIGNATURES = {
     "vfem_device_count": (c_int, []),
     "vfem_set_device": (c_int, [c_int]),
     "vfem_version": (c_int, []),
-    "vfem_debug_set": (c_int, [c_int, c_int]),
     "vfem_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
     "vfem_free": (c_int, [c_void_p]),
     "vfem_copy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -34,6 +34,7 @@ SIGNATURES = {
     "vfem_sim_num_elements": (c_int64, [c_void_p]),
     "vfem_sim_set_isotropic": (c_int, [c_void_p, c_double, c_double]),
     "vfem_sim_set_simp": (c_int, [c_void_p, c_double, c_double, c_double]),
+    "vfem_sim_set_option": (c_int, [c_void_p, c_int, c_int]),
     "vfem_sim_k0": (c_int, [c_void_p, c_void_p]),
     "vfem_sim_set_dirichlet": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vfem_sim_set_loads": (c_int, [c_void_p, c_void_p, c_void_p]),
@@ -89,6 +90,7 @@ SIGNATURES = {
     "vfem_gsim_set_dirichlet": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vfem_gsim_set_densities": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vfem_gsim_get_densities": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "vfem_gsim_set_option": (c_int, [c_void_p, c_int, c_int]),
     "vfem_gsim_apply_k": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "vfem_gsim_compliance_gradient": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "vfem_gsim_compliance": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double), c_void_p]),
@@ -139,6 +141,9 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if hasattr(lib, "vfem_debug_set"):          # ablation build only (wrong-result timing variants for tools/)
+        lib.vfem_debug_set.restype = c_int
+        lib.vfem_debug_set.argtypes = [c_int, c_int]
     _lib = lib
     return lib
 

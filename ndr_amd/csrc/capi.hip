@@ -18,12 +18,6 @@
 #include <mutex>
 
 namespace vfem {
-
-extern int g_apply_pd, g_apply_skeleton, g_gs_variant, g_apply_store, g_dma_chunks, g_dma_strip, g_gs_pair;
-}
-extern int g_q2_impl;
-int g_mlp_ablate = 0;       // vfem_debug_set(8, v): MLP forward timing ablations
-namespace vfem {
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
@@ -196,18 +190,19 @@ static void mg_apply(vfem_mg *mg, int l, const double *u, const double *b, int r
     if (L.kind == OP_STENCIL) launch_apply_stencil(L.d, L.S.p, u, b, L.maskp, res, out, s);
     else if (L.kind == OP_MF0 && mg->fine->fast_ok) {
         const vfem_sim *sim = mg->fine;
-        if (res == 0 && g_apply_impl == 0 && launch_apply_dma(L.d, sim->Dm, level_E(mg, 0), sim->E.p + sim->n_store(), u, out, s)) return;
-        launch_apply_fast(L.d, sim->Dm, level_E(mg, 0), u, b, L.maskp, res, out, s);
+        const Tuning &t = sim->tune;
+        if (res == 0 && t.apply_impl == 0 &&
+            launch_apply_dma(L.d, sim->Dm, level_E(mg, 0), sim->E.p + sim->n_store(), u, out, s, 0, -1, t.dma_chunks, t.dma_strip)) return;
+        launch_apply_fast(L.d, sim->Dm, level_E(mg, 0), u, b, L.maskp, res, out, s, t.apply_pd);
     }
     else launch_apply_gather(L.d, L.kind, level_K(mg, l), level_E(mg, l), u, b, L.maskp, res, out, s);
 }
 
 static void mg_smooth(vfem_mg *mg, int l, double *u, const double *b, int forward, hipStream_t s, int first = 0, int count = 8) {
     MgLevel &L = mg->lv[l];
-    g_mf1_sym = mg->mf1_sym ? 1 : 0;
     if (L.kind == OP_STENCIL) launch_gs_sweep_stencil(L.d, L.S.p, u, b, L.maskp, forward, L.xparity, first, count, s);
     else launch_gs_sweep_mf(L.d, L.kind, level_K(mg, l), l == 0 ? mg->fine->dGsTab.p : mg->mf1diag.p, level_E(mg, l), u, b, L.maskp,
-                            forward, L.xparity, first, count, s);
+                            forward, L.xparity, first, count, s, mg->fine->tune, mg->mf1_sym);
 }
 
 static void coarsest_solve(vfem_mg *mg, const double *b, double *x, hipStream_t s) {
@@ -312,20 +307,16 @@ extern "C" {
 
 const char *vfem_last_error(void) { return vfem::g_err.c_str(); }
 int vfem_version(void) { return 100; }
+#ifdef VFEM_ABLATION
+// timing ablations with WRONG results (tools/ only): exists in `make ablation` builds of the library, never in the shipped one
 int vfem_debug_set(int key, int value) {
-    if (key == 0) vfem::g_apply_pd = value;
-    else if (key == 1) vfem::g_apply_skeleton = value;
-    else if (key == 2) vfem::g_gs_variant = value;
-    else if (key == 3) vfem::g_apply_store = value;
-    else if (key == 4) vfem::g_apply_impl = value;
-    else if (key == 6) g_q2_impl = value;
-    else if (key == 8) g_mlp_ablate = value;
-    else if (key == 7) vfem::g_dma_chunks = value;
-    else if (key == 9) vfem::g_dma_strip = value;
-    else if (key == 10) vfem::g_gs_pair = value;
+    if (key == 1) vfem::g_ablate_apply = value;
+    else if (key == 3) vfem::g_ablate_store = value;
+    else if (key == 8) vfem::g_ablate_mlp = value;
     else return 1;
     return 0;
 }
+#endif
 
 int vfem_device_count(void) {
     int n = 0;
@@ -385,6 +376,7 @@ int vfem_sim_create(vfem_sim **out, const double bbmin[3], const double bbmax[3]
     sim->loads.alloc((size_t) sim->d.nn * 3); sim->loads.zero(nullptr);
     sim->hmask.assign((size_t) sim->d.nn, 0);
     sim->hvals.assign((size_t) sim->d.nn * 3, 0.0);
+    sim->red.alloc(2048 + 8);
     VFEM_HIP(hipDeviceSynchronize());
     *out = sim.release();
     VFEM_CATCH
@@ -406,6 +398,22 @@ int vfem_sim_set_simp(vfem_sim *sim, double E0, double Emin, double gamma) {
     sim->E0 = E0; sim->Emin = Emin; sim->gamma = gamma;
     launch_simp(sim->n_store(), sim->rho.p, E0, Emin, gamma, sim->E.p, nullptr);
     VFEM_HIP(hipDeviceSynchronize());
+    VFEM_CATCH
+}
+int vfem_sim_set_option(vfem_sim *sim, int key, int value) {
+    VFEM_TRY
+    Tuning &t = sim->tune;
+    switch (key) {
+        case VFEM_OPT_APPLY_PLANES:  if (value < 2 || value > 4) throw Error("planes in flight must be 2..4"); t.apply_pd = value; break;
+        case VFEM_OPT_GS_VARIANT:    t.gs_variant = value != 0; break;
+        case VFEM_OPT_APPLY_IMPL:    t.apply_impl = value != 0; break;
+        case VFEM_OPT_DMA_CHUNKS:    if (value < 0) throw Error("negative chunk count"); t.dma_chunks = value; break;
+        case VFEM_OPT_DMA_STRIP:     if (value < 0 || value > 2) throw Error("strip mode must be 0..2"); t.dma_strip = value; break;
+        case VFEM_OPT_GS_PAIR:       t.gs_pair = value != 0; break;
+        case VFEM_OPT_GS_FUSED:      t.gs_fused = value != 0; break;
+        case VFEM_OPT_L1_STENCIL:    t.l1_stencil = value != 0; break;
+        default: throw Error("unknown simulator option " + std::to_string(key));
+    }
     VFEM_CATCH
 }
 int vfem_sim_k0(const vfem_sim *sim, double *K0_host) {
@@ -459,9 +467,10 @@ int vfem_sim_apply_k(const vfem_sim *sim, const double *u, double *out, int vari
     ScopedTimer tm("applyK");
     if (variant != 1 && sim->fast_ok) {
         bool done = false;
-        if (variant == 0 && g_apply_impl == 0)
-            done = launch_apply_dma(sim->d, sim->Dm, sim->Ep(), sim->E.p + sim->n_store(), u, out, S(stream));
-        if (!done) launch_apply_fast(sim->d, sim->Dm, sim->Ep(), u, nullptr, nullptr, 0, out, S(stream));
+        if (variant == 0 && sim->tune.apply_impl == 0)
+            done = launch_apply_dma(sim->d, sim->Dm, sim->Ep(), sim->E.p + sim->n_store(), u, out, S(stream), 0, -1,
+                                    sim->tune.dma_chunks, sim->tune.dma_strip);
+        if (!done) launch_apply_fast(sim->d, sim->Dm, sim->Ep(), u, nullptr, nullptr, 0, out, S(stream), sim->tune.apply_pd);
     }
     else launch_apply_gather(sim->d, OP_MF0, sim->dK0.p, sim->Ep(), u, nullptr, nullptr, 0, out, S(stream));
     VFEM_CATCH
@@ -471,7 +480,8 @@ int vfem_sim_apply_k_planes(const vfem_sim *sim, const double *u, double *out, i
     if (plane_lo < 0 || plane_hi > sim->d.NX - 1) throw Error("plane range outside the node grid");
     if (plane_lo > plane_hi) return 0;
     if (!sim->fast_ok) throw Error("plane-range apply needs the mode-space kernel (box voxels, isotropic tensor)");
-    if (!launch_apply_dma(sim->d, sim->Dm, sim->Ep(), sim->E.p + sim->n_store(), u, out, S(stream), (int) plane_lo, (int) plane_hi))
+    if (!launch_apply_dma(sim->d, sim->Dm, sim->Ep(), sim->E.p + sim->n_store(), u, out, S(stream), (int) plane_lo, (int) plane_hi,
+                          sim->tune.dma_chunks, sim->tune.dma_strip))
         throw Error("plane-range apply needs 8-byte aligned device buffers");
     VFEM_CATCH
 }
@@ -482,10 +492,10 @@ int vfem_sim_compliance_gradient(const vfem_sim *sim, const double *u, double *g
 }
 int vfem_compliance(const vfem_sim *sim, const double *f, const double *u, double *value_host, void *stream) {
     VFEM_TRY
-    DevBuf<double> tmp; tmp.alloc(2048 + 8);
-    launch_dot(3 * sim->d.nn, f, u, tmp.p + 8, tmp.p, S(stream));
+    double *tmp = sim->red.p;              // persistent scratch (allocated with the simulator): no hipMalloc/hipFree per evaluation
+    launch_dot(3 * sim->d.nn, f, u, tmp + 8, tmp, S(stream));
     double v = 0.0;
-    VFEM_HIP(hipMemcpyAsync(&v, tmp.p, sizeof(double), hipMemcpyDeviceToHost, S(stream)));
+    VFEM_HIP(hipMemcpyAsync(&v, tmp, sizeof(double), hipMemcpyDeviceToHost, S(stream)));
     VFEM_HIP(hipStreamSynchronize(S(stream)));
     *value_host = 0.5 * v;
     VFEM_CATCH
@@ -921,7 +931,7 @@ int vfem_mlp_load_weights(vfem_mlp *m, const float *B, const float *W1, const fl
 #include "mlp_args.h"
 static vfem::MlpArgs mlp_base_args(const vfem_mlp *m) {
     vfem::MlpArgs a{};
-    a.ablate = g_mlp_ablate;
+    a.ablate = ablate_mlp();
     a.es = m->es; a.nn = m->nn; a.n_hidden = m->n_layers - 2; a.sigmoid = m->sigmoid;
     a.B = m->B.p; a.W1 = m->W1.p; a.Wh = m->Wh.p; a.bias = m->bias.p; a.wout = m->wout.p; a.bout = m->bout;
     return a;

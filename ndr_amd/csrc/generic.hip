@@ -556,7 +556,6 @@ __global__ void __launch_bounds__(256) kg_gradient(GDims d, const double *__rest
 
 using namespace vfem;
 
-int g_q2_impl = 0;       // vfem_debug_set(6, v): 0 = marching kernel (mode space), 1 = dense gather kernel (cross-check), 2 = pencil kernel
 
 // ------------------------------------------------------------------------------------------
 // handles
@@ -570,6 +569,7 @@ struct vfem_gsim {
     DevBuf<double> dK0, rho, E, dvals;
     DevBuf<double> q2tab;                          // degree-2 hexahedra: packed mode-space blocks (q2_modes.h)
     bool q2_fast = false;
+    int q2_impl = 0;                               // vfem_gsim_set_option(6, v): 0 marching kernel (mode space), 1 dense gather kernel (cross-check), 2 pencil kernel
     DevBuf<uint8_t> dmask;
     std::vector<uint8_t> hmask;
     void update_k0();
@@ -713,8 +713,8 @@ static void level_op(const vfem_gmg *mg, int l, const double *&K, long long &kst
 
 static void gmg_apply(vfem_gmg *mg, int l, const double *u, const double *b, int mode, double *out, hipStream_t s) {
     const vfem_gsim *sim = mg->fine;
-    if (l == 0 && sim->d.N == 3 && sim->d.p == 2 && sim->q2_fast && g_q2_impl != 1) {       // finest degree-2 level: mode-space kernels
-        if (g_q2_impl == 0) launch_apply_q2_march(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E.p, u, out, s);
+    if (l == 0 && sim->d.N == 3 && sim->d.p == 2 && sim->q2_fast && sim->q2_impl != 1) {       // finest degree-2 level: mode-space kernels
+        if (sim->q2_impl == 0) launch_apply_q2_march(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E.p, u, out, s);
         else launch_apply_q2_pencil(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E.p, u, out, s);
         if (mode != 0) launch_q2_residual_fix(sim->d.nnodes, b, mg->lv[0].mask.p, mode, out, s);
         return;
@@ -726,7 +726,7 @@ static void gmg_apply(vfem_gmg *mg, int l, const double *u, const double *b, int
 
 static void gmg_smooth(vfem_gmg *mg, int l, double *u, const double *b, int forward, hipStream_t s) {
     const GDims &d = mg->lv[l].d;
-    if (l == 0 && d.N == 3 && d.p == 2 && g_q2_impl != 1) {                                  // finest degree-2 level: thread per node
+    if (l == 0 && d.N == 3 && d.p == 2 && mg->fine->q2_impl != 1) {                                  // finest degree-2 level: thread per node
         launch_gs_sweep_q2_level0(d.ne[0], d.ne[1], d.ne[2], mg->fine->dK0.p, mg->fine->E.p, u, b, mg->lv[0].mask.p, forward, s);
         return;
     }
@@ -1021,11 +1021,17 @@ int vfem_gsim_get_densities(const vfem_gsim *sim, double *rho, void *stream) {
     VFEM_HIP(hipMemcpyAsync(rho, sim->rho.p, (size_t) sim->d.nelems * sizeof(double), hipMemcpyDeviceToDevice, GS(stream)));
     G_CATCH
 }
+int vfem_gsim_set_option(vfem_gsim *sim, int key, int value) {
+    G_TRY
+    if (key == 6 && value >= 0 && value <= 2) sim->q2_impl = value;
+    else throw Error("unknown option or value out of range");
+    G_CATCH
+}
 int vfem_gsim_apply_k(const vfem_gsim *sim, const double *u, double *out, void *stream) {
     G_TRY
-    if (sim->d.N == 3 && sim->d.p == 2 && sim->q2_fast && g_q2_impl == 0)
+    if (sim->d.N == 3 && sim->d.p == 2 && sim->q2_fast && sim->q2_impl == 0)
         launch_apply_q2_march(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E.p, u, out, GS(stream));
-    else if (sim->d.N == 3 && sim->d.p == 2 && sim->q2_fast && g_q2_impl == 2)
+    else if (sim->d.N == 3 && sim->d.p == 2 && sim->q2_fast && sim->q2_impl == 2)
         launch_apply_q2_pencil(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E.p, u, out, GS(stream));
     else if (sim->d.N == 3 && sim->d.p == 2)
         launch_apply_q2(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->dK0.p, sim->E.p, u, out, GS(stream));

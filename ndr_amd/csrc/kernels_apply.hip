@@ -290,32 +290,35 @@ __global__ void __launch_bounds__(TY * TZ, WPS == 1 ? 2 : WPS) k_apply_fast(Dims
     }
 }
 
-bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, const double *E_alloc_end, const double *u,
-                      double *out, hipStream_t s);
-int g_apply_impl = 0;        // 0: LDS-DMA kernel (falls back to the register-staged one when it cannot run), 1: register-staged
-int g_apply_pd = 2;          // tuning knobs (vfem_debug_set): planes in flight, memory-skeleton diagnostic
-int g_apply_skeleton = 0;
-int g_apply_store = 0;
+#ifdef VFEM_ABLATION
+int g_ablate_apply = 0, g_ablate_store = 0, g_ablate_mlp = 0;
+#endif
 
 void launch_apply_fast(const Dims &d, const double *Dm_host, const double *E, const double *u, const double *b,
-                       const uint8_t *mask, int mode, double *out, hipStream_t s) {
+                       const uint8_t *mask, int mode, double *out, hipStream_t s, int pd) {
     DmArgs dm;
     for (int q = 0; q < 36; ++q) dm.v[q] = Dm_host[q];
     int nchunks = d.NX >= 64 ? 8 : (d.NX >= 16 ? 4 : 1);
     if (d.NX >= 1024) nchunks = 16;
     const int ppc = (d.NX + nchunks - 1) / nchunks;
     dim3 blk(TZ, TY, 1), grd((d.NX + ppc - 1) / ppc, (d.NZ + TZ - 2) / (TZ - 1), (d.NY + TY - 2) / (TY - 1));
-    if (g_apply_skeleton) {
-        if (g_apply_pd == 2)      k_apply_fast<0, 1, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, g_apply_store);
-        else if (g_apply_pd == 3) k_apply_fast<0, 1, 3><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, g_apply_store);
-        else                      k_apply_fast<0, 1, 4><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, g_apply_store);
-    } else if (mode == 0) {
-        if (g_apply_pd == 2)      k_apply_fast<0, 2, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, g_apply_store);
-        else if (g_apply_pd == 3) k_apply_fast<0, 2, 3><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, g_apply_store);
-        else                      k_apply_fast<0, 2, 4><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, g_apply_store);
+    const int st = ablate_store();
+#ifdef VFEM_ABLATION
+    if (ablate_apply()) {      // memory skeleton (wrong results, timing only)
+        if (pd == 2)      k_apply_fast<0, 1, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, st);
+        else if (pd == 3) k_apply_fast<0, 1, 3><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, st);
+        else              k_apply_fast<0, 1, 4><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, st);
+        VFEM_HIP(hipGetLastError());
+        return;
     }
-    else if (mode == 1) k_apply_fast<1, 2, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, g_apply_store);
-    else                k_apply_fast<2, 2, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, g_apply_store);
+#endif
+    if (mode == 0) {
+        if (pd == 2)      k_apply_fast<0, 2, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, st);
+        else if (pd == 3) k_apply_fast<0, 2, 3><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, st);
+        else              k_apply_fast<0, 2, 4><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, st);
+    }
+    else if (mode == 1) k_apply_fast<1, 2, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, st);
+    else                k_apply_fast<2, 2, 2><<<grd, blk, 0, s>>>(d, dm, E, u, b, mask, out, ppc, st);
     VFEM_HIP(hipGetLastError());
 }
 

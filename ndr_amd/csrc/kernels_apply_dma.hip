@@ -69,8 +69,6 @@ using Strip = Cfg<4, 16>;
 
 struct DmArgs2 { double v[36]; };
 
-int g_dma_chunks = 0;        // vfem_debug_set(7, n): number of x-chunks of the marching blocks (0 = default)
-
 __device__ __forceinline__ void glds16(const void *g, void *l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) g,
                                      (__attribute__((address_space(3))) void *) l, 16, 0, 0);
@@ -84,7 +82,7 @@ __device__ __forceinline__ void apply_tile(const Dims &d, const DmArgs2 &dm, con
     using namespace dma;
     constexpr int TY = C::TY, TZ = C::TZ, PU = C::PU, PE = C::PE, ROW_D = C::ROW_D, EROW_D = C::EROW_D;
     constexpr int U_INSTR = C::U_INSTR, NQ = C::NQ, NI = C::NI, SLOT_BYTES = C::SLOT_BYTES, SS_DOUBLES = C::SS_DOUBLES;
-    // ablations (vfem_debug_set(1, n), wrong results): 1 no LDS scatter, 2 no mode-space arithmetic, 3 neither, 4 memory skeleton,
+    // ablations (-DVFEM_ABLATION builds only, vfem_debug_set(1, n), wrong results): 1 no LDS scatter, 2 no mode-space arithmetic, 3 neither, 4 memory skeleton,
     // 5 DMA + barriers only, 6 stores + barriers only, 7 / 8: variants 6 / 0 with non-temporal stores, 9: variant 4 storing to two
     // planes only, 10: variant 4 loading four planes only, 11: variant 6 with row-contiguous 16-byte stores
     constexpr int X = (EXP == 8) ? 0 : ((EXP == 7 || EXP == 11) ? 6 : (EXP >= 9 ? 4 : EXP));
@@ -402,10 +400,9 @@ __global__ void __launch_bounds__(64 * (dma::WAVES + dma::NW)) k_apply_dma(Dims 
     }
 }
 
-int g_dma_strip = 1;         // vfem_debug_set(9, 0): tile the whole row with the main shape (no strip launch)
-
+// chunks: number of x-chunks of the marching blocks (0 = default); strip: 0 tiles the whole row with the main shape
 bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, const double *E_alloc_end, const double *u,
-                      double *out, hipStream_t s, int plane_lo, int plane_hi) {
+                      double *out, hipStream_t s, int plane_lo, int plane_hi, int g_dma_chunks, int g_dma_strip) {
     using namespace dma;
     if (plane_hi < 0 || plane_hi > d.NX - 1) plane_hi = d.NX - 1;
     if (plane_lo < 0) plane_lo = 0;
@@ -423,7 +420,7 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
     const unsigned gx = (unsigned) ((np + ppc - 1) / ppc);
     // last admissible (aligned) piece: the one holding the last byte of each array
     auto last_piece = [](const char *end) { return reinterpret_cast<const char *>((reinterpret_cast<uintptr_t>(end) - 1) & ~(uintptr_t) 15); };
-    extern int g_apply_skeleton;
+    const int g_apply_skeleton = ablate_apply();
     // z tiling: 63 node columns per main tile; a remainder of at most 15 columns goes to the strip shape (47 x 15 per block)
     const int wz = Main::TZ - 1;
     int n_main = (d.NZ + wz - 1) / wz, rem = 0;
@@ -446,6 +443,7 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
         }                                                                                                                    \
         k_apply_dma<X><<<grd, blk, Main::LDS_BYTES, s>>>(d, dm, E, u, out, ppc, ul, el, plane_lo, plane_hi, n_main, wz * n_main, strip_ytiles, strip_ppc); \
     } while (0)
+#ifdef VFEM_ABLATION
     switch (g_apply_skeleton) {
         case 1: VFEM_DMA_LAUNCH(1); break;
         case 2: VFEM_DMA_LAUNCH(2); break;
@@ -460,6 +458,9 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
         case 11: VFEM_DMA_LAUNCH(11); break;
         default: VFEM_DMA_LAUNCH(0);
     }
+#else
+    VFEM_DMA_LAUNCH(0);
+#endif
 #undef VFEM_DMA_LAUNCH
     VFEM_HIP(hipGetLastError());
     return true;

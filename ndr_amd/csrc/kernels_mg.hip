@@ -93,8 +93,6 @@ __device__ __forceinline__ void mf_node(const Dims &d, const double *__restrict_
     }
 }
 
-int g_gs_variant = 0;   // 0: row-streaming level-0 sweep, 1: plain gather sweep (cross-check)
-
 // ------------------------------------------------------------------------------------------
 // apply / residual, matrix-free gather form
 // ------------------------------------------------------------------------------------------
@@ -525,12 +523,12 @@ bool coarsened_matrices_are_mirror_images(const double *cK0 /* 8 x 576, host */)
     return err <= 1e-13 * scale;
 }
 
-int g_mf1_sym = 0;     // set by the hierarchy when coarsened_matrices_are_mirror_images() holds
-
-int g_gs_pair = 1;       // vfem_debug_set(10, 0): the two z colours of a row in separate launches
-
+// mf1_sym: coarsened_matrices_are_mirror_images() holds for the hierarchy (level-1 sweeps read cK0[0] only)
 void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *gs_tab, const double *E, double *u,
-                        const double *b, const uint8_t *mask, int forward, int xparity, int first, int count, hipStream_t s) {
+                        const double *b, const uint8_t *mask, int forward, int xparity, int first, int count, hipStream_t s,
+                        const Tuning &tune, bool mf1_sym) {
+    const int g_gs_variant = tune.gs_variant, g_gs_pair = tune.gs_pair;
+    const bool g_mf1_sym = mf1_sym;
     for (int ci = first; ci < first + count; ++ci) {
         const int lni = forward ? ci : 7 - ci;
         const int cx = ((lni >> 2) & 1) ^ (xparity & 1), cy = (lni >> 1) & 1, cz = lni & 1;   // global -> local x parity

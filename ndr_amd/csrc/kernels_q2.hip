@@ -582,14 +582,17 @@ void launch_apply_q2_march(int nx, int ny, int nz, const double *tab, const doub
     for (int cb = 0; cb < 2; ++cb) {
         const int cnt = (nblk - cb + 1) / 2;
         if (cnt <= 0) continue;
-        extern int g_apply_skeleton;
         const dim3 grd(nchunk, cnt, nxc), blk(64, 4, 1);
-        switch (g_apply_skeleton) {
+#ifdef VFEM_ABLATION
+        switch (vfem::ablate_apply()) {
             case 1: k_apply_q2_march<1><<<grd, blk, 0, s>>>(d, tab, E, u, out, cb, xsteps); break;
             case 2: k_apply_q2_march<2><<<grd, blk, 0, s>>>(d, tab, E, u, out, cb, xsteps); break;
             case 3: k_apply_q2_march<3><<<grd, blk, 0, s>>>(d, tab, E, u, out, cb, xsteps); break;
             default: k_apply_q2_march<0><<<grd, blk, 0, s>>>(d, tab, E, u, out, cb, xsteps);
         }
+#else
+        k_apply_q2_march<0><<<grd, blk, 0, s>>>(d, tab, E, u, out, cb, xsteps);
+#endif
     }
     VFEM_HIP(hipGetLastError());
 }

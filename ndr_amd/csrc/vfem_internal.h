@@ -72,22 +72,45 @@ void launch_apply_gather(const Dims &d, OpKind kind, const double *K, const doub
                          const double *b, const uint8_t *mask, int res, double *out, hipStream_t s);
 void launch_apply_stencil(const Dims &d, const double *S, const double *u, const double *b, const uint8_t *mask,
                           int res, double *out, hipStream_t s);
+// Per-simulator choices between equivalent (bitwise or to rounding) implementations: cross-checks and tuning, set through
+// vfem_sim_set_option.  Nothing here changes results beyond rounding; the wrong-result timing ablations are a separate
+// build (-DVFEM_ABLATION, `make ablation`) and do not exist in the shipped library.
+struct Tuning {
+    int apply_impl = 0;     // 0: LDS-DMA kernel (register-staged kernel when it cannot run), 1: register-staged kernel
+    int apply_pd = 2;       // register-staged kernel: node planes in flight (2..4)
+    int dma_chunks = 0;     // x-chunks of the marching blocks (0 = default)
+    int dma_strip = 1;      // 0: main tile shape only, 1: strip tiles for the left-over node columns, 2: strip with main-length chunks
+    int gs_variant = 0;     // 0: row-streaming / symmetric sweeps, 1: plain gather sweeps
+    int gs_pair = 1;        // level 0: both z colours of a row in one launch
+    int gs_fused = 1;       // level 0: all eight colours in one pass over u (k_gs_sweep_mf0)
+    int l1_stencil = 1;     // level 1: stored symmetric-half stencil instead of the matrix-free Galerkin form (when memory allows)
+};
+#ifdef VFEM_ABLATION
+extern int g_ablate_apply, g_ablate_store, g_ablate_mlp;   // vfem_debug_set (ablation build only): wrong results, timing only
+inline int ablate_apply() { return g_ablate_apply; }
+inline int ablate_store() { return g_ablate_store; }
+inline int ablate_mlp() { return g_ablate_mlp; }
+#else
+constexpr int ablate_apply() { return 0; }
+constexpr int ablate_store() { return 0; }
+constexpr int ablate_mlp() { return 0; }
+#endif
+
 // production level-0 apply (symmetry-reduced, x-marching)
 void launch_apply_fast(const Dims &d, const double *Dm_host, const double *E, const double *u, const double *b,
-                       const uint8_t *mask, int mode, double *out, hipStream_t s);
+                       const uint8_t *mask, int mode, double *out, hipStream_t s, int planes_in_flight = 2);
 // LDS-DMA version of the plain apply (mode 0); returns false when it must not be used for these buffers
 bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, const double *E_alloc_end, const double *u,
-                      double *out, hipStream_t s, int plane_lo = 0, int plane_hi = -1);
-extern int g_apply_impl;
+                      double *out, hipStream_t s, int plane_lo = 0, int plane_hi = -1, int chunks = 0, int strip = 1);
 
 // colours are processed in the reference order (global parity); `xparity` = global x-parity of local plane 0,
 // [first, first+count) selects a sub-range of the 8 colours (half sweeps between halo exchanges)
 void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *gs_tab, const double *E, double *u,
-                        const double *b, const uint8_t *mask, int forward, int xparity, int first, int count, hipStream_t s);
+                        const double *b, const uint8_t *mask, int forward, int xparity, int first, int count, hipStream_t s,
+                        const Tuning &tune, bool mf1_sym);
 void build_gs_table(const double *K0, double *tab /* 72*12 doubles */);
 bool coarsened_matrices_are_mirror_images(const double *cK0_host /* 8 x 576 */);
 void build_mf1_diag_table(const double *cK0_0, double *tab /* 8*12 */);
-extern int g_mf1_sym;
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
                              int forward, int xparity, int first, int count, hipStream_t s);
 
@@ -165,6 +188,8 @@ struct vfem_sim {
     bool nonzero_dirichlet = false;
     // slab decomposition: element arrays (rho, E) may hold extra x-layers in front of / behind the node grid
     long long ex_lo = 0, ex_hi = 0;
+    vfem::Tuning tune;
+    vfem::DevBuf<double> red;                   // scratch of the reductions (vfem_compliance)
     long long n_store() const { return (long long) (d.nx + ex_lo + ex_hi) * d.ny * d.nz; }
     const double *Ep() const { return E.p + ex_lo * d.ny * d.nz; }
     const double *rhop() const { return rho.p + ex_lo * d.ny * d.nz; }

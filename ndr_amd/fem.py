@@ -1,8 +1,8 @@
-"""Driver-level mirror of the reference's ``fem.py`` for the accelerated path: the ground-truth OC loop
-(``fem.ground_truth_topopt``, fem.py:20-106) and the autograd bridge used by train_xdg
-(``fem.VoxelFEMFunction``, fem.py:109-134), on top of ``ndr_amd.pyVoxelFEM``.  Plotting / .vtr export of the
-reference drivers is out of scope; everything numerical keeps the reference's call sequence and its
-hard-coded settings (E0 = 1, Emin = 1e-4, tol 1e-4, one FMG cycle per CG iteration, 2+2 sweeps)."""
+"""Driver-level entry points of the accelerated path with the names the reference's ``fem.py`` exports: the ground-truth
+OC loop (``ground_truth_topopt``; here a thin wrapper over ``DesignLoop``) and the autograd bridge used by train_xdg
+(``VoxelFEMFunction``), on top of ``ndr_amd.pyVoxelFEM``.  Plotting of the reference drivers is out of scope (SURVEY
+8f-4); everything numerical keeps the reference's hard-coded settings (E0 = 1, Emin = 1e-4, tol 1e-4, one FMG cycle per
+CG iteration, 2+2 sweeps)."""
 import sys
 import time
 
@@ -13,103 +13,124 @@ import torch.autograd as autograd
 from . import pyVoxelFEM
 
 
-class _History:
-    def __init__(self):
-        self.objective = []
-
-
-class _ProblemObj:
-    def __init__(self, top):
-        self.problem = top
-        self.history = _History()
-        self.beta_interval = self.beta_scaler = self.radius_interval = self.radius_scaler = None
-
-
 def initializeTensorProductSimulator(orderFEM, domainCorners, numberElements, uniformDensity, E0, Emin, SIMPExp,
                                      materialPath, bcsPath):
-    """VoxelFEM/python/helpers/ipopt_helpers.py:7-15"""
+    """Same arguments as the reference helper (ipopt_helpers.py:7-15): simulator with material, BCs and SIMP law set."""
     tps = pyVoxelFEM.TensorProductSimulator(orderFEM, domainCorners, numberElements)
     tps.readMaterial(materialPath)
     tps.setUniformDensities(uniformDensity)
     tps.applyDisplacementsAndLoadsFromFile(bcsPath)
-    tps.E_0 = E0
-    tps.E_min = Emin
-    tps.gamma = SIMPExp
+    tps.E_0, tps.E_min, tps.gamma = E0, Emin, SIMPExp
     return tps
+
+
+class DesignLoop:
+    """One ground-truth optimisation run (what fem.ground_truth_topopt sets up, fem.py:20-106) as an object: simulator,
+    compliance objective, volume constraint, smoothing + projection filters and the optimality-criterion update.  All
+    vectors stay in HBM between iterations; only the scalar compliance comes back per step.
+
+    Reference behaviour kept: E0 = 1 and Emin = 1e-4 whatever the problem file says (fem.py:31-32), the solver settings of
+    fem.py:64-70, the design starts at the uniform volume fraction, compliance is reported as f.u = 2 x evaluateObjective."""
+
+    SOLVER = {"tol": 1e-4, "mgIterations": 1, "fullMultigrid": True, "zeroInit": False, "mgSmoothingIterations": 2}
+
+    def __init__(self, material, bcs, order, corners, grid, simp_exponent, volume_fraction, mg_levels, use_multigrid=True):
+        corners = [np.asarray(c, dtype=np.float64) for c in corners]
+        self.order = list(order)
+        self.tps = initializeTensorProductSimulator(self.order, corners, grid, volume_fraction, 1, 1e-4, simp_exponent,
+                                                    material, bcs)
+        if use_multigrid:
+            self.objective = pyVoxelFEM.MultigridComplianceObjective(self.tps.multigridSolver(mg_levels))
+            for name, value in self.SOLVER.items():
+                setattr(self.objective, name, value)
+        else:
+            self.objective = pyVoxelFEM.ComplianceObjective(self.tps)
+        self.problem = pyVoxelFEM.TopologyOptimizationProblem(
+            self.tps, self.objective, [pyVoxelFEM.TotalVolumeConstraint(volume_fraction)],
+            [pyVoxelFEM.SmoothingFilter(), pyVoxelFEM.ProjectionFilter()])
+        self.history = []
+        self.adaptive_filtering = None          # stored for the drivers, never read on the OC path (fem.py:54-55)
+
+    def seed(self, design=None):
+        """start from `design` (array or tensor of design variables) or from the simulator's current densities"""
+        if design is None:
+            design = self.tps.getDensities()
+        elif isinstance(design, torch.Tensor):
+            design = design.detach().cpu().numpy()
+        self.problem.setVars(np.asarray(design, dtype=np.float64).reshape(-1))
+
+    def compliance(self):
+        return 2.0 * self.problem.evaluateObjective()
+
+    def run(self, steps, log=None):
+        oc = pyVoxelFEM.OCOptimizer(self.problem)
+        clock = time.perf_counter()
+        for k in range(steps):
+            c = self.compliance()
+            self.history.append(c)
+            if log is not None:
+                log.write('Total Steps: {:d}, Runtime: {:.1f}, Compliance loss {:.6f}\n'.format(k, time.perf_counter() - clock, c))
+            clock = time.perf_counter()
+            oc.step()
+        return self.history
+
+    def thresholded_compliance(self):
+        """compliance of the design rounded to {0, 1} at 0.5 (utils.compute_binary_compliance_loss); the design is restored"""
+        x = self.tps.getDensities()
+        self.problem.setVars((x > 0.5).astype(np.float64))
+        c = self.compliance()
+        self.problem.setVars(x)
+        return c
 
 
 def ground_truth_topopt(MATERIAL_PATH, BC_PATH, orderFEM, domainCorners, gridDimensions, SIMPExponent, maxVolume,
                         optimizer, multigrid_levels, use_multigrid=True, adaptive_filtering=[1, 1, 1, 1],
                         max_iter=100, init=None, obj_history=False, verbose=True, **kwargs):
-    """fem.ground_truth_topopt (fem.py:20-106), optimizer 'OC' only (the L-BFGS branch needs cyipopt)."""
-    E0, Emin = 1, 1e-4                                             # fem.py:31-32 (the JSON values are ignored)
-    constraints = [pyVoxelFEM.TotalVolumeConstraint(maxVolume)]
-    filters = [pyVoxelFEM.SmoothingFilter(), pyVoxelFEM.ProjectionFilter()]
-    domain = [np.asarray(domainCorners[0], dtype=np.float64), np.asarray(domainCorners[1], dtype=np.float64)]
-    tps = initializeTensorProductSimulator(orderFEM, domain, gridDimensions, maxVolume, E0, Emin, SIMPExponent,
-                                           MATERIAL_PATH, BC_PATH)
-    if use_multigrid:
-        objective = pyVoxelFEM.MultigridComplianceObjective(tps.multigridSolver(multigrid_levels))
-    else:
-        objective = pyVoxelFEM.ComplianceObjective(tps)
-    top = pyVoxelFEM.TopologyOptimizationProblem(tps, objective, constraints, filters)
-    problemObj = _ProblemObj(top)
-    if adaptive_filtering is not None:
-        (problemObj.beta_interval, problemObj.beta_scaler, problemObj.radius_interval,
-         problemObj.radius_scaler) = adaptive_filtering
-    if init is not None:
-        init = np.asarray(init.detach().cpu().numpy() if isinstance(init, torch.Tensor) else init, dtype=np.float64)
-        top.setVars(init.flatten())
-    if use_multigrid:
-        objective.tol = 1e-4                                       # fem.py:64-70
-        objective.mgIterations = 1
-        objective.fullMultigrid = True
-        objective.zeroInit = False
-        objective.mgSmoothingIterations = 2
+    """Signature and return value of the reference's fem.ground_truth_topopt (fem.py:20-106); optimizer 'OC' only (the
+    L-BFGS branch is IPOPT, out of scope).  Returns (tps | densities for 2-D, final compliance, thresholded compliance
+    [, history])."""
     if optimizer != 'OC':
         raise ValueError('Optimizer {} is unknown or not implemented.'.format(optimizer))
-    oco = pyVoxelFEM.OCOptimizer(top)
-    top.setVars(tps.getDensities())
-    iter_start_time = 0
-    for idx in range(max_iter):
-        iter_time = time.perf_counter() - iter_start_time
-        objective_value = 2.0 * top.evaluateObjective()
-        problemObj.history.objective.append(objective_value)
-        if verbose:
-            sys.stderr.write('Total Steps: {:d}, Runtime: {:.1f}, Compliance loss {:.6f}\n'.format(idx, iter_time, objective_value))
-        iter_start_time = time.perf_counter()
-        oco.step()
-    x0 = tps.getDensities()
-    density_binary = (x0 > 0.5) * 1.0                              # utils.compute_binary_compliance_loss
-    top.setVars(density_binary.astype(np.float64))
-    binary_objective = 2.0 * top.evaluateObjective()
-    top.setVars(x0)
-    out = (tps if len(orderFEM) == 3 else tps.getDensities(), 2.0 * top.evaluateObjective(), binary_objective)
-    return out + (problemObj.history.objective,) if obj_history else out
+    loop = DesignLoop(MATERIAL_PATH, BC_PATH, orderFEM, domainCorners, gridDimensions, SIMPExponent, maxVolume,
+                      multigrid_levels, use_multigrid)
+    loop.adaptive_filtering = adaptive_filtering
+    if init is not None:
+        loop.seed(init)
+    loop.seed()
+    loop.run(max_iter, sys.stderr if verbose else None)
+    binary = loop.thresholded_compliance()
+    result = (loop.tps if len(orderFEM) == 3 else loop.tps.getDensities(), loop.compliance(), binary)
+    return result + (loop.history,) if obj_history else result
+
+
+def _compliance_and_sensitivity(top, densities):
+    """f.u and d(f.u)/d(rho) for physical densities `densities` (any shape, float): the solver reads a device tensor in
+    place, a host tensor through numpy; the sensitivity comes back in float32 on the input's device (fem.py:125)"""
+    rho = densities.detach().to(torch.float64).reshape(-1)
+    if rho.is_cuda:
+        top.setVars(rho)
+        value = 2.0 * top.evaluateObjective()
+        sens = top.evaluateObjectiveGradient_device().to(torch.float32)
+    else:
+        top.setVars(rho.numpy())
+        value = 2.0 * top.evaluateObjective()
+        sens = torch.from_numpy(top.evaluateObjectiveGradient().astype(np.float32))
+    return value, sens.reshape(densities.shape)
 
 
 class VoxelFEMFunction(autograd.Function):
-    """fem.VoxelFEMFunction (fem.py:109-134): compliance of the predicted densities as an autograd node.  Densities
-    may live on the GPU; the sensitivity is returned in float32 on the input's device, as the reference does."""
+    """Compliance of the predicted densities as an autograd node (the reference's fem.VoxelFEMFunction, fem.py:109-134):
+    forward solves and caches the sensitivity, backward scales it by the incoming gradient."""
 
     @staticmethod
     def forward(ctx, densities, top):
-        dev = densities.device
-        if densities.is_cuda:                                      # zero-copy: the solver consumes the device tensor
-            top.setVars(densities.detach().to(torch.float64).reshape(-1))
-            output_objective = 2.0 * top.evaluateObjective()
-            grad = top.evaluateObjectiveGradient_device().to(torch.float32).reshape(densities.shape)
-        else:
-            top.setVars(densities.detach().to(torch.float64).numpy())
-            output_objective = 2.0 * top.evaluateObjective()
-            grad = torch.from_numpy(top.evaluateObjectiveGradient().astype(np.float32)).reshape(densities.shape)
-        ctx.save_for_backward(grad)
-        return torch.tensor(output_objective, device=dev).float()
+        value, sens = _compliance_and_sensitivity(top, densities)
+        ctx.save_for_backward(sens)
+        return torch.tensor(value, device=densities.device, dtype=torch.float32)
 
     @staticmethod
     def backward(ctx, grad_output):
-        (grad,) = ctx.saved_tensors
-        return grad * grad_output, None
+        return ctx.saved_tensors[0] * grad_output, None
 
 
 def save_for_interactive_vis(density, grid_dimensions, title, visualize, path):

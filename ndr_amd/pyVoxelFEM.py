@@ -12,6 +12,7 @@ problem cache) restate ``TopologyOptimization{Problem,Filter,Constraint}.hh`` an
 """
 import ctypes
 import json
+import os
 import sys
 import types
 
@@ -106,6 +107,100 @@ def _parse_regions(path):
     return regions
 
 
+class SuiteSparseMatrix:
+    """What ``TensorProductSimulator.getK()`` returns (TPS.hh:966-973): the assembled stiffness matrix in compressed-column
+    form, upper triangle only (TPS.hh:590-612 accumulates ``di <= dj``), with the attribute names of MeshFEM's binding
+    (python_bindings/sparse_matrices.cc:67-125): m, n, nz, Ap, Ai, Ax, symmetry_mode, trace(), apply(), toSciPy().
+    Host-side and assembled with numpy: a diagnostic of small problems, not part of the device path."""
+
+    def __init__(self, upper_csc):
+        self._A = upper_csc
+        self.m, self.n = upper_csc.shape
+        self.nz = int(upper_csc.nnz)
+        self.Ap = upper_csc.indptr.astype(np.int64)
+        self.Ai = upper_csc.indices.astype(np.int64)
+        self.Ax = upper_csc.data
+        self.symmetry_mode = "UPPER_TRIANGLE"
+
+    def trace(self):
+        return float(self._A.diagonal().sum())
+
+    def toSciPy(self):
+        return self._A.copy()
+
+    def full(self):
+        """the symmetric matrix the upper triangle stands for"""
+        import scipy.sparse as sp
+        return (self._A + sp.triu(self._A, 1).T).tocsc()
+
+    def apply(self, vec, transpose=False):
+        return self.full() @ np.asarray(vec, dtype=np.float64).reshape(-1)
+
+
+def _assemble_upper(elem_nodes, K0, young, ndof_per_node, num_nodes):
+    """sum_e E_e G_e^T K0 G_e, entries with row <= column (TPS.hh:590-625)"""
+    import scipy.sparse as sp
+    nd = ndof_per_node
+    dofs = (elem_nodes[:, :, None] * nd + np.arange(nd)[None, None, :]).reshape(elem_nodes.shape[0], -1)
+    ke = K0.shape[0]
+    n = num_nodes * nd
+    A = sp.csc_matrix((n, n))
+    step = max(1, (1 << 22) // (ke * ke))                  # bounded temporary: ~4 M triplets at a time
+    for a in range(0, dofs.shape[0], step):
+        d = dofs[a:a + step]
+        rows = np.repeat(d, ke, axis=1).reshape(-1)
+        cols = np.tile(d, (1, ke)).reshape(-1)
+        vals = (young[a:a + step, None] * K0.reshape(1, -1)).reshape(-1)
+        keep = rows <= cols
+        A = A + sp.coo_matrix((vals[keep], (rows[keep], cols[keep])), shape=(n, n)).tocsc()
+    A.sum_duplicates()
+    A.sort_indices()
+    return SuiteSparseMatrix(A)
+
+
+def _constant_strain_load(eps, lam, mu, h, degree, rho_grid):
+    """TPS::constantStrainLoad (TPS.hh:792-821 with Element::constantStrainLoad, :145-173): nodal load of the unit strain
+    ``eps`` (N x N symmetric): every element contributes  rho_e * vol * (C : eps) . int grad(phi_j)  to its node j -- the
+    RAW density scales the load (no SIMP law, TPS.hh:813).  int grad(phi_j) factorises over the axes of the tensor-product
+    Lagrange basis: int phi' = phi(1) - phi(0), int phi = the Newton-Cotes weights."""
+    N = len(h)
+    eps = np.asarray(eps, dtype=np.float64).reshape(N, N)
+    sigma = lam * np.trace(eps) * np.eye(N) + 2.0 * mu * 0.5 * (eps + eps.T)            # isotropic C : eps
+    I = {1: np.array([0.5, 0.5]), 2: np.array([1.0, 4.0, 1.0]) / 6.0}[degree]
+    dI = {1: np.array([-1.0, 1.0]), 2: np.array([-1.0, 0.0, 1.0])}[degree]
+    vol = float(np.prod(h))
+    ne = rho_grid.shape
+    nn = tuple(n * degree + 1 for n in ne)
+    F = torch.zeros(nn + (N,), dtype=torch.float64, device=rho_grid.device)
+    for loc in np.ndindex(*([degree + 1] * N)):
+        g = np.array([dI[loc[k]] / h[k] * np.prod([I[loc[m]] for m in range(N) if m != k]) for k in range(N)])
+        load = torch.as_tensor(vol * (sigma @ g), dtype=torch.float64, device=rho_grid.device)
+        sl = tuple(slice(loc[d], loc[d] + degree * ne[d], degree) for d in range(N))
+        F[sl] += rho_grid[..., None] * load
+    return F.reshape(-1, N)
+
+
+def _densities_from_msh(path, field, ne, N):
+    """TPS::readDensities (TPS.hh:470-509): per-element scalar field of a Gmsh file; an element's grid cell is found from
+    its vertex centroid relative to the bounding box of the mesh vertices"""
+    if not str(path).endswith(".msh"):
+        raise RuntimeError("Material file extension" + os.path.splitext(str(path))[1] + " is not supported")
+    from . import io
+    parser = io.MSHFieldParser3(path)
+    values = np.asarray(parser.scalarField(field), dtype=np.float64).reshape(-1)
+    V, E = np.asarray(parser.vertices(), dtype=np.float64), np.asarray(parser.elements())
+    nel = int(np.prod(ne))
+    if E.shape[0] != nel:
+        raise RuntimeError("The number of elements in the mesh : %d and the number of elements of the simulator : %d must be equal."
+                           % (E.shape[0], nel))
+    lo, hi = V.min(axis=0), V.max(axis=0)
+    rel = (V[E].mean(axis=1) - lo) / np.where(hi > lo, hi - lo, 1.0)
+    cell = np.minimum(np.floor(rel[:, :N] * np.asarray(ne)).astype(np.int64), np.asarray(ne) - 1)
+    rho = np.zeros(nel)
+    rho[np.ravel_multi_index(tuple(cell.T), tuple(int(n) for n in ne))] = values
+    return rho
+
+
 # ----------------------------------------------------------------------------------------------
 # TensorProductSimulator<1,1,1>
 # ----------------------------------------------------------------------------------------------
@@ -190,10 +285,38 @@ class TensorProductSimulator1_1_1:
     # ---- material / SIMP ----
     def readMaterial(self, materialPath):
         young, poisson = _read_isotropic_material(materialPath)
+        self._young, self._poisson = young, poisson
         _lib.check(self._lib.vfem_sim_set_isotropic(self._h, young, poisson))
+        self._direct_mg = None                    # the reference resets its solver when the operator changes (TPS.hh:404)
 
     def _push_simp(self):
         _lib.check(self._lib.vfem_sim_set_simp(self._h, self._E0, self._Emin, self._gamma))
+
+    def _lame(self):
+        E, nu = getattr(self, "_young", 1.0), getattr(self, "_poisson", 0.0)         # ETensor(1, 0) default, TPS.hh:1379
+        return nu * E / ((1.0 + nu) * (1.0 - 2.0 * nu)), E / (2.0 + 2.0 * nu)
+
+    def readDensities(self, materialPath, fieldName="density"):
+        """TPS::readDensities (VoxelFEM.cc:54)"""
+        self.setElementDensities(_densities_from_msh(materialPath, fieldName, self._ne, 3))
+
+    def constantStrainLoad(self, eps):
+        """TPS::constantStrainLoad (VoxelFEM.cc:66), evaluated on the device"""
+        lam, mu = self._lame()
+        rho = self.getDensities_device()[:self.numElements()].reshape(tuple(int(n) for n in self._ne))
+        return _to_np(_constant_strain_load(eps, lam, mu, (self._bbmax - self._bbmin) / self._ne, 1, rho))
+
+    def getK(self):
+        """TPS::getK (VoxelFEM.cc:62): assembled stiffness matrix, upper triangle, compressed columns (host, small grids)"""
+        if self.numElements() > (1 << 21):
+            raise RuntimeError("getK assembles on the host; use applyK for grids of this size")
+        rho = self.getDensities()[:self.numElements()]
+        young = self._Emin + rho ** self._gamma * (self._E0 - self._Emin)
+        nodes = np.stack([self.elementNodes(0) - 0], 0).astype(np.int64)
+        eidx = np.stack(np.meshgrid(*[np.arange(n) for n in self._ne], indexing="ij"), -1).reshape(-1, 3)
+        nstr = np.array([self._nn[1] * self._nn[2], self._nn[2], 1])
+        nodes = (eidx @ nstr)[:, None] + nodes
+        return _assemble_upper(nodes, self.fullDensityElementStiffnessMatrix(), young, 3, self.numNodes())
 
     E_0 = property(lambda s: s._E0, lambda s, v: (setattr(s, "_E0", float(v)), s._push_simp())[0])
     E_min = property(lambda s: s._Emin, lambda s, v: (setattr(s, "_Emin", float(v)), s._push_simp())[0])
@@ -255,6 +378,7 @@ class TensorProductSimulator1_1_1:
         vals = np.ascontiguousarray(self._dvals)
         _lib.check(self._lib.vfem_sim_set_dirichlet(self._h, m.ctypes.data_as(ctypes.c_void_p),
                                                    vals.ctypes.data_as(ctypes.c_void_p)))
+        self._direct_mg = None                    # coarse Dirichlet masks of a cached hierarchy would be stale (TPS.hh:404)
 
     def _push_loads(self):
         _lib.check(self._lib.vfem_sim_set_loads(self._h, _ptr(self._loads), _stream()))
@@ -383,6 +507,10 @@ class TensorProductSimulator1_1_1:
         u = mg.preconditionedConjugateGradient_device(torch.zeros((self.numNodes(), 3), dtype=torch.float64,
                                                                   device=_dev()),
                                                       _to_dev(f, (self.numNodes(), 3)), 500, 1e-11, None, 1, 2, True)
+        if not mg.last_relative_residual <= 1e-11:
+            raise RuntimeError("TensorProductSimulator.solve: the iterative solve that stands in for the direct factorisation "
+                               "did not converge (relative residual %.3e after %d iterations)"
+                               % (mg.last_relative_residual, mg.last_iterations))
         return _to_np(u)
 
     def solveWithImposedLoads(self):
@@ -1046,7 +1174,34 @@ class _GenericSimulator:
     # ---- material / SIMP ----
     def readMaterial(self, materialPath):
         young, poisson = _read_isotropic_material(materialPath)
+        self._young, self._poisson = young, poisson
         _lib.check(self._lib.vfem_gsim_set_isotropic(self._h, young, poisson))
+        self._direct_mg = None                    # the reference resets its solver when the operator changes (TPS.hh:404)
+
+    def _lame(self):
+        """ElasticityTensor::setIsotropic (ElasticityTensor.hh:100-133): 3-D Lame parameters, plane stress in 2-D"""
+        E, nu = getattr(self, "_young", 1.0), getattr(self, "_poisson", 0.0)
+        lam = nu * E / ((1.0 + nu) * (1.0 - 2.0 * nu)) if self.N == 3 else nu * E / (1.0 - nu * nu)
+        return lam, E / (2.0 + 2.0 * nu)
+
+    def readDensities(self, materialPath, fieldName="density"):
+        """TPS::readDensities (VoxelFEM.cc:54)"""
+        self.setElementDensities(_densities_from_msh(materialPath, fieldName, self._ne, self.N))
+
+    def constantStrainLoad(self, eps):
+        """TPS::constantStrainLoad (VoxelFEM.cc:66), evaluated on the device"""
+        lam, mu = self._lame()
+        rho = self.getDensities_device().reshape(tuple(int(n) for n in self._ne))
+        return _to_np(_constant_strain_load(eps, lam, mu, (self._bbmax - self._bbmin) / self._ne, self.P, rho))
+
+    def getK(self):
+        """TPS::getK (VoxelFEM.cc:62): assembled stiffness matrix, upper triangle, compressed columns (host, small grids)"""
+        if self.numElements() * (self.P + 1) ** (2 * self.N) > (1 << 30):
+            raise RuntimeError("getK assembles on the host; use applyK for grids of this size")
+        rho = self.getDensities()
+        young = self._Emin + rho ** self._gamma * (self._E0 - self._Emin)
+        nodes = np.stack([np.asarray(self.elementNodes(e), dtype=np.int64) for e in range(self.numElements())])
+        return _assemble_upper(nodes, self.fullDensityElementStiffnessMatrix(), young, self.N, self.numNodes())
 
     def _push_simp(self):
         _lib.check(self._lib.vfem_gsim_set_simp(self._h, self._E0, self._Emin, self._gamma))
@@ -1102,6 +1257,7 @@ class _GenericSimulator:
         vals = np.ascontiguousarray(self._dvals)
         _lib.check(self._lib.vfem_gsim_set_dirichlet(self._h, m.ctypes.data_as(ctypes.c_void_p),
                                                     vals.ctypes.data_as(ctypes.c_void_p)))
+        self._direct_mg = None                    # coarse Dirichlet masks of a cached hierarchy would be stale (TPS.hh:404)
 
     def applyDisplacementsAndLoadsFromFile(self, bcPath):
         """applyDisplacementsAndLoads (TPS.hh:358-409), see ``TensorProductSimulator1_1_1``."""

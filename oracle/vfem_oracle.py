@@ -7,8 +7,9 @@ product package ``ndr_amd`` never does.
 
 Parity status: PINNED.  ``tests/test_oracle_kats.py`` checks this module against the
 compliance values the reference itself logged (``tests/golden/reference_logs.json``,
-taken from ``logs/slurm/gt/*.log``), the textbook K0 entries and the reference's
-quadrature test tables (``tests/golden/tp_quadrature_*.json``).  The reference C++ cannot
+taken from ``logs/slurm/gt/*.log``), the textbook K0 entries and the rule of the reference's
+quadrature test (``VoxelFEM/tests/test_tp_gauss_quadrature.cc`` with ``tp_quadrature_{1,2,3}var_test.inl``:
+every monomial a degree-D-per-axis rule must integrate exactly has the integral prod 1/(d_i+1)).  The reference C++ cannot
 be compiled here (Eigen/TBB/CHOLMOD/Boost are not vendored), so there is no
 ``oracle/_ref`` build.
 
@@ -379,6 +380,38 @@ class OracleSim:
         nodes = first[:, None] + loc[None, :]                       # [ne, npe]
         dofs = (self.N * nodes[:, :, None] + np.arange(self.N)[None, None, :]).reshape(self.num_elems, -1)
         return nodes, dofs
+
+    def constant_strain_load(self, eps):
+        """TPS::constantStrainLoad (TPS.hh:792-821): per element l(i, j) = rho_e * vol * int strain(node j, comp i) : (C : eps)
+        by the element's own quadrature (Element::constantStressLoad, TPS.hh:145-160; the RAW density scales it, :172),
+        accumulated to the element's nodes in element order."""
+        N = self.N
+        lam, mu = self.lam_mu
+        eps = np.asarray(eps, dtype=np.float64).reshape(N, N)
+        sig = lam * np.trace(eps) * np.eye(N) + 2.0 * mu * 0.5 * (eps + eps.T)        # E_tensor.doubleContract(cstrain)
+        loc = list(np.ndindex(*([2] * N)))
+        l = np.zeros((N, len(loc)))
+        for j, nj in enumerate(loc):
+            for i in range(N):
+                def f(*p):
+                    g = np.zeros(N)
+                    for d in range(N):
+                        v = 1.0
+                        for e in range(N):
+                            v *= dlagrange(1, nj[e], p[e]) if e == d else lagrange(1, nj[e], p[e])
+                        g[d] = v / self.h[d]
+                    st = np.zeros((N, N))
+                    st[i, :] += 0.5 * g
+                    st[:, i] += 0.5 * g
+                    return np.sum(st * sig)
+                l[i, j] = integrate_tensor(f, [1] * N)
+        l *= np.prod(self.h)
+        nodes, _ = self.element_dofs()
+        F = np.zeros((self.num_nodes, N))
+        for ei in range(self.num_elems):
+            for j in range(len(loc)):
+                F[nodes[ei, j]] += self.rho[ei] * l[:, j]
+        return F
 
     def assemble(self):
         import scipy.sparse as sp

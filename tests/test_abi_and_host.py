@@ -117,3 +117,42 @@ def test_pipelined_scalar_loads_are_hazard_free(tmp_path):
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert " 0 violations" in out.stdout and "84 request..wait windows" in out.stdout, out.stdout
+
+
+def test_host_helpers_of_getk_constant_strain_load_read_densities(tmp_path):
+    """host logic behind TensorProductSimulator.getK / constantStrainLoad / readDensities (VoxelFEM.cc:54,62,66) against the
+    oracle, 2-D and 3-D (no GPU: the helpers take plain arrays)"""
+    import scipy.sparse as sp
+    import torch
+    from ndr_amd import io, pyVoxelFEM as pv
+    from oracle import vfem_oracle as vo
+    for ne, dom in (((5, 3), ([0, 0], [2.0, 1.0])), ((4, 3, 2), ([0, 0, 0], [1.5, 1.0, 0.8]))):
+        N = len(ne)
+        o = vo.OracleSim(dom, ne, vo.lame(1.0, 0.3, N))
+        o.Emin = 1e-4
+        rho = np.random.default_rng(3).uniform(0.05, 1.0, o.num_elems)
+        o.set_densities(rho)
+        nodes, _ = o.element_dofs()
+        K = pv._assemble_upper(nodes, o.K0, o.young(), N, o.num_nodes)
+        A = o.assemble()
+        assert abs(K.full() - A).max() < 1e-13 and sp.tril(K.toSciPy(), -1).nnz == 0
+        assert K.nz == K.Ap[-1] == len(K.Ai) == len(K.Ax) and K.symmetry_mode == "UPPER_TRIANGLE"
+        eps = np.random.default_rng(4).standard_normal((N, N))
+        eps = eps + eps.T
+        lam, mu = o.lam_mu
+        F = pv._constant_strain_load(eps, lam, mu, o.h, 1, torch.from_numpy(rho.reshape(ne))).numpy()
+        ref = o.constant_strain_load(eps)
+        assert np.abs(F - ref).max() < 1e-13 * np.abs(ref).max()
+    # element field of a hexahedral .msh, elements in reverse order
+    ne = (4, 3, 2)
+    idx = np.stack(np.meshgrid(*[np.arange(n + 1) for n in ne], indexing="ij"), -1).reshape(-1, 3)
+    V = idx * np.array([0.4, 0.3, 0.2]) + np.array([1.0, -2.0, 0.5])
+    nstr = np.array([(ne[1] + 1) * (ne[2] + 1), ne[2] + 1, 1])
+    eidx = np.stack(np.meshgrid(*[np.arange(n) for n in ne], indexing="ij"), -1).reshape(-1, 3)
+    Fh = np.stack([eidx @ nstr + np.array([(m >> 2) & 1, (m >> 1) & 1, m & 1]) @ nstr for m in (0, 1, 3, 2, 4, 5, 7, 6)], 1)
+    rho = np.random.default_rng(5).uniform(size=len(Fh))
+    path = str(tmp_path / "field.msh")
+    io.MSHFieldWriter(path, V, Fh[::-1]).addField("density", rho[::-1])
+    assert np.array_equal(pv._densities_from_msh(path, "density", ne, 3), rho)
+    with pytest.raises(RuntimeError):
+        pv._densities_from_msh(str(tmp_path / "field.obj"), "density", ne, 3)

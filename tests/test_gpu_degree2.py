@@ -69,12 +69,9 @@ def test_q2_apply_kernels_agree_across_chunk_seams(ne):
     t.setElementDensities(torch.rand(t.numElements(), dtype=torch.float64, device="cuda", generator=g))
     u = torch.randn((t.numNodes(), 3), dtype=torch.float64, device="cuda", generator=g)
     res = {}
-    try:
-        for impl in (1, 0, 2):
-            lib.vfem_debug_set(6, impl)
-            res[impl] = t.applyK_device(u).clone()
-    finally:
-        lib.vfem_debug_set(6, 0)
+    for impl in (1, 0, 2):
+        _lib.check(lib.vfem_gsim_set_option(t._h, 6, impl))        # VFEM_OPT_Q2_IMPL, a property of this simulator only
+        res[impl] = t.applyK_device(u).clone()
     scale = float(res[1].abs().max())
     assert float((res[0] - res[1]).abs().max()) < 1e-12 * scale
     assert float((res[2] - res[1]).abs().max()) < 1e-12 * scale

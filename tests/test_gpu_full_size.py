@@ -1,6 +1,13 @@
-"""-m gpu, full-size known answers: the reference's own logged compliance trajectory of the 3-D cantilever
-(256x128x128, v0 = 0.5, 3 coarsening levels, OC; logs/slurm/gt/c1001.log:137-140) replayed through the drop-in
-driver API on the HIP path."""
+"""-m gpu, full-size known answers: the reference's own logged compliance trajectories (logs/slurm/gt/) replayed through
+the drop-in driver API on the HIP path -- 3-D cantilever 256x128x128 (c1001.log:137-140) and 3-D bridge 320x160x80
+(b1000.log:141-144), each: uniform start, 3 coarsening levels, tol 1e-4, OC updates with smoothing + projection filters.
+
+Tolerance.  north_star asks 1e-5 relative on compliance for the same grid and BCs.  The logged numbers are themselves
+compliances of PCG iterates stopped at ||r|| <= 1e-4 ||b|| (fem.py:66), not of converged solutions: two reference runs of
+the same problem agree to 1.4e-8 only because they execute the same arithmetic.  Iteration 0 (uniform density) is held
+to 1e-5.  Later iterations inherit the design from the previous solve through the OC update (the sensitivities of a
+1e-4-converged iterate), so a different-but-equally-converged iterate shifts them at the 1e-5 level; they are held to
+2e-5 and the achieved deltas are recorded (gpurun_out/parity_deltas.json -> profiles/)."""
 import json
 import os
 import sys
@@ -14,16 +21,29 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def test_cantilever_256x128x128_matches_reference_log():
-    from helpers import BC_CANTILEVER, GOLDEN, MATERIAL
+def _replay(key, bc, dom, grid, v0):
+    from helpers import GOLDEN, MATERIAL, record_deltas
     from ndr_amd import fem
-    logs = json.load(open(os.path.join(GOLDEN, "reference_logs.json")))["3d_cantilever_256x128x128"]
-    tps, final, binary, hist = fem.ground_truth_topopt(MATERIAL, BC_CANTILEVER, [1, 1, 1], [[0, 0, 0], [2, 1, 1]],
-                                                       [256, 128, 128], 3, 0.5, 'OC', 3, use_multigrid=True,
-                                                       max_iter=3, obj_history=True, verbose=False)
-    want = logs["compliance"]
-    for got, ref in zip(hist, want):
-        assert abs(got - ref) < 2e-5 * ref, (hist, want)
+    want = json.load(open(os.path.join(GOLDEN, "reference_logs.json")))[key]["compliance"]
+    n = len(want)
+    tps, final, binary, hist = fem.ground_truth_topopt(MATERIAL, bc, [1, 1, 1], dom, list(grid), 3, v0, 'OC', 3,
+                                                       use_multigrid=True, max_iter=n, obj_history=True, verbose=False)
+    rel = [abs(g - r) / r for g, r in zip(hist, want)]
+    record_deltas("log_replay_" + key, {"logged": want, "hip": hist, "relative_delta": rel})
+    assert rel[0] < 1e-5, (hist, want, rel)
+    assert max(rel) < 2e-5, (hist, want, rel)
+
+
+def test_cantilever_256x128x128_matches_reference_log():
+    from helpers import BC_CANTILEVER
+    _replay("3d_cantilever_256x128x128", BC_CANTILEVER, [[0, 0, 0], [2, 1, 1]], (256, 128, 128), 0.5)
+
+
+def test_bridge_320x160x80_matches_reference_log():
+    """face load split over 26 001 nodes + x-roller + clamp, non-cubic voxels, v0 = 0.4 (projection filter active from
+    iteration 0: proj(0.4) = 0.392)"""
+    from helpers import BC_BRIDGE
+    _replay("3d_bridge_320x160x80", BC_BRIDGE, [[0, 0, 0], [4, 2, 1]], (320, 160, 80), 0.4)
 
 
 def test_voxelfem_function_autograd():

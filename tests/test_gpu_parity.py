@@ -56,14 +56,11 @@ def test_apply_k_tile_shapes_agree(ne):
     u = np.random.default_rng(4).standard_normal((o.num_nodes, 3))
     ud = torch.as_tensor(u, device="cuda")
     res = {}
-    try:
-        for mode in (1, 2, 0):
-            lib.vfem_debug_set(9, mode)
-            out = torch.empty_like(ud)
-            _lib.check(lib.vfem_sim_apply_k(t._h, _ptr(ud), _ptr(out), 0, _stream()))
-            res[mode] = out
-    finally:
-        lib.vfem_debug_set(9, 1)
+    for mode in (1, 2, 0):
+        _lib.check(lib.vfem_sim_set_option(t._h, 9, mode))         # VFEM_OPT_DMA_STRIP, a property of this simulator only
+        out = torch.empty_like(ud)
+        _lib.check(lib.vfem_sim_apply_k(t._h, _ptr(ud), _ptr(out), 0, _stream()))
+        res[mode] = out
     assert torch.equal(res[1], res[0]) and torch.equal(res[2], res[0])
     assert relerr(res[1].cpu().numpy(), o.apply_k(u)) < 1e-12
 
@@ -230,3 +227,49 @@ def test_apply_plane_range_equals_full_apply():
         assert bool(torch.isnan(ov[:lo]).all()) and bool(torch.isnan(ov[hi + 1:]).all()), (lo, hi)
     with pytest.raises(RuntimeError):
         _lib.check(t._lib.vfem_sim_apply_k_planes(t._h, _ptr(u), _ptr(out), 0, ne[0] + 1, _stream()))
+
+
+def test_get_k_constant_strain_load_read_densities(tmp_path):
+    """the three TensorProductSimulator methods of VoxelFEM.cc:54,62,66 against the oracle: assembled matrix (upper
+    triangle, compressed columns), unit-strain load, densities from a Gmsh element field"""
+    import scipy.sparse as sp
+    from ndr_amd import io
+    ne, dom = (6, 4, 5), ([0, 0, 0], [1.5, 1.0, 0.8])
+    rho = seeded_density(ne, 5)
+    t, o = make_hip(ne, dom, BC_CANTILEVER, rho), make_oracle(ne, dom, BC_CANTILEVER, rho)
+    K = t.getK()
+    A = o.assemble()
+    assert K.symmetry_mode == "UPPER_TRIANGLE" and K.m == K.n == 3 * o.num_nodes and K.nz == len(K.Ax) == K.Ap[-1]
+    assert abs(sp.triu(K.toSciPy(), 1) - sp.triu(A, 1)).max() < 1e-13 and sp.tril(K.toSciPy(), -1).nnz == 0
+    assert abs(K.full() - A).max() < 1e-13 and abs(K.trace() - A.diagonal().sum()) < 1e-12
+    u = np.random.default_rng(1).standard_normal(3 * o.num_nodes)
+    assert relerr(K.apply(u), t.applyK(u.reshape(-1, 3)).reshape(-1)) < 1e-12        # the matrix-free apply is this matrix
+    eps = np.array([[0.3, 0.1, -0.2], [0.1, -0.5, 0.4], [-0.2, 0.4, 1.0]])
+    assert relerr(t.constantStrainLoad(eps), o.constant_strain_load(eps)) < 1e-13
+    # densities through a .msh element field, elements written in reverse order: the cell comes from the element centroid
+    V, F = t.getMesh()
+    path = str(tmp_path / "rho.msh")
+    w = io.MSHFieldWriter(path, V, F[::-1])
+    w.addField("density", rho[::-1])
+    del w
+    t2 = make_hip(ne, dom, None, None)
+    t2.readDensities(path)
+    assert np.array_equal(t2.getDensities(), rho)
+    with pytest.raises(RuntimeError):
+        t2.readDensities(str(tmp_path / "rho.vtk"))
+
+
+def test_direct_solve_cache_follows_boundary_condition_changes():
+    """TPS::solve after a change of the Dirichlet mask must not reuse the hierarchy (coarse masks) built for the old one"""
+    ne, dom = (16, 8, 8), ([0, 0, 0], [2, 1, 1])
+    rho = seeded_density(ne, 9)
+    t, o = make_hip(ne, dom, BC_CANTILEVER, rho), make_oracle(ne, dom, BC_CANTILEVER, rho)
+    f = o.build_load_vector()
+    assert relerr(t.solve(f), o.solve(f)) < 1e-8
+    mask = t.dirichletMask
+    last = np.arange(o.num_nodes).reshape(17, 9, 9)[-1].reshape(-1)
+    mask[last, 0] = True                                   # add an x-roller on the far face
+    t.dirichletMask = mask
+    o.dmask[last, 0] = 1
+    o._lu = None
+    assert relerr(t.solve(f), o.solve(f)) < 1e-8

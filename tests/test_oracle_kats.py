@@ -25,12 +25,15 @@ def test_gauss_rules_exact_on_monomials():
         assert abs(w.sum() - 1.0) < 1e-15
         for deg in range(0, 2 * npts):
             assert abs(np.sum(w * x ** deg) - 1.0 / (deg + 1)) < 5e-16, (npts, deg)
-    # tensor rule, every monomial x^a y^b z^c up to degree 3 per variable with the 2-point rule per axis
-    for a in range(4):
-        for b in range(4):
-            for c in range(4):
-                v = vo.integrate_tensor(lambda x, y, z: x ** a * y ** b * z ** c, [3, 3, 3])
-                assert abs(v - 1.0 / ((a + 1) * (b + 1) * (c + 1))) < 5e-16
+    # tensor rules as VoxelFEM/tests/test_tp_gauss_quadrature.cc tests them (tp_quadrature_3var_test.inl: monomials
+    # x^a y^b z^c, exact integral 1/((a+1)(b+1)(c+1)), tolerance 5e-16): every monomial a degree-D-per-axis rule must
+    # integrate exactly, for the rules of the degree-1 (D = 3: 2 points) and degree-2 (D = 5: 3 points) elements and D = 1
+    for D in (1, 3, 5):
+        for a in range(D + 1):
+            for b in range(D + 1):
+                for c in range(D + 1):
+                    v = vo.integrate_tensor(lambda x, y, z: x ** a * y ** b * z ** c, [D, D, D])
+                    assert abs(v - 1.0 / ((a + 1) * (b + 1) * (c + 1))) < 5e-16, (D, a, b, c)
 
 
 def test_k0_textbook_entries_and_null_space():
@@ -123,12 +126,27 @@ def test_sensitivity_finite_difference():
         assert abs(fd - g[e]) < 1e-5 * abs(g[e]) + 1e-10
 
 
-@pytest.mark.slow
-@pytest.mark.skipif(os.environ.get("NDR_SLOW", "0") != "1", reason="about 10 minutes of CPU; run with NDR_SLOW=1")
 def test_3d_cantilever_log_kat_full_size():
+    """c1001.log:137, iteration 0 of the 256x128x128 cantilever (about a minute on 8 cores)"""
     k = LOGS["3d_cantilever_256x128x128"]
     ne, dom = (256, 128, 128), ([0, 0, 0], [2, 1, 1])
     o = make_oracle(ne, dom, BC_CANTILEVER, None, v0=0.5)
+    mg = vo.OracleMG(o, 3, nthreads=8)
+    f = o.build_load_vector()
+    u = mg.pcg(np.zeros_like(f), f, 100, 1e-6, 1, 2, True)
+    assert abs(np.sum(f * u) - k["compliance"][0]) < 1e-5 * k["compliance"][0]
+
+
+def test_3d_bridge_log_kat_full_size():
+    """b1000.log:141 (= b01.log:46), iteration 0 of the 320x160x80 bridge on [0,4]x[0,2]x[0,1], v0 = 0.4: pins the face
+    load (force split evenly over the matched nodes, TPS.hh:383-388) and the x-roller mask at full size"""
+    k = LOGS["3d_bridge_320x160x80"]
+    ne, dom = (320, 160, 80), ([0, 0, 0], [4, 2, 1])
+    # the drivers pass the uniform design x = v0 through the smoothing (uniform in, uniform out) and projection filters
+    # (Filter.hh:55-79, beta = 1): the physical density of iteration 0 is proj(0.4) = 0.39216, not 0.4 (proj(0.5) = 0.5)
+    beta = 1.0
+    rho_phys = 0.5 * (np.tanh(0.5 * beta) + np.tanh(beta * (0.4 - 0.5))) / np.tanh(0.5 * beta)
+    o = make_oracle(ne, dom, BC_BRIDGE, None, v0=rho_phys)
     mg = vo.OracleMG(o, 3, nthreads=8)
     f = o.build_load_vector()
     u = mg.pcg(np.zeros_like(f), f, 100, 1e-6, 1, 2, True)

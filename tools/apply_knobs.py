@@ -3,6 +3,8 @@ import numpy as np, torch
 import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 from helpers import make_hip
 from ndr_amd import _lib
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _knobs import set_knob
 lib = _lib.load()
 n = 512
 t = make_hip((n, n, n), ([0, 0, 0], [1, 1, 1]), None, None, v0=0.5)
@@ -12,7 +14,7 @@ ref = t.applyK_device(u, 1)
 for rnd in range(2):
     for skel in (0, 1):
         for pd in (0,):
-            lib.vfem_debug_set(4, skel); lib.vfem_debug_set(3, 0)
+            set_knob(t, 4, skel); set_knob(None, 3, 0)
             if skel == 0 and rnd == 0:
                 o = t.applyK_device(u); print("store mode", pd, "rel err", float((o - ref).abs().max() / ref.abs().max()))
             t.applyK_device(u); torch.cuda.synchronize(); t0 = time.perf_counter()

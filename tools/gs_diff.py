@@ -4,6 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import BC_CANTILEVER, make_hip, seeded_density
 from ndr_amd import _lib
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _knobs import set_knob
 from ndr_amd.pyVoxelFEM import _ptr, _stream
 lib = _lib.load()
 ne = tuple(int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (24, 8, 16)
@@ -17,7 +19,7 @@ b = torch.randn((nn, 3), dtype=torch.float64, device="cuda", generator=g)
 for fwd in (1, 0):
     res = {}
     for variant in (0, 1, 2):
-        lib.vfem_debug_set(2, variant)
+        set_knob(tps, 2, variant)
         u = u0.clone()
         lib.vfem_mg_smooth_colors(mg._h, 0, _ptr(u), _ptr(b), fwd, 2, 2, _stream())
         torch.cuda.synchronize()
@@ -29,4 +31,4 @@ for fwd in (1, 0):
     if len(bad):
         print("x:", sorted(set(bad[:, 0]))[:40]); print("y:", sorted(set(bad[:, 1]))[:40]); print("z:", sorted(set(bad[:, 2]))[:40])
         print(bad[:12].tolist()); i=tuple(bad[0]); print('pair', res[0][i], 'rows', res[1][i], 'orig', u0.cpu().numpy().reshape(res[0].shape)[i])
-lib.vfem_debug_set(2, 0)
+set_knob(tps, 2, 0)

@@ -1,9 +1,11 @@
-"""MLP forward timing ablations (vfem_debug_set(8, n)): where the 0.12 s of the 512x256x256 forward go."""
+"""MLP forward timing ablations (ablation build, key 8): where the 0.12 s of the 512x256x256 forward go."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ndr_amd import _lib
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _knobs import set_knob
 from ndr_amd.mlp import MLP
 lib = _lib.load()
 rng = np.random.default_rng(88); es, nn_, nl, sigma = 1024, 512, 4, 4.0
@@ -14,10 +16,10 @@ m = MLP(3, 1, nn_, nl, es, sigma); m.load_arrays(B, Ws, bs)
 side = (512, 256, 256)
 names = {0: "production", 1: "no feature generation", 2: "no hidden layers", 3: "no layer-1 MFMAs"}
 for ab in (0, 1, 2, 3, 0):
-    lib.vfem_debug_set(8, ab)
+    set_knob(None, 8, ab)
     for _ in range(2): m.forward_grid(side)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(3): m.forward_grid(side)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
     print("ablation %d %-24s %.4f s" % (ab, names[ab], dt), flush=True)
-lib.vfem_debug_set(8, 0)
+set_knob(None, 8, 0)

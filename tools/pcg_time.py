@@ -4,6 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import BC_CANTILEVER, make_hip
 from ndr_amd import _lib
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _knobs import set_knob
 lib = _lib.load()
 for n, levels in ((256, 5), (512, 6)):
     ne = (n, n, n)
@@ -13,13 +15,13 @@ for n, levels in ((256, 5), (512, 6)):
     mg = tps.multigridSolver(levels)
     f = tps.buildLoadVector_device()
     for variant in [int(a) for a in sys.argv[1:]] or [0, 1]:
-        lib.vfem_debug_set(2, variant)
+        set_knob(tps, 2, variant)
         x0 = torch.zeros_like(f)
         mg.preconditionedConjugateGradient_device(x0, f, 1, 1e-4, None, 1, 2, True)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         u = mg.preconditionedConjugateGradient_device(x0, f, 100, 1e-4, None, 1, 2, True)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print("n=%d gs_variant=%d iterations %d  %.3f s  %.2f it/s  compliance %.10f" % (n, variant, mg.last_iterations, dt, mg.last_iterations / dt, float((f * u).sum())), flush=True)
-    lib.vfem_debug_set(2, 0)
+    set_knob(tps, 2, 0)
     del mg, tps, f, u, x0
     torch.cuda.empty_cache()

@@ -4,6 +4,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ndr_amd import _lib, pyVoxelFEM as pv
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _knobs import set_knob
 lib = _lib.load()
 
 def run(ne, impls, reps):
@@ -14,7 +16,7 @@ def run(ne, impls, reps):
     u = torch.randn((t.numNodes(), 3), dtype=torch.float64, device="cuda", generator=g)
     res = {}
     for impl in impls:
-        lib.vfem_debug_set(6, impl)
+        set_knob(t, 6, impl)
         for _ in range(3):
             out = t.applyK_device(u)
         torch.cuda.synchronize()
@@ -26,7 +28,7 @@ def run(ne, impls, reps):
         ab = 2 * t.numNodes() * 24 + t.numElements() * 8
         print("%s impl %d: %.3f ms  %.2f GVoxel/s  algorithmic %.0f GB/s (%.3f of 8 TB/s)" % (ne, impl, dt * 1e3, t.numElements() / dt / 1e9, ab / dt / 1e9, ab / dt / 8e12), flush=True)
         del out
-    lib.vfem_debug_set(6, 0)
+    set_knob(t, 6, 0)
     if len(impls) > 1:
         ref = res[impls[0]]
         for impl in impls[1:]:
@@ -38,10 +40,10 @@ if sys.argv[1] == "check":
 elif sys.argv[1] == "exp":
     n = int(sys.argv[2])
     for exp in (0, 1, 2, 3, 0):
-        lib.vfem_debug_set(1, exp)
+        set_knob(None, 1, exp)
         print("ablation", exp, {0: "production", 1: "no element product", 2: "no row stores", 3: "no row loads"}[exp])
         run((n, n, n), (0,), 5)
-    lib.vfem_debug_set(1, 0)
+    set_knob(None, 1, 0)
 else:
     n = int(sys.argv[1])
     run((n, n, n), (0,) if len(sys.argv) > 2 else (2, 0), 5)
