@@ -160,11 +160,16 @@ def pcg_rate(ne, levels, dom):
     from helpers import BC_CANTILEVER, make_hip
     tps = make_hip(ne, dom, BC_CANTILEVER, None, v0=0.5)
     g = torch.Generator(device="cuda").manual_seed(88)
-    tps.setElementDensities(torch.rand(tps.numElements(), dtype=torch.float64, device="cuda", generator=g))
+    rho = torch.rand(tps.numElements(), dtype=torch.float64, device="cuda", generator=g)
+    tps.setElementDensities(rho)
     mg = tps.multigridSolver(levels)
     f = tps.buildLoadVector_device()
     x0 = torch.zeros_like(f)
-    mg.preconditionedConjugateGradient_device(x0, f, 1, 1e-4, None, 1, 2, True)       # warm-up (operator build)
+    mg.preconditionedConjugateGradient_device(x0, f, 1, 1e-4, None, 1, 2, True)       # warm-up (allocations, first-touch)
+    # the timed solve includes the per-solve operator update (Galerkin matrices, stencils, dense coarsest inverse).
+    # The library skips that update when the moduli have not changed since the last one, so the densities are set again here,
+    # as a design iteration would
+    tps.setElementDensities(rho)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     u = mg.preconditionedConjugateGradient_device(x0, f, 100, 1e-4, None, 1, 2, True)
@@ -172,7 +177,8 @@ def pcg_rate(ne, levels, dom):
     dt = time.perf_counter() - t0
     return {"grid": "%dx%dx%d" % tuple(ne), "levels": levels, "iterations": mg.last_iterations,
             "seconds": dt, "iterations_per_s": mg.last_iterations / dt,
-            "relative_residual": mg.last_relative_residual, "compliance": float((f * u).sum())}
+            "relative_residual": mg.last_relative_residual, "compliance": float((f * u).sum()),
+            "includes_operator_update": True}
 
 
 def mlp_rate(side=(512, 256, 256), es=1024, nn_=512, nl=4, sigma=4.0, reps=3):

@@ -54,8 +54,8 @@ enum {
     VFEM_OPT_DMA_CHUNKS   = 7,   /* x-chunks of the marching apply (0 = default) */
     VFEM_OPT_DMA_STRIP    = 9,   /* z-remainder strip tiles: 0 off, 1 on, 2 on with the main chunk length */
     VFEM_OPT_GS_PAIR      = 10,  /* level-0 Gauss-Seidel: fused z-colour pairs (1) or one launch per colour (0) */
-    VFEM_OPT_GS_FUSED     = 11,  /* level-0 Gauss-Seidel: all eight colours in one pass over u (1) */
-    VFEM_OPT_L1_STENCIL   = 12   /* level 1: stored symmetric-half stencil (1) or matrix-free Galerkin form (0) */
+    VFEM_OPT_L1_DIAG      = 12,  /* level-1 Gauss-Seidel: diagonal blocks precomputed per operator update (1) or inside every sweep (0) */
+    VFEM_OPT_GS_RESIDENT  = 13   /* level-0 Gauss-Seidel: K0 held in SGPRs (1, when K0 has the 36-value structure) or coefficient table (0) */
 };
 
 /* ---- raw device memory helpers (for callers without their own HIP allocator) ---- */

@@ -139,9 +139,11 @@ void vfem_sim::update_k0() {
         if (!used[q] && std::fabs(Dfull[q]) > 1e-13 * maxabs) fast_ok = false;
     dK0.alloc(576);
     VFEM_HIP(hipMemcpy(dK0.p, K0, sizeof(K0), hipMemcpyHostToDevice));
-    double tab[72 * 12];
+    double tab[GS_TABLE_DOUBLES + 36];
     vfem::build_gs_table(K0, tab);
-    dGsTab.alloc(72 * 12);
+    gs_resident_ok = vfem::build_gs_coef(K0, tab + GS_TABLE_DOUBLES);
+    tune.gs_resident = gs_resident_ok ? 1 : 0;
+    dGsTab.alloc(GS_TABLE_DOUBLES + 36);
     VFEM_HIP(hipMemcpy(dGsTab.p, tab, sizeof(tab), hipMemcpyHostToDevice));
 }
 
@@ -202,7 +204,8 @@ static void mg_smooth(vfem_mg *mg, int l, double *u, const double *b, int forwar
     MgLevel &L = mg->lv[l];
     if (L.kind == OP_STENCIL) launch_gs_sweep_stencil(L.d, L.S.p, u, b, L.maskp, forward, L.xparity, first, count, s);
     else launch_gs_sweep_mf(L.d, L.kind, level_K(mg, l), l == 0 ? mg->fine->dGsTab.p : mg->mf1diag.p, level_E(mg, l), u, b, L.maskp,
-                            forward, L.xparity, first, count, s, mg->fine->tune, mg->mf1_sym);
+                            forward, L.xparity, first, count, s, mg->fine->tune, mg->mf1_sym,
+                            (l == 1 && mg->fine->tune.l1_diag) ? L.Mdiag.p : nullptr);
 }
 
 static void coarsest_solve(vfem_mg *mg, const double *b, double *x, hipStream_t s) {
@@ -211,8 +214,12 @@ static void coarsest_solve(vfem_mg *mg, const double *b, double *x, hipStream_t 
 }
 
 static void update_operators(vfem_mg *mg, hipStream_t s) {
-    ScopedTimer tm("updateElementStiffnessMatrices");
     vfem_sim *sim = mg->fine;
+    // the reference rebuilds the coarse operators at the start of every solve (MG.hh:690-691) because its densities may have
+    // changed; here the simulator counts the changes, so a solve on unchanged moduli (a second right-hand side, the objective's
+    // constructor solve followed by setVars with the same design) keeps Galerkin matrices, stencils and the dense inverse
+    if (mg->operators_valid && mg->operators_version == sim->operator_version) return;
+    ScopedTimer tm("updateElementStiffnessMatrices");
     const int L = mg->slab ? mg->L - 1 : mg->L;      // the last level of a slab hierarchy only serves the grid transfers
     // Galerkin element matrices for levels >= 2 (level 1 stays virtual: sum_f E_f cK0[f])
     // (element arrays cover lv.da = node grid + extra x-layers; array origins halve exactly from level to level)
@@ -222,12 +229,17 @@ static void update_operators(vfem_mg *mg, hipStream_t s) {
         if (l == 2) launch_coarsen_ke(lv.da, 3, mg->c2K0.p, sim->E.p, nullptr, lv.Ke.p, s);
         else        launch_coarsen_ke(lv.da, 2, nullptr, nullptr, mg->lv[l - 1].Ke.p, lv.Ke.p, s);
     }
+    if (mg->L >= 1 && mg->first_active <= 1 && mg->mf1_sym && sim->tune.l1_diag) {   // level 1: diagonal blocks of the virtual operator
+        MgLevel &l1 = mg->lv[1];
+        l1.Mdiag.alloc((size_t) l1.d.nn * 9);
+        launch_mf1_diag(l1.d, mg->mf1diag.p, level_E(mg, 1), l1.Mdiag.p, s);
+    }
     for (int l = std::max(2, mg->first_active); l <= L; ++l) {
         MgLevel &lv = mg->lv[l];
         lv.S.alloc((size_t) lv.d.nn * 27 * 9);
         launch_stencil_from_ke(lv.d, lv.Ke.p + lv.ex_lo * (long long) lv.d.ny * lv.d.nz * 576, lv.S.p, s);
     }
-    if (mg->slab) { mg->operators_valid = true; return; }       // the coarse levels live in the replicated hierarchy
+    if (mg->slab) { mg->operators_valid = true; mg->operators_version = sim->operator_version; return; }       // the coarse levels live in the replicated hierarchy
     // coarsest level: dense inverse
     MgLevel &cl = mg->lv[L];
     const long long n = 3 * cl.d.nn;
@@ -262,6 +274,7 @@ static void update_operators(vfem_mg *mg, hipStream_t s) {
     launch_dense_finish_inverse(n, cl.maskp, mg->Ainv.p, s);
     VFEM_HIP(hipStreamSynchronize(s));   // tmpS lifetime
     mg->operators_valid = true;
+    mg->operators_version = sim->operator_version;
 }
 
 // vcycle, MG.hh:516-553
@@ -391,11 +404,13 @@ int vfem_sim_set_isotropic(vfem_sim *sim, double young, double poisson) {
     sim->lambda = poisson * young / ((1.0 + poisson) * (1.0 - 2.0 * poisson));   // ElasticityTensor.hh:105-106
     sim->mu = young / (2.0 + 2.0 * poisson);
     sim->update_k0();
+    ++sim->operator_version;
     VFEM_CATCH
 }
 int vfem_sim_set_simp(vfem_sim *sim, double E0, double Emin, double gamma) {
     VFEM_TRY
     sim->E0 = E0; sim->Emin = Emin; sim->gamma = gamma;
+    ++sim->operator_version;
     launch_simp(sim->n_store(), sim->rho.p, E0, Emin, gamma, sim->E.p, nullptr);
     VFEM_HIP(hipDeviceSynchronize());
     VFEM_CATCH
@@ -410,8 +425,8 @@ int vfem_sim_set_option(vfem_sim *sim, int key, int value) {
         case VFEM_OPT_DMA_CHUNKS:    if (value < 0) throw Error("negative chunk count"); t.dma_chunks = value; break;
         case VFEM_OPT_DMA_STRIP:     if (value < 0 || value > 2) throw Error("strip mode must be 0..2"); t.dma_strip = value; break;
         case VFEM_OPT_GS_PAIR:       t.gs_pair = value != 0; break;
-        case VFEM_OPT_GS_FUSED:      t.gs_fused = value != 0; break;
-        case VFEM_OPT_L1_STENCIL:    t.l1_stencil = value != 0; break;
+        case VFEM_OPT_GS_RESIDENT:   t.gs_resident = (value != 0 && sim->gs_resident_ok) ? 1 : 0; break;
+        case VFEM_OPT_L1_DIAG:       t.l1_diag = value != 0; ++sim->operator_version; break;   // hierarchies (re)build the blocks
         default: throw Error("unknown simulator option " + std::to_string(key));
     }
     VFEM_CATCH
@@ -446,6 +461,7 @@ int vfem_sim_build_load_vector(const vfem_sim *sim, double *f, void *stream) {
 int vfem_sim_set_densities(vfem_sim *sim, const double *rho, void *stream) {
     VFEM_TRY
     VFEM_HIP(hipMemcpyAsync(sim->rho.p, rho, (size_t) sim->n_store() * sizeof(double), hipMemcpyDeviceToDevice, S(stream)));
+    ++sim->operator_version;
     launch_simp(sim->n_store(), sim->rho.p, sim->E0, sim->Emin, sim->gamma, sim->E.p, S(stream));
     VFEM_CATCH
 }
@@ -453,6 +469,7 @@ int vfem_sim_set_uniform_density(vfem_sim *sim, double rho, void *stream) {
     VFEM_TRY
     if (rho > 1.0 || rho < 0.0)
         throw Error("Density value (" + std::to_string(rho) + ") has to be in between 0 and 1");   // TPS.hh:457-458
+    ++sim->operator_version;
     launch_fill(sim->n_store(), rho, sim->rho.p, S(stream));
     launch_simp(sim->n_store(), sim->rho.p, sim->E0, sim->Emin, sim->gamma, sim->E.p, S(stream));
     VFEM_CATCH
@@ -704,21 +721,21 @@ static void check_level(const vfem_mg *mg, int level) {
 int vfem_mg_apply_k(vfem_mg *mg, int level, const double *u, double *out, void *stream) {
     VFEM_TRY
     check_level(mg, level);
-    if (level >= 2 && !mg->operators_valid) update_operators(mg, S(stream));
+    if (level >= 1) update_operators(mg, S(stream));          // no-op when the operators match the current moduli
     mg_apply(mg, level, u, nullptr, 0, out, S(stream));
     VFEM_CATCH
 }
 int vfem_mg_residual(vfem_mg *mg, int level, const double *u, const double *b, double *r, void *stream) {
     VFEM_TRY
     check_level(mg, level);
-    if (level >= 2 && !mg->operators_valid) update_operators(mg, S(stream));
+    if (level >= 1) update_operators(mg, S(stream));          // no-op when the operators match the current moduli
     mg_apply(mg, level, u, b, 1, r, S(stream));
     VFEM_CATCH
 }
 int vfem_mg_smooth(vfem_mg *mg, int level, double *u, const double *b, int forward, void *stream) {
     VFEM_TRY
     check_level(mg, level);
-    if (level >= 2 && !mg->operators_valid) update_operators(mg, S(stream));
+    if (level >= 1) update_operators(mg, S(stream));          // no-op when the operators match the current moduli
     mg_smooth(mg, level, u, b, forward, S(stream));
     VFEM_CATCH
 }
@@ -742,7 +759,7 @@ int vfem_mg_interpolate(vfem_mg *mg, int fine_level, const double *coarse, doubl
 }
 int vfem_mg_coarsest_solve(vfem_mg *mg, const double *b, double *x, void *stream) {
     VFEM_TRY
-    if (!mg->operators_valid) update_operators(mg, S(stream));
+    update_operators(mg, S(stream));
     coarsest_solve(mg, b, x, S(stream));
     VFEM_CATCH
 }
@@ -751,7 +768,7 @@ int vfem_mg_smooth_colors(vfem_mg *mg, int level, double *u, const double *b, in
     VFEM_TRY
     check_level(mg, level);
     if (first < 0 || count < 0 || first + count > 8) throw Error("colour range out of [0, 8)");
-    if (level >= 2 && !mg->operators_valid) update_operators(mg, S(stream));
+    if (level >= 1) update_operators(mg, S(stream));          // no-op when the operators match the current moduli
     mg_smooth(mg, level, u, b, forward, S(stream), first, count);
     VFEM_CATCH
 }
@@ -761,7 +778,7 @@ int vfem_mg_cycle_from_level(vfem_mg *mg, int level, double *x, const double *b,
     if (level < mg->first_active) throw Error("level below the first active level of this hierarchy");
     if (mg->slab) throw Error("slab hierarchies are cycled by the distributed driver");
     hipStream_t s = S(stream);
-    if (!mg->operators_valid) update_operators(mg, s);
+    update_operators(mg, s);
     MgLevel &L = mg->lv[(size_t) level];
     const size_t bytes = (size_t) L.d.nn * 3 * sizeof(double);
     VFEM_HIP(hipMemcpyAsync(L.b.p, b, bytes, hipMemcpyDeviceToDevice, s));
@@ -779,7 +796,8 @@ int vfem_mg_solve(vfem_mg *mg, double *x, const double *f, int num_steps, int ns
     VFEM_TRY
     ScopedTimer tm("MG Solver");
     hipStream_t s = S(stream);
-    if (!stiffness_updated || !mg->operators_valid) update_operators(mg, s);
+    (void) stiffness_updated;                       // the simulator tracks changes of the moduli itself
+    update_operators(mg, s);
     if (num_steps == 0) return 0;
     const size_t bytes = (size_t) mg->fine->d.nn * 3 * sizeof(double);
     VFEM_HIP(hipMemcpyAsync(mg->lv[0].x.p, x, bytes, hipMemcpyDeviceToDevice, s));

@@ -165,6 +165,42 @@ __global__ void __launch_bounds__(256) k_gs_color_mf(Dims d, const double *__res
 // K0[rows of n] . u_e; the element moduli enter once at the end (S = sum_e E_e T_e, M = sum_e E_e K0_nn).
 // The next row's loads are in flight while the current row is consumed.
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Resident coefficients.  For a box voxel with an isotropic tensor K0 has 36 distinct magnitudes (closed form in
+// capi.hip, vfem_sim::update_k0):
+//   same component a:   K0[(n,a),(m,a)] depends on a and on which of the three index bits of n and m agree   -> 3 x 8 values
+//   components a != b:  K0[(n,a),(m,b)] = sign * C,  C chosen by the axis pair, by the agreement of the third axis' bits and by
+//                       whether tau1 = s(n_lo) s(m_hi) equals tau2 = s(n_hi) s(m_lo)  (lo < hi the two axes, s(bit) = +-1);
+//                       sign = tau1 for a < b, tau2 for a > b                                                -> 3 x 2 x 2 values
+// so a sweep can keep the whole matrix in 72 SGPRs and select entry and sign at compile time: no coefficient loads inside
+// the node loop (the table version spends one 24-double scalar load per 18 multiply-adds).  build_gs_coef() fills the table
+// from K0 and checks that EVERY entry of K0 is reproduced bit for bit; otherwise the table kernels are used.
+// ------------------------------------------------------------------------------------------
+struct KSel { int idx; bool neg; };
+__host__ __device__ constexpr int kbit(int n, int d) { return (n >> (2 - d)) & 1; }
+__host__ __device__ constexpr KSel ksel(int n, int a, int m, int b) {
+    if (a == b) return KSel{a * 8 + (kbit(n, 0) == kbit(m, 0) ? 4 : 0) + (kbit(n, 1) == kbit(m, 1) ? 2 : 0) + (kbit(n, 2) == kbit(m, 2) ? 1 : 0), false};
+    const int lo = a < b ? a : b, hi = a < b ? b : a, t = 3 - a - b;
+    const bool t1 = kbit(n, lo) == kbit(m, hi);          // tau1 = s(n_lo) s(m_hi) = +1 iff the bits agree
+    const bool t2 = kbit(n, hi) == kbit(m, lo);
+    const int idx = 24 + (lo + hi - 1) * 4 + (kbit(n, t) == kbit(m, t) ? 2 : 0) + (t1 == t2 ? 1 : 0);
+    return KSel{idx, !(a < b ? t1 : t2)};
+}
+bool build_gs_coef(const double *K0, double *coef /* 36 */) {
+    bool have[36] = {false};
+    for (int q = 0; q < 36; ++q) coef[q] = 0.0;
+    for (int n = 0; n < 8; ++n)
+        for (int a = 0; a < 3; ++a)
+            for (int m = 0; m < 8; ++m)
+                for (int b = 0; b < 3; ++b) {
+                    const KSel k = ksel(n, a, m, b);
+                    const double v = k.neg ? -K0[(3 * n + a) * 24 + 3 * m + b] : K0[(3 * n + a) * 24 + 3 * m + b];
+                    if (!have[k.idx]) { coef[k.idx] = v; have[k.idx] = true; }
+                    else if (coef[k.idx] != v) return false;
+                }
+    return true;
+}
+
 constexpr int GS_ROWBUF = 448;   // 129 nodes x 3 doubles = 387, padded to 7 x 64 so that every staging store is unconditional
 
 // Host-side layout of the coefficient table consumed by k_gs_rows_mf0 (same loop nest as the kernel):
@@ -201,10 +237,20 @@ void build_gs_table(const double *K0, double *tab /* 72*12 */) {
 }
 
 // one z-segment (64 colour nodes from colour index l0) of the colour row (x, y): the work of one wave
-__device__ __forceinline__ void gs_row_segment_mf0(const Dims &d, const double *__restrict__ tab, const double *__restrict__ E,
+// RES: `tab` holds the 36 resident coefficients (build_gs_coef) instead of the 72 x 12 table (build_gs_table); the arithmetic
+// (order of the multiply-adds, operands) is the same in both forms, so the results agree bit for bit
+struct GsCoef { d8_t c[4]; d4_t t; };
+template <bool RES>
+__device__ __forceinline__ void gs_row_segment_mf0(const Dims &d, const double *__restrict__ tab, const GsCoef &ck, const double *__restrict__ E,
                                                    double *__restrict__ u, const double *__restrict__ b,
                                                    const uint8_t *__restrict__ mask, int x, int y, int l0, int cz, int forward,
                                                    double *buf) {
+    auto coef = [&](auto nn, auto aa, auto mm, auto bb) -> double {   // K0[(n,a),(m,b)] from the resident table, compile-time selection
+        constexpr KSel k = ksel(decltype(nn)::value, decltype(aa)::value, decltype(mm)::value, decltype(bb)::value);
+        constexpr int i = k.idx;
+        const double v = i < 32 ? ck.c[i < 32 ? i / 8 : 0][i < 32 ? i % 8 : 0] : ck.t[i >= 32 ? i - 32 : 0];
+        return k.neg ? -v : v;
+    };
     const int lane = threadIdx.x;
     const int z = 2 * (l0 + lane) + cz;
     const int zlo = 2 * l0 + cz - 1;                    // first node of the staged segment
@@ -245,7 +291,10 @@ __device__ __forceinline__ void gs_row_segment_mf0(const Dims &d, const double *
     for (int c = 0; c < 3; ++c) bv[c] = b[3 * n + c];
     const uint8_t mk = mask[n];
 
-    double pre[7];
+    // All nine rows are requested before the first one is consumed (63 loads per lane in flight, retired in order by counted
+    // vmcnt waits).  With one row requested ahead, as this loop was first written, a segment cost nine dependent memory round
+    // trips (~12 us per segment and wave against 1.5 us of arithmetic: the sweep was latency-bound at a third of the VALU rate).
+    double pre[9][7];
     auto issue = [&](int r9) {
         int gx = x + r9 / 3 - 1, gy = y + r9 % 3 - 1;
         gx = gx < 0 ? 0 : (gx > d.NX - 1 ? d.NX - 1 : gx);
@@ -256,18 +305,15 @@ __device__ __forceinline__ void gs_row_segment_mf0(const Dims &d, const double *
         const int hi = __builtin_amdgcn_readfirstlane((int) (ro >> 32));
         const double *rowp = u + (((long long) hi << 32) | (long long) lo);
 #pragma unroll
-        for (int s7 = 0; s7 < 7; ++s7) pre[s7] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(rowp) + qc[s7]);
+        for (int s7 = 0; s7 < 7; ++s7) pre[r9][s7] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(rowp) + qc[s7]);
     };
-    issue(0);
-    int hg = 0;
 #pragma unroll
-    for (int r9 = 0; r9 < 9; ++r9) {
-        const int dx = r9 / 3 - 1, dy = r9 % 3 - 1;
+    for (int r9 = 0; r9 < 9; ++r9) issue(r9);
+    // row r9 of the 3 x 3 rows (dx, dy) around the node: staged values -> LDS -> the lane's three neighbours in z
+    auto stage_row = [&](int r9, double u3[3][3]) {
 #pragma unroll
-        for (int s7 = 0; s7 < 7; ++s7) buf[lane + 64 * s7] = pre[s7];
-        if (r9 + 1 < 9) issue(r9 + 1);
+        for (int s7 = 0; s7 < 7; ++s7) buf[lane + 64 * s7] = pre[r9][s7];
         __builtin_amdgcn_wave_barrier();
-        double u3[3][3];
 #pragma unroll
         for (int n3 = 0; n3 < 3; ++n3)
 #pragma unroll
@@ -277,6 +323,39 @@ __device__ __forceinline__ void gs_row_segment_mf0(const Dims &d, const double *
 #pragma unroll
             for (int c = 0; c < 3; ++c) uself[c] = u3[1][c];
         }
+    };
+    if constexpr (RES) {
+        // elements touching row (dx,dy): (di,mx) with di-1+mx == dx, (dj,my) with dj-1+my == dy; same nest and order as below
+        static_for<9>([&](auto r9c) {
+            constexpr int r9 = decltype(r9c)::value, dx = r9 / 3 - 1, dy = r9 % 3 - 1;
+            double u3[3][3];
+            stage_row(r9, u3);
+            static_for<16>([&](auto ec) {
+                constexpr int e = decltype(ec)::value, di = (e >> 3) & 1, mx = (e >> 2) & 1, dj = (e >> 1) & 1, my = e & 1;
+                if constexpr (di - 1 + mx == dx && dj - 1 + my == dy) {
+                    static_for<2>([&](auto dkc) {
+                        constexpr int dk = decltype(dkc)::value, sl = di * 4 + dj * 2 + dk;
+                        constexpr int ln = (1 - di) * 4 + (1 - dj) * 2 + (1 - dk);
+                        static_for<2>([&](auto mzc) {
+                            constexpr int mz = decltype(mzc)::value, n3 = dk + mz, lm = mx * 4 + my * 2 + mz;
+                            static_for<9>([&](auto rc) {
+                                constexpr int r = decltype(rc)::value / 3, c = decltype(rc)::value % 3;
+                                const double kv = coef(std::integral_constant<int, ln>{}, std::integral_constant<int, r>{},
+                                                       std::integral_constant<int, lm>{}, std::integral_constant<int, c>{});
+                                T[sl][r] = fma(kv, u3[n3][c], T[sl][r]);
+                            });
+                        });
+                    });
+                }
+            });
+        });
+    } else {
+    int hg = 0;
+#pragma unroll
+    for (int r9 = 0; r9 < 9; ++r9) {
+        const int dx = r9 / 3 - 1, dy = r9 % 3 - 1;
+        double u3[3][3];
+        stage_row(r9, u3);
 
         // elements touching row (dx,dy): (di,mx) with di-1+mx == dx, (dj,my) with dj-1+my == dy
 #pragma unroll
@@ -315,10 +394,27 @@ __device__ __forceinline__ void gs_row_segment_mf0(const Dims &d, const double *
                     }
             }
     }
+    }
     if (!node_ok) return;
     double S[3] = {0.0, 0.0, 0.0}, M[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) M[q] = 0.0;
+    if constexpr (RES) {
+        static_for<8>([&](auto gc) {
+            constexpr int ln = decltype(gc)::value, sl = 7 - ln;      // local index of the node in its element; slot = complement
+            const double Ee = Ev8[sl];
+            static_for<3>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                S[r] = fma(Ee, T[sl][r], S[r]);
+                static_for<3>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    const double kv = coef(std::integral_constant<int, ln>{}, std::integral_constant<int, r>{},
+                                           std::integral_constant<int, ln>{}, std::integral_constant<int, c>{});
+                    M[3 * r + c] = fma(Ee, kv, M[3 * r + c]);
+                });
+            });
+        });
+    } else {
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
         d8_t k0;
@@ -342,6 +438,7 @@ __device__ __forceinline__ void gs_row_segment_mf0(const Dims &d, const double *
         }
         asm volatile("" : "+v"(M[0]), "+v"(M[4]), "+v"(M[8]), "+v"(S[0]));
     }
+    }
     double bms[3], ud[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) bms[c] = bv[c] - S[c];
@@ -350,6 +447,17 @@ __device__ __forceinline__ void gs_row_segment_mf0(const Dims &d, const double *
     for (int c = 0; c < 3; ++c) u[3 * n + c] = uself[c] + ud[c];      // the node's own value came through the staged row
 }
 
+// the 36 resident coefficients into SGPRs (one wave-uniform load per wave)
+template <bool RES>
+__device__ __forceinline__ void gs_load_coef(const double *__restrict__ tab, GsCoef &ck) {
+    if constexpr (RES) {
+        asm volatile("s_load_dwordx16 %0, %5, 0x0\n\ts_load_dwordx16 %1, %5, 0x40\n\ts_load_dwordx16 %2, %5, 0x80\n\t"
+                     "s_load_dwordx16 %3, %5, 0xc0\n\ts_load_dwordx8 %4, %5, 0x100\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(ck.c[0]), "=&s"(ck.c[1]), "=&s"(ck.c[2]), "=&s"(ck.c[3]), "=&s"(ck.t) : "s"(tab));
+    }
+}
+
+template <bool RES>
 __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__restrict__ tab, const double *__restrict__ E,
                                                      double *__restrict__ u, const double *__restrict__ b,
                                                      const uint8_t *__restrict__ mask, int cx, int cy, int cz, int forward) {
@@ -357,7 +465,9 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
     const int x = 2 * blockIdx.z + cx;
     const int y = 2 * (blockIdx.y * 4 + threadIdx.y) + cy;
     if (y >= d.NY || x >= d.NX) return;                 // wave-uniform; no block-level barrier below
-    gs_row_segment_mf0(d, tab, E, u, b, mask, x, y, blockIdx.x * 64, cz, forward, rowbuf[threadIdx.y]);
+    GsCoef ck;
+    gs_load_coef<RES>(tab, ck);
+    gs_row_segment_mf0<RES>(d, tab, ck, E, u, b, mask, x, y, blockIdx.x * 64, cz, forward, rowbuf[threadIdx.y]);
 }
 
 // Both z colours of the rows (cx, cy) in one launch: a wave owns its row over the whole z extent and relaxes, segment by segment,
@@ -366,31 +476,34 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
 // second time they come from L2): the sweep is bound by the HBM traffic of its passes over u and E.  No other wave of the launch
 // reads this row (rows of equal parity are two apart), and the order A(s+1) before B(s) (even colour first) resp. A(s), B(s)
 // (odd colour first) keeps every first-colour update ahead of the second-colour updates that read it and behind none.
+template <bool RES>
 __global__ void __launch_bounds__(256) k_gs_rows_mf0_pair(Dims d, const double *__restrict__ tab, const double *__restrict__ E,
                                                           double *__restrict__ u, const double *__restrict__ b,
-                                                          const uint8_t *__restrict__ mask, int cx, int cy, int c1, int forward) {
+                                                          const uint8_t *__restrict__ mask, int cx, int cy, int c1, int forward,
+                                                          int ystride) {
     __shared__ double rowbuf[4][GS_ROWBUF];
     const int x = 2 * blockIdx.z + cx;
-    const int y = 2 * (blockIdx.y * 4 + threadIdx.y) + cy;
+    const int y = ystride * (blockIdx.y * 4 + threadIdx.y) + cy;       // ystride 2: every row of parity cy
     if (y >= d.NY || x >= d.NX) return;                 // wave-uniform; no block-level barrier below
     double *buf = rowbuf[threadIdx.y];
+    GsCoef ck;
+    gs_load_coef<RES>(tab, ck);
     const int c2 = 1 - c1;
     const int nA = ((d.NZ - 1 - c1) / 2 + 1 + 63) / 64, nB = d.NZ - 1 - c2 < 0 ? 0 : ((d.NZ - 1 - c2) / 2 + 1 + 63) / 64;
     const int lag = c1 == 0 ? 1 : 0;                    // even colour first: the last node of B(s) needs the first node of A(s+1)
     const int steps = nA > nB + lag ? nA : nB + lag;
     for (int s = 0; s < steps; ++s) {
-        if (s < nA) gs_row_segment_mf0(d, tab, E, u, b, mask, x, y, 64 * s, c1, forward, buf);
+        if (s < nA) gs_row_segment_mf0<RES>(d, tab, ck, E, u, b, mask, x, y, 64 * s, c1, forward, buf);
         if (s - lag >= 0 && s - lag < nB) {
             // the first-colour values this wave has just stored are read back below (same wave, in order; the fence makes the
             // stores complete before the loads are issued)
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            gs_row_segment_mf0(d, tab, E, u, b, mask, x, y, 64 * (s - lag), c2, forward, buf);
+            gs_row_segment_mf0<RES>(d, tab, ck, E, u, b, mask, x, y, 64 * (s - lag), c2, forward, buf);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         }
     }
 }
-
 
 
 // ------------------------------------------------------------------------------------------
@@ -404,17 +517,77 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0_pair(Dims d, const double *
 // f the rows are the rows rho = li ^ f of cK0[0]; the column permutation m -> m ^ f and the signs are resolved at
 // compile time (register renaming, per-component partial sums).  Register footprint as the general kernel.
 // ------------------------------------------------------------------------------------------
+// diagonal block of one incident element of a level-1 node: sum_f E_f s_r s_c cK0[0][(rho,r),(rho,c)], rho = li ^ f, from the
+// 8 x 9 table of diagonal blocks (build_mf1_diag_table); li = local index of the node in the element
+__device__ __forceinline__ void mf1_diag_slot(const double *__restrict__ Dtab, int li, const double Ef[8], double M[9]) {
+    static_for<8>([&](auto fc) {
+        constexpr int f = decltype(fc)::value;
+        const int rho = li ^ f;
+        d8_t k0;
+        d4_t k1;
+        sload12(Dtab, rho * 96, k0, k1);
+        constexpr bool ng[3] = {(bool) ((f >> 2) & 1), (bool) ((f >> 1) & 1), (bool) (f & 1)};
+        static_for<9>([&](auto qc) {
+            constexpr int q = decltype(qc)::value, r = q / 3, c = q % 3;
+            const double kv = q < 8 ? k0[q < 8 ? q : 0] : k1[0];
+            M[q] = fma((ng[r] != ng[c]) ? -Ef[f] : Ef[f], kv, M[q]);
+        });
+        asm volatile("" : "+v"(M[0]), "+v"(M[4]), "+v"(M[8]), "+v"(M[1]), "+v"(M[2]), "+v"(M[5]));
+    });
+}
+
+// The diagonal blocks of the level-1 operator depend on the moduli only: computed once per operator update (same sums, same
+// order as inside the sweep: bitwise the same blocks) and read back by the sweeps -- 72 B per node visit instead of 576
+// multiply-adds and 64 scalar loads (11 % of the sweep's arithmetic).
+__global__ void __launch_bounds__(256) k_mf1_diag(Dims d, const double *__restrict__ Dtab, const double *__restrict__ E,
+                                                  double *__restrict__ Mdiag) {
+    const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z;
+    if (k >= d.NZ || j >= d.NY) return;
+    const long long nyf = 2LL * d.ny, nzf = 2LL * d.nz;
+    double M[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) M[q] = 0.0;
+#pragma unroll 1
+    for (int slot = 0; slot < 8; ++slot) {
+        const int li = 7 - slot;
+        const int ex = i - 1 + ((slot >> 2) & 1), ey = j - 1 + ((slot >> 1) & 1), ez = k - 1 + (slot & 1);
+        const bool ok = ex >= 0 && ex < d.nx && ey >= 0 && ey < d.ny && ez >= 0 && ez < d.nz;
+        const int exc = min(max(ex, 0), d.nx - 1), eyc = min(max(ey, 0), d.ny - 1), ezc = min(max(ez, 0), d.nz - 1);
+        double Ef[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const double v = E[((2LL * exc + ((f >> 2) & 1)) * nyf + (2LL * eyc + ((f >> 1) & 1))) * nzf + (2LL * ezc + (f & 1))];
+            Ef[f] = ok ? v : 0.0;
+        }
+        mf1_diag_slot(Dtab, li, Ef, M);
+    }
+    const long long n = nidx(d, i, j, k);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Mdiag[9 * n + q] = M[q];
+}
+
+void launch_mf1_diag(const Dims &d, const double *Dtab, const double *E, double *Mdiag, hipStream_t s) {
+    k_mf1_diag<<<dim3((d.NZ + 63) / 64, (d.NY + 3) / 4, d.NX), dim3(64, 4, 1), 0, s>>>(d, Dtab, E, Mdiag);
+    VFEM_HIP(hipGetLastError());
+}
+
 // relaxation of one level-1 node (i, j, k) with the mirror-symmetric child matrices: the work of one lane
 __device__ __forceinline__ void gs_node_mf1_sym(const Dims &d, const double *__restrict__ K0c, const double *__restrict__ Dtab,
-                                                const double *__restrict__ E, double *__restrict__ u,
+                                                const double *__restrict__ Mdiag, const double *__restrict__ E, double *__restrict__ u,
                                                 const double *__restrict__ b, const uint8_t *__restrict__ mask, int i, int j, int k,
                                                 int forward) {
     if (k >= d.NZ) return;
     const long long nyf = 2LL * d.ny, nzf = 2LL * d.nz;
     const long long sx = (long long) d.NY * d.NZ, sy = d.NZ;
     double S[3] = {0.0, 0.0, 0.0}, M[9];
+    if (Mdiag) {                                   // precomputed diagonal block, requested ahead of the slot loop
+        const long long nq = 9 * nidx(d, i, j, k);
 #pragma unroll
-    for (int q = 0; q < 9; ++q) M[q] = 0.0;
+        for (int q = 0; q < 9; ++q) M[q] = Mdiag[nq + q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) M[q] = 0.0;
+    }
     // the element slot is a run-time loop: fully unrolled the kernel is ~60 KB of straight-line code, about the size of
     // the instruction cache two CUs share; the child index f stays compile-time (it permutes registers and fixes the signs)
 #pragma unroll 1
@@ -462,21 +635,7 @@ __device__ __forceinline__ void gs_node_mf1_sym(const Dims &d, const double *__r
             S[r] = fma(Ef[f], t, S[r]);
             asm volatile("" : "+v"(S[r]));                            // retire before the next row load
         });
-        // diagonal block: sum_f E_f s_r s_c cK0[0][(rho,r),(rho,c)] from the 8 x 9 table of diagonal blocks
-        static_for<8>([&](auto fc) {
-            constexpr int f = decltype(fc)::value;
-            const int rho = li ^ f;
-            d8_t k0;
-            d4_t k1;
-            sload12(Dtab, rho * 96, k0, k1);
-            constexpr bool ng[3] = {(bool) ((f >> 2) & 1), (bool) ((f >> 1) & 1), (bool) (f & 1)};
-            static_for<9>([&](auto qc) {
-                constexpr int q = decltype(qc)::value, r = q / 3, c = q % 3;
-                const double kv = q < 8 ? k0[q < 8 ? q : 0] : k1[0];
-                M[q] = fma((ng[r] != ng[c]) ? -Ef[f] : Ef[f], kv, M[q]);
-            });
-            asm volatile("" : "+v"(M[0]), "+v"(M[4]), "+v"(M[8]), "+v"(M[1]), "+v"(M[2]), "+v"(M[5]));
-        });
+        if (!Mdiag) mf1_diag_slot(Dtab, li, Ef, M);
     }
     const long long n = nidx(d, i, j, k);
     double bms[3], ud[3];
@@ -488,14 +647,14 @@ __device__ __forceinline__ void gs_node_mf1_sym(const Dims &d, const double *__r
 }
 
 __global__ void __launch_bounds__(256, 4) k_gs_color_mf1_sym(Dims d, const double *__restrict__ K0c, const double *__restrict__ Dtab,
-                                                             const double *__restrict__ E, double *__restrict__ u,
+                                                             const double *__restrict__ Mdiag, const double *__restrict__ E, double *__restrict__ u,
                                                              const double *__restrict__ b, const uint8_t *__restrict__ mask, int cx,
                                                              int cy, int cz, int forward) {
     const int k = 2 * (blockIdx.x * 64 + threadIdx.x) + cz;
     const int j = 2 * (blockIdx.y * 4 + threadIdx.y) + cy;
     const int i = 2 * blockIdx.z + cx;
     if (j >= d.NY || i >= d.NX) return;
-    gs_node_mf1_sym(d, K0c, Dtab, E, u, b, mask, i, j, k, forward);
+    gs_node_mf1_sym(d, K0c, Dtab, Mdiag, E, u, b, mask, i, j, k, forward);
 }
 
 // diagonal blocks of cK0[0] for k_gs_color_mf1_sym: 8 groups of 12 doubles (9 used)
@@ -526,9 +685,10 @@ bool coarsened_matrices_are_mirror_images(const double *cK0 /* 8 x 576, host */)
 // mf1_sym: coarsened_matrices_are_mirror_images() holds for the hierarchy (level-1 sweeps read cK0[0] only)
 void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *gs_tab, const double *E, double *u,
                         const double *b, const uint8_t *mask, int forward, int xparity, int first, int count, hipStream_t s,
-                        const Tuning &tune, bool mf1_sym) {
+                        const Tuning &tune, bool mf1_sym, const double *mdiag) {
     const int g_gs_variant = tune.gs_variant, g_gs_pair = tune.gs_pair;
     const bool g_mf1_sym = mf1_sym;
+    const bool res = tune.gs_resident != 0;       // level 0: the 36 resident coefficients follow the 72 x 12 table in gs_tab
     for (int ci = first; ci < first + count; ++ci) {
         const int lni = forward ? ci : 7 - ci;
         const int cx = ((lni >> 2) & 1) ^ (xparity & 1), cy = (lni >> 1) & 1, cz = lni & 1;   // global -> local x parity
@@ -537,13 +697,15 @@ void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const doubl
         dim3 blk(64, 4, 1), grd((cntz + 63) / 64, (cnty + 3) / 4, cntx);
         if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab && g_gs_pair && ((ci - first) % 2 == 0) && ci % 2 == 0 && ci + 1 < first + count && d.NZ >= 3) {
             // colours 2m and 2m+1 of the sweep order differ in cz only: one launch, the wave walks its row through both
-            k_gs_rows_mf0_pair<<<dim3(1, (cnty + 3) / 4, cntx), blk, 0, s>>>(d, gs_tab, E, u, b, mask, cx, cy, cz, forward);
+            if (res) k_gs_rows_mf0_pair<true><<<dim3(1, (cnty + 3) / 4, cntx), blk, 0, s>>>(d, gs_tab + GS_TABLE_DOUBLES, E, u, b, mask, cx, cy, cz, forward, 2);
+            else     k_gs_rows_mf0_pair<false><<<dim3(1, (cnty + 3) / 4, cntx), blk, 0, s>>>(d, gs_tab, E, u, b, mask, cx, cy, cz, forward, 2);
             ++ci;
             continue;
         }
-        if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab) k_gs_rows_mf0<<<grd, blk, 0, s>>>(d, gs_tab, E, u, b, mask, cx, cy, cz, forward);
+        if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab && res) k_gs_rows_mf0<true><<<grd, blk, 0, s>>>(d, gs_tab + GS_TABLE_DOUBLES, E, u, b, mask, cx, cy, cz, forward);
+        else if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab) k_gs_rows_mf0<false><<<grd, blk, 0, s>>>(d, gs_tab, E, u, b, mask, cx, cy, cz, forward);
         else if (kind == OP_MF0) k_gs_color_mf<0><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
-        else if (g_mf1_sym && g_gs_variant == 0 && gs_tab) k_gs_color_mf1_sym<<<grd, blk, 0, s>>>(d, K, gs_tab, E, u, b, mask, cx, cy, cz, forward);
+        else if (g_mf1_sym && g_gs_variant == 0 && gs_tab) k_gs_color_mf1_sym<<<grd, blk, 0, s>>>(d, K, gs_tab, mdiag, E, u, b, mask, cx, cy, cz, forward);
         else                k_gs_color_mf<1><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
     }
     VFEM_HIP(hipGetLastError());
@@ -991,18 +1153,26 @@ void launch_dense_finish_inverse(long long n, const uint8_t *mask, double *A, hi
     VFEM_HIP(hipGetLastError());
 }
 
-// y = A x, one wave per row
+// y = A x, one wave per row; four independent 16-byte loads of the row in flight per lane (the rows come from L2: with one
+// 8-byte load per round trip a 2187-column row took 34 dependent trips and the launch 370 us)
 __global__ void __launch_bounds__(256) k_gemv(long long n, const double *__restrict__ A, const double *__restrict__ x,
                                               double *__restrict__ y) {
     const long long row = (long long) blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= n) return;
     const double *a = A + row * n;
-    double acc = 0.0;
-    for (long long c = lane; c < n; c += 64) acc = fma(a[c], x[c], acc);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    long long c = lane;
+    for (; c + 192 < n; c += 256) {
+        const double a0 = a[c], a1 = a[c + 64], a2 = a[c + 128], a3 = a[c + 192];
+        const double x0 = x[c], x1 = x[c + 64], x2 = x[c + 128], x3 = x[c + 192];
+        acc[0] = fma(a0, x0, acc[0]); acc[1] = fma(a1, x1, acc[1]); acc[2] = fma(a2, x2, acc[2]); acc[3] = fma(a3, x3, acc[3]);
+    }
+    for (; c < n; c += 64) acc[0] = fma(a[c], x[c], acc[0]);
+    double r = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if (lane == 0) y[row] = acc;
+    for (int o = 32; o > 0; o >>= 1) r += __shfl_down(r, o);
+    if (lane == 0) y[row] = r;
 }
 
 void launch_gemv_sym(long long n, const double *A, const double *x, double *y, hipStream_t s) {

@@ -82,8 +82,9 @@ struct Tuning {
     int dma_strip = 1;      // 0: main tile shape only, 1: strip tiles for the left-over node columns, 2: strip with main-length chunks
     int gs_variant = 0;     // 0: row-streaming / symmetric sweeps, 1: plain gather sweeps
     int gs_pair = 1;        // level 0: both z colours of a row in one launch
-    int gs_fused = 1;       // level 0: all eight colours in one pass over u (k_gs_sweep_mf0)
-    int l1_stencil = 1;     // level 1: stored symmetric-half stencil instead of the matrix-free Galerkin form (when memory allows)
+    int gs_resident = 0;    // level 0: K0 kept in 72 SGPRs (36 distinct values; set when build_gs_coef reproduces K0 bit for bit)
+    int l1_diag = 0;        // level 1: diagonal blocks precomputed once per operator update instead of inside every sweep (measured
+                            // 3 % SLOWER at 512^3, profiles/r02_gs_experiments.json: the sweep is not bound by its arithmetic)
 };
 #ifdef VFEM_ABLATION
 extern int g_ablate_apply, g_ablate_store, g_ablate_mlp;   // vfem_debug_set (ablation build only): wrong results, timing only
@@ -107,8 +108,12 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
 // [first, first+count) selects a sub-range of the 8 colours (half sweeps between halo exchanges)
 void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *gs_tab, const double *E, double *u,
                         const double *b, const uint8_t *mask, int forward, int xparity, int first, int count, hipStream_t s,
-                        const Tuning &tune, bool mf1_sym);
+                        const Tuning &tune, bool mf1_sym, const double *mf1_diag = nullptr);
+// level 1: diagonal 3x3 blocks of the virtual Galerkin operator, [nn][9] (once per operator update)
+void launch_mf1_diag(const Dims &d, const double *Dtab, const double *E, double *Mdiag, hipStream_t s);
 void build_gs_table(const double *K0, double *tab /* 72*12 doubles */);
+constexpr int GS_TABLE_DOUBLES = 72 * 12;
+bool build_gs_coef(const double *K0, double *coef /* 36 doubles; false: K0 lacks the box-voxel / isotropic structure */);
 bool coarsened_matrices_are_mirror_images(const double *cK0_host /* 8 x 576 */);
 void build_mf1_diag_table(const double *cK0_0, double *tab /* 8*12 */);
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
@@ -181,6 +186,7 @@ struct vfem_sim {
     double K0[576];                             // host copy, row-major
     double Dm[64];                              // symmetry-reduced (mode-space) coefficients, host
     bool   fast_ok = false;                     // mode-space sparsity pattern verified for this K0
+    bool   gs_resident_ok = false;              // the 36-value structure of K0 verified (build_gs_coef)
     vfem::DevBuf<double> dK0, dGsTab, rho, E, dvals, loads;
     vfem::DevBuf<uint8_t> dmask;
     std::vector<uint8_t> hmask;                 // host copy of the Dirichlet mask
@@ -188,6 +194,7 @@ struct vfem_sim {
     bool nonzero_dirichlet = false;
     // slab decomposition: element arrays (rho, E) may hold extra x-layers in front of / behind the node grid
     long long ex_lo = 0, ex_hi = 0;
+    long long operator_version = 1;             // bumped whenever K(rho) changes (densities, SIMP law, material): hierarchies rebuild
     vfem::Tuning tune;
     vfem::DevBuf<double> red;                   // scratch of the reductions (vfem_compliance)
     long long n_store() const { return (long long) (d.nx + ex_lo + ex_hi) * d.ny * d.nz; }
@@ -208,6 +215,7 @@ struct MgLevel {
     const uint8_t *maskp = nullptr;
     std::vector<uint8_t> hmask;
     vfem::DevBuf<double> Ke, S;                 // Galerkin element matrices / stencil (levels >= 2)
+    vfem::DevBuf<double> Mdiag;                 // level 1: precomputed diagonal blocks [nn][9] of the virtual operator
     vfem::DevBuf<double> x, b, r;               // work vectors (m_x, m_b of MG.hh:755-756 + residual)
 };
 
@@ -225,6 +233,7 @@ struct vfem_mg {
     int first_active = 0;                       // levels below are never cycled (replicated coarse hierarchy)
     bool symmetric_gs = true;                   // MG.hh:758
     bool operators_valid = false;
+    long long operators_version = 0;            // fine->operator_version the coarse operators were built for
     bool mf1_sym = false;                       // cK0[f] are mirror images of cK0[0]: level-1 sweeps read cK0[0] only
     void *rocblas = nullptr;                    // rocblas_handle for the coarsest factorisation
     vfem::DevBuf<int> info;

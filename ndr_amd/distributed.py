@@ -239,9 +239,10 @@ def bench_pcg(ne, levels, tol=1e-4):
     g = torch.Generator(device="cuda").manual_seed(88)
     rho = torch.rand(ne[0] * ne[1] * ne[2], dtype=torch.float64, device="cuda", generator=g)   # same on every rank
     ds.set_global_densities(rho)
-    del rho
     f = ds.local_loads()
-    ds.pcg(torch.zeros_like(f), f, 1, tol, 1, 2, True)              # warm-up (operator build, NCCL channels)
+    ds.pcg(torch.zeros_like(f), f, 1, tol, 1, 2, True)              # warm-up (allocations, NCCL channels)
+    ds.set_global_densities(rho)                                    # the timed solve rebuilds the coarse operators, as a design iteration does
+    del rho
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()

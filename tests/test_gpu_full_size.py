@@ -2,12 +2,11 @@
 the drop-in driver API on the HIP path -- 3-D cantilever 256x128x128 (c1001.log:137-140) and 3-D bridge 320x160x80
 (b1000.log:141-144), each: uniform start, 3 coarsening levels, tol 1e-4, OC updates with smoothing + projection filters.
 
-Tolerance.  north_star asks 1e-5 relative on compliance for the same grid and BCs.  The logged numbers are themselves
-compliances of PCG iterates stopped at ||r|| <= 1e-4 ||b|| (fem.py:66), not of converged solutions: two reference runs of
-the same problem agree to 1.4e-8 only because they execute the same arithmetic.  Iteration 0 (uniform density) is held
-to 1e-5.  Later iterations inherit the design from the previous solve through the OC update (the sensitivities of a
-1e-4-converged iterate), so a different-but-equally-converged iterate shifts them at the 1e-5 level; they are held to
-2e-5 and the achieved deltas are recorded (gpurun_out/parity_deltas.json -> profiles/)."""
+Tolerance.  north_star asks 1e-5 relative on compliance for the same grid and BCs.  The logs print six decimals, i.e. they
+carry a rounding of up to 2e-8 relative on the smallest value; the HIP path reproduces all eight logged values to 1e-8
+(measured: cantilever <= 4e-10, bridge <= 9.2e-9, profiles/r02_parity_deltas.json), so the test holds them to 1e-7 -- a
+hundred times tighter than the bar.  (The iterates are stopped at ||r|| <= 1e-4 ||b||, fem.py:66, like the reference's; that
+the compliances still agree to the printed digits says the stopping points coincide: same iteration counts, same cycle.)"""
 import json
 import os
 import sys
@@ -30,8 +29,7 @@ def _replay(key, bc, dom, grid, v0):
                                                        use_multigrid=True, max_iter=n, obj_history=True, verbose=False)
     rel = [abs(g - r) / r for g, r in zip(hist, want)]
     record_deltas("log_replay_" + key, {"logged": want, "hip": hist, "relative_delta": rel})
-    assert rel[0] < 1e-5, (hist, want, rel)
-    assert max(rel) < 2e-5, (hist, want, rel)
+    assert max(rel) < 1e-7, (hist, want, rel)
 
 
 def test_cantilever_256x128x128_matches_reference_log():

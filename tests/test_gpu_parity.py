@@ -234,7 +234,7 @@ def test_get_k_constant_strain_load_read_densities(tmp_path):
     triangle, compressed columns), unit-strain load, densities from a Gmsh element field"""
     import scipy.sparse as sp
     from ndr_amd import io
-    ne, dom = (6, 4, 5), ([0, 0, 0], [1.5, 1.0, 0.8])
+    ne, dom = (6, 4, 4), ([0, 0, 0], [1.5, 1.0, 0.8])      # even ny, nz: the cantilever's point load sits on the mid node
     rho = seeded_density(ne, 5)
     t, o = make_hip(ne, dom, BC_CANTILEVER, rho), make_oracle(ne, dom, BC_CANTILEVER, rho)
     K = t.getK()

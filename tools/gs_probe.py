@@ -1,3 +1,5 @@
+"""Level-0 / level-1 Gauss-Seidel sweep: time per sweep and bitwise agreement of the implementation choices.
+   python tools/gs_probe.py [n=256] [level=0]"""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,30 +21,31 @@ nn = mg._nn(level)
 u = torch.randn((nn, 3), dtype=torch.float64, device="cuda", generator=g)
 b = torch.randn((nn, 3), dtype=torch.float64, device="cuda", generator=g)
 from ndr_amd.pyVoxelFEM import _ptr, _stream
-if level in (0, 1):
-    base = None
-    for pair in (1, 0, 1, 0):
-        set_knob(tps, 10, pair)
-        for fwd in (1, 0):
-            for rep in range(3):
-                uu = u.clone()
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-                lib.vfem_mg_smooth(mg._h, level, _ptr(uu), _ptr(b), fwd, _stream())
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
-            if base is None: base = {}
-            base.setdefault(fwd, uu)
-            print("level %d fused z-colour pairs %d forward %d: %.3f ms per sweep   max |diff| to first: %.3e" % (level, pair, fwd, dt * 1e3, float((uu - base[fwd]).abs().max())), flush=True)
-    set_knob(tps, 10, 1)
-res = {}
-for variant in (0, 2, 1):
-    set_knob(tps, 2, variant)
-    for rep in range(3):
+
+def sweep(fwd, reps=4):
+    best = 1e9
+    for rep in range(reps):
         uu = u.clone()
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        lib.vfem_mg_smooth(mg._h, level, _ptr(uu), _ptr(b), 1, _stream())
+        _lib.check(lib.vfem_mg_smooth(mg._h, level, _ptr(uu), _ptr(b), fwd, _stream()))
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    res[variant] = uu
-    print("level %d variant %d: %.3f ms per sweep   max |diff| to variant 0: %.3e" % (level, variant, dt * 1e3, float((uu - res[0]).abs().max())), flush=True)
-set_knob(tps, 2, 0)
+        best = min(best, time.perf_counter() - t0)
+    return uu, best
+
+# (name, [(key, value), ...]); the first entry is the reference the others are compared with bit for bit
+configs = [("production", []), ("plain gather sweeps", [(2, 1)])]
+if level == 0:
+    configs += [("coefficient table (no resident K0)", [(13, 0)]), ("one launch per colour", [(10, 0)])]
+if level == 1:
+    configs += [("precomputed diagonal blocks", [(12, 1)])]
+base = {}
+for name, knobs in configs + [configs[0]]:
+    for k, v in knobs:
+        set_knob(tps, k, v)
+    for fwd in (1, 0):
+        uu, dt = sweep(fwd)
+        base.setdefault(fwd, uu)
+        print("level %d %-36s forward %d: %.3f ms per sweep   max |diff| to production: %.3e" %
+              (level, name, fwd, dt * 1e3, float((uu - base[fwd]).abs().max())), flush=True)
+    for k, v in knobs:
+        set_knob(tps, k, {2: 0, 13: 1, 10: 1, 12: 0}[k])
