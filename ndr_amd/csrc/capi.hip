@@ -236,7 +236,7 @@ static void update_operators(vfem_mg *mg, hipStream_t s) {
     }
     for (int l = std::max(2, mg->first_active); l <= L; ++l) {
         MgLevel &lv = mg->lv[l];
-        lv.S.alloc((size_t) lv.d.nn * 27 * 9);
+        lv.S.alloc((size_t) stencil_storage_doubles(lv.d));
         launch_stencil_from_ke(lv.d, lv.Ke.p + lv.ex_lo * (long long) lv.d.ny * lv.d.nz * 576, lv.S.p, s);
     }
     if (mg->slab) { mg->operators_valid = true; mg->operators_version = sim->operator_version; return; }       // the coarse levels live in the replicated hierarchy
@@ -248,7 +248,7 @@ static void update_operators(vfem_mg *mg, hipStream_t s) {
     const double *Sc = cl.S.p;
     DevBuf<double> tmpS;
     if (L < 2) {
-        tmpS.alloc((size_t) cl.d.nn * 27 * 9);
+        tmpS.alloc((size_t) stencil_storage_doubles(cl.d));
         launch_stencil_from_mf(cl.d, L == 0 ? OP_MF0 : OP_MF1, level_K(mg, L), level_E(mg, L), tmpS.p, s);
         Sc = tmpS.p;
     }

@@ -130,6 +130,7 @@ void launch_enforce_dirichlet(long long nn, const uint8_t *mask, const double *v
 // mode 2 = children read from Kef.  `c` = dims of the level being built.
 void launch_coarsen_ke(const Dims &c, int mode, const double *cK0, const double *Efine, const double *Kef,
                        double *Kec, hipStream_t s);
+long long stencil_storage_doubles(const Dims &d);            // size of a level's stencil array (tiles padded per colour)
 void launch_stencil_from_ke(const Dims &d, const double *Ke, double *S, hipStream_t s);
 void launch_stencil_from_mf(const Dims &d, OpKind kind, const double *K, const double *E, double *S, hipStream_t s);
 void launch_dense_from_stencil(const Dims &d, const double *S, const uint8_t *mask, double *A, hipStream_t s);
