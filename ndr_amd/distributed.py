@@ -77,36 +77,15 @@ class HaloExchanger:
         self.group = group
 
     def start(self, field):
-        """begin the exchange; under nccl the transfers run on RCCL's stream while the caller launches work that
-        does not touch the ghost planes, `finish` makes the current stream wait for them.  Under gloo (CPU tests,
-        one-GPU rehearsal) the exchange completes here."""
+        """Begin the exchange of the two interface planes with each neighbour and return a handle for `finish`.  The transfers
+        are posted as one batch of non-blocking sends / receives and run while the caller launches work that does not touch
+        the ghost planes (DistributedStiffness.apply: the interior planes).  The same code serves both backends: under nccl
+        (RCCL over xGMI) the plane views of the device tensor are sent as they are; under gloo (CPU tests, one-GPU
+        rehearsal) a device plane is staged through host memory first and copied back in `finish`."""
         p = self.p
         if p.world == 1:
-            return []
-        if dist.get_backend(self.group) == "gloo":
-            self.exchange(field)
-            return []
+            return None
         v = field.view(p.n_planes, -1)
-        ops = []
-        if p.gl:
-            ops.append(dist.P2POp(dist.isend, v[p.first_owned + 1], p.rank - 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, v[0], p.rank - 1, self.group))
-        if p.gr:
-            ops.append(dist.P2POp(dist.isend, v[p.last_owned - 1], p.rank + 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, v[p.last_owned + 1], p.rank + 1, self.group))
-        return dist.batch_isend_irecv(ops)
-
-    def finish(self, works):
-        for w in works:
-            w.wait()
-
-    def exchange(self, field):
-        p = self.p
-        if p.world == 1:
-            return
-        v = field.view(p.n_planes, -1)
-        # gloo moves host memory: stage device planes through the CPU (test / single-GPU rehearsal path only;
-        # with the nccl backend the planes go GPU-to-GPU over xGMI)
         staged = field.is_cuda and dist.get_backend(self.group) == "gloo"
         ops, recvs = [], []
 
@@ -122,10 +101,20 @@ class HaloExchanger:
             add(p.first_owned + 1, 0, p.rank - 1)
         if p.gr:   # right neighbour: send my plane last_owned-1, receive my ghost plane last_owned+1
             add(p.last_owned - 1, p.last_owned + 1, p.rank + 1)
-        for w in dist.batch_isend_irecv(ops):
+        return dist.batch_isend_irecv(ops), recvs, v
+
+    def finish(self, handle):
+        """wait for the transfers of `start`; afterwards the ghost planes of the field hold the neighbours' values"""
+        if handle is None:
+            return
+        works, recvs, v = handle
+        for w in works:
             w.wait()
         for plane, rb in recvs:
             v[plane].copy_(rb)
+
+    def exchange(self, field):
+        self.finish(self.start(field))
 
     def dot(self, a, b):
         """global sum a.b with interface planes counted once"""

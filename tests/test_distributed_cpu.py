@@ -27,6 +27,24 @@ class OracleLocalOps:
         return torch.from_numpy(self.sim.apply_k(u.numpy()))
 
 
+class OracleLocalOpsWithPlanes(OracleLocalOps):
+    """adds the plane-range apply that lets DistributedStiffness overlap the halo exchange with the interior planes; it records
+    what the ghost planes of the input held at each call (the overlap contract: interior planes are computed BEFORE the
+    exchange has finished, the two boundary planes after)"""
+
+    def __init__(self, part, bbmin, bbmax):
+        super().__init__(part, bbmin, bbmax)
+        self.part, self.calls = part, []
+
+    def apply_planes(self, u, out, lo, hi):
+        p = self.part
+        uv = u.view(p.n_planes, -1)
+        ghosts_poisoned = bool((p.gl and float(uv[0].abs().max()) > 1e29) or (p.gr and float(uv[-1].abs().max()) > 1e29))
+        self.calls.append((int(lo), int(hi), ghosts_poisoned))
+        full = self.apply(u).view(p.n_planes, -1)
+        out.view(p.n_planes, -1)[lo:hi + 1] = full[lo:hi + 1]
+
+
 def _worker(rank, world, port, ne, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -49,6 +67,23 @@ def _worker(rank, world, port, ne, q):
     K = vd.DistributedStiffness(part, ops)
     out = K.apply(u)
     nrm = K.halo.dot(out, out)
+    # the overlapped sequence (start -> interior planes -> finish -> boundary planes) against the blocking one, same input
+    u2 = vd.seeded_slab_field(part)
+    u2v = u2.view(part.n_planes, -1)
+    if part.gl:
+        u2v[0] = 1e30
+    if part.gr:
+        u2v[-1] = -1e30
+    ops2 = OracleLocalOpsWithPlanes(part, *dom)
+    ops2.set_densities(vd.seeded_slab_density(part))
+    out2 = vd.DistributedStiffness(part, ops2).apply(u2)
+    own = slice(part.first_owned, part.last_owned + 1)
+    assert torch.equal(out2.view(part.n_planes, -1)[own], out.view(part.n_planes, -1)[own])
+    assert torch.equal(u2, u)                                       # both paths leave the same (repaired) ghost planes
+    if world > 1:
+        interior = [c for c in ops2.calls if c[0] == part.first_owned + (1 if part.gl else 0)]
+        assert interior and interior[0][2], ops2.calls              # interior planes were computed while the ghosts were stale
+        assert all(not c[2] for c in ops2.calls[1:]), ops2.calls    # the boundary planes only after finish()
     # global reference on every rank
     full = vd.SlabPartition(ne, 1, 0)
     g = make_oracle(ne, dom, None, vd.seeded_slab_density(full).numpy())

@@ -13,12 +13,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, ne, q):
+def _worker(rank, world, port, ne, q, backend="gloo"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # gloo: both ranks share device 0 (planes staged through the host); nccl (= RCCL): one device per rank, planes go GPU to GPU
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from ndr_amd import distributed as vd
     part = vd.SlabPartition(ne, world, rank, align=2)
     ops = vd.HipLocalOps(part, [0, 0, 0], [2, 1, 1])
@@ -41,6 +43,26 @@ def _worker(rank, world, port, ne, q):
     err = float((mine - want).abs().max() / want.abs().max())
     q.put((rank, err, nrm, float((ref * ref).sum())))
     dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL transport needs one device per rank (the test box has one)")
+def test_two_ranks_two_gpus_rccl_apply():
+    """the same slab apply over the nccl backend: HaloExchanger.start / finish with device plane views, overlapped with the
+    interior planes -- runs wherever at least two devices are visible (the driver's multi-GPU node)"""
+    ne, world = (24, 10, 70), 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ne, q, "nccl")) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, nrm, ref in res:
+        assert err < 1e-12, (rank, err)
+        assert abs(nrm - ref) < 1e-10 * ref
 
 
 def test_two_ranks_one_gpu_apply():
