@@ -349,15 +349,17 @@ def main():
 
     kernel_s = time_apply(tps, u, args.steps, 1)
     ab = algorithmic_bytes(ne)
-    traffic = None
+    # HBM bytes per launch by the PMC counters: collected in separate rocprofv3 --pmc passes (FETCH_SIZE x 2, WRITE_SIZE; the
+    # guide's gfx950 correction) and committed under profiles/ -- NOT measured inside this run; the source is named in the line
+    traffic, traffic_source = None, None
     prof = os.path.join(ROOT, "profiles", "apply_traffic.json")
     if os.path.exists(prof):
         with open(prof) as fh:
             t = json.load(fh)
         if t.get("grid") == list(ne):
-            traffic = t.get("hbm_bytes_per_launch")
+            traffic, traffic_source = t.get("hbm_bytes_per_launch"), "from profile " + str(t.get("source"))
     roofline = {"bound": "hbm", "achieved": ab / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ab / kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": ab / kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "vfem::k_apply_dma", "algorithmic_bytes_per_launch": ab, "kernel_ms": kernel_s * 1e3}
     del out
 

@@ -146,6 +146,12 @@ const double *vfem_mg_field_ptr(const vfem_mg *mg, int which, int level);
 /* updateElementStiffnessMatrices + updateBlockKs (MG.hh:415-441): rebuild the coarse operators
  * (Galerkin, MG.hh:604-669) and the coarsest-level factorisation from the current densities. */
 int vfem_mg_update_operators(vfem_mg *mg, void *stream);
+/* Slab decomposition without a global density field.  export: the Galerkin element matrices (MG.hh:604-669) of `level` (>= 2)
+ * for `count_x` element layers, built from this (local) hierarchy's moduli -- the children start at layer `child_first_layer`
+ * of the child level's element array (of the fine array for level 2): [count_x * ny * nz][576] doubles.  import: hand a
+ * partial (replicated) hierarchy the element matrices of its first active level; its operators are then rebuilt from them. */
+int vfem_mg_export_level_ke(vfem_mg *mg, int level, int64_t child_first_layer, int64_t count_x, double *ke_out, void *stream);
+int vfem_mg_import_level_ke(vfem_mg *mg, int level, const double *ke, void *stream);
 /* MG::applyK(l,u) (MG.hh:353-358), computeResidual (MG.hh:401-413), smoothingMulticoloredGS
  * (MG.hh:336-340; forward != 0 => forward colour/component order), zeroOutDirichletComponents
  * (MG.hh:364-378), restriction (MG.hh:146-161), interpolation / accum_interpolation (MG.hh:116-141),

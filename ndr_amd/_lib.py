@@ -61,6 +61,8 @@ SIGNATURES = {
     "vfem_mg_set_symmetric_gauss_seidel": (c_int, [c_void_p, c_int]),
     "vfem_mg_field_ptr": (c_void_p, [c_void_p, c_int, c_int]),
     "vfem_mg_update_operators": (c_int, [c_void_p, c_void_p]),
+    "vfem_mg_export_level_ke": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
+    "vfem_mg_import_level_ke": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "vfem_mg_apply_k": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "vfem_mg_residual": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vfem_mg_smooth": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),

@@ -223,7 +223,9 @@ static void update_operators(vfem_mg *mg, hipStream_t s) {
     const int L = mg->slab ? mg->L - 1 : mg->L;      // the last level of a slab hierarchy only serves the grid transfers
     // Galerkin element matrices for levels >= 2 (level 1 stays virtual: sum_f E_f cK0[f])
     // (element arrays cover lv.da = node grid + extra x-layers; array origins halve exactly from level to level)
-    for (int l = 2; l <= L; ++l) {
+    // (a replicated coarse hierarchy of a slab decomposition may be handed the element matrices of its first active level,
+    // vfem_mg_import_level_ke: it then never looks at its simulator's moduli)
+    for (int l = mg->external_ke_level > 0 ? mg->external_ke_level + 1 : 2; l <= L; ++l) {
         MgLevel &lv = mg->lv[l];
         lv.Ke.alloc((size_t) lv.da.ne * 576);
         if (l == 2) launch_coarsen_ke(lv.da, 3, mg->c2K0.p, sim->E.p, nullptr, lv.Ke.p, s);
@@ -712,10 +714,42 @@ const double *vfem_mg_field_ptr(const vfem_mg *mg, int which, int level) {
     return which == 0 ? mg->lv[(size_t) level].x.p : mg->lv[(size_t) level].b.p;
 }
 
-int vfem_mg_update_operators(vfem_mg *mg, void *stream) { VFEM_TRY update_operators(mg, S(stream)); VFEM_CATCH }
-
 static void check_level(const vfem_mg *mg, int level) {
     if (level < 0 || level > mg->L) throw Error("level out of range");
+}
+
+int vfem_mg_update_operators(vfem_mg *mg, void *stream) { VFEM_TRY update_operators(mg, S(stream)); VFEM_CATCH }
+
+int vfem_mg_export_level_ke(vfem_mg *mg, int level, int64_t child_first_layer, int64_t count_x, double *ke_out, void *stream) {
+    VFEM_TRY
+    check_level(mg, level);
+    if (level < 2) throw Error("element matrices exist from level 2 on (level 1 is virtual)");
+    if (count_x < 0 || child_first_layer < 0) throw Error("negative layer range");
+    update_operators(mg, S(stream));
+    const MgLevel &lv = mg->lv[(size_t) level];
+    const Dims c(count_x, lv.d.ny, lv.d.nz);
+    if (level == 2) {         // straight from the fine moduli (64 per element): layers child_first_layer .. of the simulator's array
+        const vfem_sim *sim = mg->fine;
+        if (child_first_layer + 4 * count_x > sim->d.nx + sim->ex_lo + sim->ex_hi) throw Error("layer range outside the fine element array");
+        launch_coarsen_ke(c, 3, mg->c2K0.p, sim->E.p + child_first_layer * (long long) sim->d.ny * sim->d.nz, nullptr, ke_out, S(stream));
+    } else {
+        const MgLevel &ch = mg->lv[(size_t) level - 1];
+        if (!ch.Ke.p) throw Error("the child level holds no element matrices");
+        if (child_first_layer + 2 * count_x > ch.da.nx) throw Error("layer range outside the child level's element array");
+        launch_coarsen_ke(c, 2, nullptr, nullptr, ch.Ke.p + child_first_layer * (long long) ch.da.ny * ch.da.nz * 576, ke_out, S(stream));
+    }
+    VFEM_CATCH
+}
+int vfem_mg_import_level_ke(vfem_mg *mg, int level, const double *ke, void *stream) {
+    VFEM_TRY
+    check_level(mg, level);
+    if (level < 2 || level != mg->first_active) throw Error("element matrices can be supplied for the first active level (>= 2) of a partial hierarchy");
+    MgLevel &lv = mg->lv[(size_t) level];
+    lv.Ke.alloc((size_t) lv.da.ne * 576);
+    VFEM_HIP(hipMemcpyAsync(lv.Ke.p, ke, (size_t) lv.da.ne * 576 * sizeof(double), hipMemcpyDeviceToDevice, S(stream)));
+    mg->external_ke_level = level;
+    mg->operators_valid = false;              // rebuilt from these matrices at the next update
+    VFEM_CATCH
 }
 
 int vfem_mg_apply_k(vfem_mg *mg, int level, const double *u, double *out, void *stream) {

@@ -232,6 +232,7 @@ struct vfem_mg {
     vfem::DevBuf<double> scal, scratch;
     bool slab = false;                          // local part of an x-slab decomposition: no coarsest solver here
     int first_active = 0;                       // levels below are never cycled (replicated coarse hierarchy)
+    int external_ke_level = 0;                  // > 0: the element matrices of this level were supplied (vfem_mg_import_level_ke)
     bool symmetric_gs = true;                   // MG.hh:758
     bool operators_valid = false;
     long long operators_version = 0;            // fine->operator_version the coarse operators were built for

@@ -227,11 +227,22 @@ def bench_pcg(ne, levels, tol=1e-4):
     ds = DistributedMGSolver(ne, [0.0, 0.0, 0.0], [2.0, 1.0, 1.0], bc, mat, levels)
     g = torch.Generator(device="cuda").manual_seed(88)
     rho = torch.rand(ne[0] * ne[1] * ne[2], dtype=torch.float64, device="cuda", generator=g)   # same on every rank
-    ds.set_global_densities(rho)
+    # (the same seeded field as the single-GPU bench, generated whole here only to cut this rank's owned layers out of it: the
+    # solver itself is handed the owned layers and never sees the rest)
+    own = rho.view(ne[0], -1)[ds.part.x0:ds.part.x1].reshape(-1).clone()
+    del rho
+    sharded = ds.T >= 2
+    set_rho = (lambda: ds.set_local_densities(own)) if sharded else None
+    if sharded:
+        set_rho()
+    else:
+        g = torch.Generator(device="cuda").manual_seed(88)
+        whole = torch.rand(ne[0] * ne[1] * ne[2], dtype=torch.float64, device="cuda", generator=g)
+        set_rho = lambda: ds.set_global_densities(whole)
+        set_rho()
     f = ds.local_loads()
     ds.pcg(torch.zeros_like(f), f, 1, tol, 1, 2, True)              # warm-up (allocations, NCCL channels)
-    ds.set_global_densities(rho)                                    # the timed solve rebuilds the coarse operators, as a design iteration does
-    del rho
+    set_rho()                                                       # the timed solve rebuilds the coarse operators, as a design iteration does
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
@@ -246,7 +257,8 @@ def bench_pcg(ne, levels, tol=1e-4):
     dt = float(dt.item())
     return {"grid": "%dx%dx%d" % tuple(ne), "levels": levels, "distributed_levels": ds.Ld + 1, "iterations": ds.last_iterations,
             "seconds": dt, "iterations_per_s": ds.last_iterations / dt, "relative_residual": ds.last_relative_residual,
-            "compliance": 2.0 * ds.compliance(f, u)}
+            "compliance": 2.0 * ds.compliance(f, u), "densities": "sharded (owned layers per rank)" if sharded else "replicated",
+            "includes_operator_update": True}
 
 
 def bench_mlp(side=(512, 256, 256), es=1024, nn_=512, nl=4, sigma=4.0, reps=3):
@@ -491,13 +503,73 @@ class DistributedMGSolver:
 
     def set_global_densities(self, rho_global):
         """rho_global: [nx*ny*nz] float64 device tensor, identical on every rank"""
+        self._sharded = False
         self.gsim.setElementDensities(rho_global)
         g = self.geom[0]
         a0, b0 = g.xoffn - g.extra_lo, g.xoffn + g.nx + g.extra_hi
         self.lsim.setElementDensities_padded(rho_global.view(self.ne[0], -1)[a0:b0].reshape(-1))
 
+    def set_local_densities(self, rho_owned):
+        """rho_owned: the densities of this rank's OWNED element layers [x0, x1), flat [(x1 - x0) * ny * nz] float64 on the
+        device.  No rank ever holds the whole field: the ghost / padding layers of the local arrays come from the two
+        neighbours (one message each way), and the first replicated level gets its Galerkin element matrices from an
+        all-gather of the ranks' own slabs of them (`update_operators`)."""
+        g, p = self.geom[0], self.part
+        layer = self.ne[1] * self.ne[2]
+        own = rho_owned.reshape(p.x1 - p.x0, layer)
+        lo_need, hi_need = g.gl + g.extra_lo, g.gr + g.extra_hi           # layers wanted from the left / right neighbour
+        if lo_need > own.shape[0] or hi_need > own.shape[0]:
+            raise RuntimeError("slab thinner than the padding of the local hierarchy")
+        local = torch.empty((lo_need + own.shape[0] + hi_need, layer), dtype=torch.float64, device=own.device)
+        local[lo_need:lo_need + own.shape[0]] = own
+        staged = own.is_cuda and self.world > 1 and dist.get_backend(self.group) == "gloo"
+        ops, recvs = [], []
+
+        def add(send, recv_slice, peer):
+            sb = send.contiguous().cpu() if staged else send.contiguous()
+            rb = torch.empty_like(sb) if staged else torch.empty_like(local[recv_slice])
+            ops.append(dist.P2POp(dist.isend, sb, peer, self.group))
+            ops.append(dist.P2POp(dist.irecv, rb, peer, self.group))
+            recvs.append((recv_slice, rb))
+
+        # every interior interface needs the same number of layers on both sides (the padding depends on Ld only)
+        if g.gl:
+            add(own[:lo_need], slice(0, lo_need), self.rank - 1)          # what the left neighbour needs from me = what I need from it
+        if g.gr:
+            add(own[own.shape[0] - hi_need:], slice(lo_need + own.shape[0], lo_need + own.shape[0] + hi_need), self.rank + 1)
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for sl, rb in recvs:
+            local[sl].copy_(rb)
+        self.lsim.setElementDensities_padded(local.reshape(-1))
+        self._sharded = True
+
+    def _assemble_first_replicated_level(self):
+        """element matrices of level T for the whole grid = the ranks' slabs of them, concatenated along x"""
+        gT, child = self.geom[self.T], self.geom[self.T - 1 if self.T >= 3 else 0]
+        nyz = (self.ne[1] >> self.T) * (self.ne[2] >> self.T)
+        count = gT.X1 - gT.X0
+        mine = torch.empty(count * nyz * 576, dtype=torch.float64, device=self.dev)
+        self._chk(self.lib.vfem_mg_export_level_ke(self.lmg, self.T, child.gl + child.extra_lo, count, self._p(mine), self._s()))
+        if self.world == 1:
+            whole = mine
+        else:
+            counts = [(self.part.starts[r + 1] - self.part.starts[r]) >> self.T for r in range(self.world)]
+            staged = dist.get_backend(self.group) == "gloo"
+            parts = [torch.empty(c * nyz * 576, dtype=torch.float64, device="cpu" if staged else self.dev) for c in counts]
+            dist.all_gather(parts, mine.cpu() if staged else mine, group=self.group)
+            whole = torch.cat(parts).to(self.dev)
+        self._chk(self.lib.vfem_mg_import_level_ke(self.gmg, self.T, self._p(whole), self._s()))
+        torch.cuda.current_stream().synchronize()
+
     def update_operators(self):
         self._chk(self.lib.vfem_mg_update_operators(self.lmg, self._s()))
+        if getattr(self, "_sharded", False):
+            if self.T < 2:
+                raise RuntimeError("sharded densities need at least two distributed levels (the first replicated level must hold "
+                                   "element matrices); use set_global_densities for this configuration")
+            self._assemble_first_replicated_level()
         self._chk(self.lib.vfem_mg_update_operators(self.gmg, self._s()))
 
     # ---- operators on distributed levels -----------------------------------------------------

@@ -82,7 +82,7 @@ def test_two_ranks_one_gpu_apply():
         assert abs(nrm - ref) < 1e-10 * ref
 
 
-def _pcg_worker(rank, world, port, ne, levels, q):
+def _pcg_worker(rank, world, port, ne, levels, q, sharded=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -94,7 +94,10 @@ def _pcg_worker(rank, world, port, ne, levels, q):
     dom = ([0.0, 0.0, 0.0], [2.0, 1.0, 1.0])
     rho = torch.from_numpy(seeded_density(ne, 88)).cuda()
     ds = vd.DistributedMGSolver(ne, dom[0], dom[1], BC_CANTILEVER, MATERIAL, levels)
-    ds.set_global_densities(rho)
+    if sharded:       # the rank hands over its OWNED layers only; ghosts come from the neighbours, coarse operators from an all-gather
+        ds.set_local_densities(rho.view(ne[0], -1)[ds.part.x0:ds.part.x1].reshape(-1).clone())
+    else:
+        ds.set_global_densities(rho)
     f = ds.local_loads()
     u = ds.pcg(torch.zeros_like(f), f, 100, 1e-8, 1, 2, True)
     comp = 2.0 * ds.compliance(f, u)
@@ -125,6 +128,27 @@ def test_distributed_pcg_matches_single_process(world, ne, levels):
     q = ctx.Queue()
     port = 29800 + (os.getpid() % 1000) + levels + 10 * world
     procs = [ctx.Process(target=_pcg_worker, args=(r, world, port, ne, levels, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, Ld, it_d, it_s, comp, cg, err in res:
+        assert Ld >= 1
+        assert it_d == it_s, (it_d, it_s)
+        assert abs(comp - cg) < 1e-9 * abs(cg), (comp, cg)
+        assert err < 1e-7, err
+
+
+@pytest.mark.parametrize("world,ne,levels", [(2, (32, 16, 16), 3), (4, (64, 16, 16), 4), (3, (48, 16, 16), 3)])
+def test_distributed_pcg_with_sharded_densities(world, ne, levels):
+    """no rank holds the whole density field (set_local_densities): same iterations, compliance and displacements as the
+    single-process solve"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 1000) + levels + 10 * world
+    procs = [ctx.Process(target=_pcg_worker, args=(r, world, port, ne, levels, q, True)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=400) for _ in range(world)]
