@@ -201,6 +201,13 @@ bool build_gs_coef(const double *K0, double *coef /* 36 */) {
     return true;
 }
 
+#ifndef VFEM_GS_PF
+#define VFEM_GS_PF 9
+#endif
+#ifndef VFEM_GS_MINW
+#define VFEM_GS_MINW 1
+#endif
+constexpr int GS_PF = VFEM_GS_PF;        // node rows requested ahead of the one being consumed (9 = all of a segment's rows up front)
 constexpr int GS_ROWBUF = 448;   // 129 nodes x 3 doubles = 387, padded to 7 x 64 so that every staging store is unconditional
 
 // Host-side layout of the coefficient table consumed by k_gs_rows_mf0 (same loop nest as the kernel):
@@ -277,15 +284,24 @@ __device__ __forceinline__ void gs_row_segment_mf0(const Dims &d, const double *
     const int zc = node_ok ? z : d.NZ - 1;
     const long long n = nidx(d, x, y, zc);
     double Ev8[8], bv[3], uself[3] = {0.0, 0.0, 0.0};
+    // The two moduli of an element column (ez = z - 1, z) are neighbours in memory: ONE 16-byte load per column, and with the lanes
+    // two elements apart the four loads of a wave are dense (as eight 8-byte loads every instruction used half of each line it
+    // touched; the moduli, right-hand side and mask loads were a quarter of the sweep's time, profiles/r02_gs_experiments.json).
+    // Loads are unconditional at clamped indices and masked afterwards.  (needs nz >= 2; the callers use the plain kernels below)
+    typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
+    const int ez0 = zc - 1;
+    const int ez0c = ez0 < 0 ? 0 : (ez0 > d.nz - 2 ? d.nz - 2 : ez0), esh = ez0c - ez0;     // +1 at the lower face, -1 at the upper one
 #pragma unroll
-    for (int sl = 0; sl < 8; ++sl) {
-        const int di = (sl >> 2) & 1, dj = (sl >> 1) & 1, dk = sl & 1;
-        const int ex = x - 1 + di, ey = y - 1 + dj, ez = zc - 1 + dk;
-        const bool ok = ex >= 0 && ex < d.nx && ey >= 0 && ey < d.ny && ez >= 0 && ez < d.nz;
+    for (int xy = 0; xy < 4; ++xy) {
+        const int di = xy >> 1, dj = xy & 1;
+        const int ex = x - 1 + di, ey = y - 1 + dj;
+        const bool okxy = ex >= 0 && ex < d.nx && ey >= 0 && ey < d.ny;
         const int exc = ex < 0 ? 0 : (ex > d.nx - 1 ? d.nx - 1 : ex), eyc = ey < 0 ? 0 : (ey > d.ny - 1 ? d.ny - 1 : ey);
-        const int ezc = ez < 0 ? 0 : (ez > d.nz - 1 ? d.nz - 1 : ez);
-        const double Ev = E[eidx(d, exc, eyc, ezc)];              // unconditional load, masked afterwards
-        Ev8[sl] = ok ? Ev : 0.0;
+        const d2u_t pr = *reinterpret_cast<const d2u_t *>(E + eidx(d, exc, eyc, ez0c));
+        const double lo = esh == 0 ? pr[0] : (esh < 0 ? pr[1] : 0.0);      // modulus of ez = z - 1 (none below the grid)
+        const double hi = esh == 0 ? pr[1] : (esh > 0 ? pr[0] : 0.0);      // modulus of ez = z     (none above the grid)
+        Ev8[di * 4 + dj * 2 + 0] = (okxy && ez0 >= 0) ? lo : 0.0;
+        Ev8[di * 4 + dj * 2 + 1] = (okxy && ez0 + 1 < d.nz) ? hi : 0.0;
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) bv[c] = b[3 * n + c];
@@ -294,7 +310,7 @@ __device__ __forceinline__ void gs_row_segment_mf0(const Dims &d, const double *
     // All nine rows are requested before the first one is consumed (63 loads per lane in flight, retired in order by counted
     // vmcnt waits).  With one row requested ahead, as this loop was first written, a segment cost nine dependent memory round
     // trips (~12 us per segment and wave against 1.5 us of arithmetic: the sweep was latency-bound at a third of the VALU rate).
-    double pre[9][7];
+    double pre[GS_PF][7];
     auto issue = [&](int r9) {
         int gx = x + r9 / 3 - 1, gy = y + r9 % 3 - 1;
         gx = gx < 0 ? 0 : (gx > d.NX - 1 ? d.NX - 1 : gx);
@@ -305,14 +321,15 @@ __device__ __forceinline__ void gs_row_segment_mf0(const Dims &d, const double *
         const int hi = __builtin_amdgcn_readfirstlane((int) (ro >> 32));
         const double *rowp = u + (((long long) hi << 32) | (long long) lo);
 #pragma unroll
-        for (int s7 = 0; s7 < 7; ++s7) pre[r9][s7] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(rowp) + qc[s7]);
+        for (int s7 = 0; s7 < 7; ++s7) pre[r9 % GS_PF][s7] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(rowp) + qc[s7]);
     };
 #pragma unroll
-    for (int r9 = 0; r9 < 9; ++r9) issue(r9);
+    for (int r9 = 0; r9 < GS_PF; ++r9) issue(r9);
     // row r9 of the 3 x 3 rows (dx, dy) around the node: staged values -> LDS -> the lane's three neighbours in z
     auto stage_row = [&](int r9, double u3[3][3]) {
 #pragma unroll
-        for (int s7 = 0; s7 < 7; ++s7) buf[lane + 64 * s7] = pre[r9][s7];
+        for (int s7 = 0; s7 < 7; ++s7) buf[lane + 64 * s7] = pre[r9 % GS_PF][s7];
+        if (r9 + GS_PF < 9) issue(r9 + GS_PF);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int n3 = 0; n3 < 3; ++n3)
@@ -458,7 +475,7 @@ __device__ __forceinline__ void gs_load_coef(const double *__restrict__ tab, GsC
 }
 
 template <bool RES>
-__global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__restrict__ tab, const double *__restrict__ E,
+__global__ void __launch_bounds__(256, VFEM_GS_MINW) k_gs_rows_mf0(Dims d, const double *__restrict__ tab, const double *__restrict__ E,
                                                      double *__restrict__ u, const double *__restrict__ b,
                                                      const uint8_t *__restrict__ mask, int cx, int cy, int cz, int forward) {
     __shared__ double rowbuf[4][GS_ROWBUF];
@@ -477,7 +494,7 @@ __global__ void __launch_bounds__(256) k_gs_rows_mf0(Dims d, const double *__res
 // reads this row (rows of equal parity are two apart), and the order A(s+1) before B(s) (even colour first) resp. A(s), B(s)
 // (odd colour first) keeps every first-colour update ahead of the second-colour updates that read it and behind none.
 template <bool RES>
-__global__ void __launch_bounds__(256) k_gs_rows_mf0_pair(Dims d, const double *__restrict__ tab, const double *__restrict__ E,
+__global__ void __launch_bounds__(256, VFEM_GS_MINW) k_gs_rows_mf0_pair(Dims d, const double *__restrict__ tab, const double *__restrict__ E,
                                                           double *__restrict__ u, const double *__restrict__ b,
                                                           const uint8_t *__restrict__ mask, int cx, int cy, int c1, int forward,
                                                           int ystride) {
@@ -702,8 +719,8 @@ void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const doubl
             ++ci;
             continue;
         }
-        if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab && res) k_gs_rows_mf0<true><<<grd, blk, 0, s>>>(d, gs_tab + GS_TABLE_DOUBLES, E, u, b, mask, cx, cy, cz, forward);
-        else if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab) k_gs_rows_mf0<false><<<grd, blk, 0, s>>>(d, gs_tab, E, u, b, mask, cx, cy, cz, forward);
+        if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab && res && d.nz >= 2) k_gs_rows_mf0<true><<<grd, blk, 0, s>>>(d, gs_tab + GS_TABLE_DOUBLES, E, u, b, mask, cx, cy, cz, forward);
+        else if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab && d.nz >= 2) k_gs_rows_mf0<false><<<grd, blk, 0, s>>>(d, gs_tab, E, u, b, mask, cx, cy, cz, forward);
         else if (kind == OP_MF0) k_gs_color_mf<0><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
         else if (g_mf1_sym && g_gs_variant == 0 && gs_tab) k_gs_color_mf1_sym<<<grd, blk, 0, s>>>(d, K, gs_tab, mdiag, E, u, b, mask, cx, cy, cz, forward);
         else                k_gs_color_mf<1><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
