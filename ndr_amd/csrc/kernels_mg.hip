@@ -480,7 +480,9 @@ __global__ void __launch_bounds__(256, VFEM_GS_MINW) k_gs_rows_mf0(Dims d, const
                                                      const uint8_t *__restrict__ mask, int cx, int cy, int cz, int forward) {
     __shared__ double rowbuf[4][GS_ROWBUF];
     const int x = 2 * blockIdx.z + cx;
-    const int y = 2 * (blockIdx.y * 4 + threadIdx.y) + cy;
+    // (threadIdx.y is the wave index: telling the compiler that y is wave-uniform moves the row / column address arithmetic to
+    // the scalar unit and out of the vector registers)
+    const int y = __builtin_amdgcn_readfirstlane(2 * (blockIdx.y * 4 + threadIdx.y) + cy);
     if (y >= d.NY || x >= d.NX) return;                 // wave-uniform; no block-level barrier below
     GsCoef ck;
     gs_load_coef<RES>(tab, ck);
@@ -500,7 +502,7 @@ __global__ void __launch_bounds__(256, VFEM_GS_MINW) k_gs_rows_mf0_pair(Dims d, 
                                                           int ystride) {
     __shared__ double rowbuf[4][GS_ROWBUF];
     const int x = 2 * blockIdx.z + cx;
-    const int y = ystride * (blockIdx.y * 4 + threadIdx.y) + cy;       // ystride 2: every row of parity cy
+    const int y = __builtin_amdgcn_readfirstlane(ystride * (blockIdx.y * 4 + threadIdx.y) + cy);       // ystride 2: every row of parity cy
     if (y >= d.NY || x >= d.NX) return;                 // wave-uniform; no block-level barrier below
     double *buf = rowbuf[threadIdx.y];
     GsCoef ck;
