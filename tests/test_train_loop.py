@@ -73,3 +73,29 @@ def test_train_xdg_closure_on_device_decreases_compliance_and_keeps_volume():
     # the sensitivity that reached the network is the solver's own: compare with the problem's gradient
     g_dev = top.evaluateObjectiveGradient_device()
     assert g_dev.is_cuda and g_dev.shape[0] == int(np.prod(grid))
+
+
+@pytest.mark.gpu
+def test_driver_scripts_run_end_to_end(tmp_path, monkeypatch):
+    """training/train_voxelfem.py and training/train_xdg.py (the reference's command lines) on small grids: they run from the
+    repository root, print the reference's progress lines and leave their outputs"""
+    import importlib.util
+    monkeypatch.chdir(ROOT)
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "training", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    out = str(tmp_path / "logs")
+    h = load("train_voxelfem").main(["--jid", "t", "--grid", "[32, 16, 16]", "--prob", "problems/3d/cantilever_flexion.json", "--v0", "0.5",
+                                     "--mgl", "2", "--iter", "3", "--out", out])
+    assert len(h) == 3 and h[1] < h[0]
+    assert any(f.endswith(".vtr") for f in os.listdir(os.path.join(out, "densities", "gt", "t")))
+    h2 = load("train_voxelfem").main(["--jid", "t2", "--prob", "problems/2d/mbb_beam.json", "--grid", "[60, 20]", "--mgl", "0", "--iter", "2", "--out", out])
+    assert len(h2) == 2 and h2[1] < h2[0]
+    h3 = load("train_xdg").main(["--jid", "x", "--grid", "[32, 16, 8]", "--prob", "problems/3d/bridge.json", "--mgl", "2", "--es", "64", "--nn", "64",
+                                 "--nl", "4", "--sigma", "2", "--iter", "8", "--cs", "2", "--lr", "3e-3", "--out", out])
+    assert len(h3) == 8 and all(np.isfinite(h3)) and min(h3[1:]) < h3[0]
+    assert any(f.endswith(".pt") for f in os.listdir(os.path.join(out, "weights", "ff", "x")))
