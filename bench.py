@@ -204,6 +204,16 @@ def mlp_rate(side=(512, 256, 256), es=1024, nn_=512, nl=4, sigma=4.0, reps=3):
     res = {"grid": "%dx%dx%d" % tuple(side), "network": "%d->%d x%d->1" % (2 * es, nn_, nl - 1), "operands": "f16, f32 accumulate",
            "seconds": dt, "voxels_per_s": nv / dt, "tflops": flop / dt / 1e12,
            "mfma_frac_of_2.5PF": flop / dt / 2.5e15}
+    # the reference-precision mode (fp32 features, library SGEMMs): the parity path, reported beside the fused kernel
+    m.precision = "fp32"
+    m.forward_grid(side)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m.forward_grid(side)
+    torch.cuda.synchronize()
+    d32 = time.perf_counter() - t0
+    res["fp32_mode"] = {"seconds": d32, "voxels_per_s": nv / d32, "tflops": flop / d32 / 1e12, "operands": "f32 (rocBLAS SGEMM)"}
+    m.precision = "fp16"
     # parameter gradients of the whole grid (recomputed forward with saved activations + data path + weight-gradient GEMMs)
     g = torch.randn(nv, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
     m.backward_grid(side, g)

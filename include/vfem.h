@@ -250,6 +250,12 @@ int vfem_mlp_forward_grid(vfem_mlp *mlp, const int64_t n_host[3], const double l
  * the start of the range.  A rank of an x-slab decomposition evaluates its own planes with this (the field needs no exchange). */
 int vfem_mlp_forward_grid_range(vfem_mlp *mlp, const int64_t n_host[3], const double lo_host[3], const double hi_host[3],
                                 int64_t first_voxel, int64_t num_voxels, float *out_f32, double *out_f64, void *stream);
+/* The same two forwards in the reference's own arithmetic: fp32 features with accurate sin / cos of 2 pi x . B, fp32 GEMMs
+ * (networks.py:170-185 runs in torch's default dtype).  Parity mode: several times slower than the fused fp16-operand kernel,
+ * which moves the densities by ~1e-3 relative. */
+int vfem_mlp_forward_f32(vfem_mlp *mlp, const float *coords, int64_t nvox, float *out_f32, double *out_f64, void *stream);
+int vfem_mlp_forward_grid_range_f32(vfem_mlp *mlp, const int64_t n_host[3], const double lo_host[3], const double hi_host[3],
+                                    int64_t first_voxel, int64_t num_voxels, float *out_f32, double *out_f64, void *stream);
 /* Training (what torch.autograd does for networks.MLP in train_xdg.py:282-329): gradients of a scalar loss wrt the
  * parameters given g_out[v] = dL/d(out[v]) (device, fp32).  Outputs are overwritten, fp32, same layouts as vfem_mlp_load_weights:
  * dW1 [nn][2 es], dWh [n_layers-2][nn][nn], dbias [n_layers-1][nn], dwout [nn], dbout [1].  fp16 operands / fp32 accumulation;

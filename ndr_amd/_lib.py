@@ -75,6 +75,8 @@ SIGNATURES = {
                             RESIDUAL_CB, c_void_p, POINTER(c_int), POINTER(c_double), c_void_p]),
     "vfem_mlp_forward_grid_range": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double), c_int64, c_int64,
                                             c_void_p, c_void_p, c_void_p]),
+    "vfem_mlp_forward_grid_range_f32": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double), c_int64, c_int64,
+                                                c_void_p, c_void_p, c_void_p]),
     "vfem_mlp_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vfem_mlp_backward_grid": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double), c_void_p, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -122,6 +124,7 @@ SIGNATURES = {
     "vfem_mlp_destroy": (c_int, [c_void_p]),
     "vfem_mlp_load_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float]),
     "vfem_mlp_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "vfem_mlp_forward_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "vfem_mlp_forward_grid": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double), POINTER(c_double), c_void_p,
                                       c_void_p, c_void_p]),
     "vfem_timers_reset": (c_int, []),

@@ -963,6 +963,8 @@ int vfem_mlp_load_weights(vfem_mlp *m, const float *B, const float *W1, const fl
         VFEM_HIP(hipDeviceSynchronize());
     };
     up(m->B, B, (size_t) m->es * 3);
+    up(m->W1f, W1, (size_t) m->nn * 2 * m->es);            // fp32 copies for the reference-precision forward
+    up(m->Whf, Wh, (size_t) nh * m->nn * m->nn);
     up16(m->W1, W1, (size_t) m->nn * 2 * m->es);
     up16(m->Wh, Wh, (size_t) nh * m->nn * m->nn);
     m->WhT.alloc((size_t) nh * m->nn * m->nn);
@@ -1030,7 +1032,70 @@ int vfem_mlp_forward_grid_range(vfem_mlp *m, const int64_t n[3], const double lo
     launch_mlp_forward(a, S(stream));
     VFEM_CATCH
 }
-
+}  // extern "C"
+// Reference-precision forward (the reference evaluates networks.MLP in fp32 end to end): Fourier features in fp32 with accurate
+// sin / cos, the Linear layers as library SGEMMs (fp32 MFMA in rocBLAS), bias + ReLU and the output layer as small kernels.
+// Voxels are processed in chunks; nothing is fused, every activation passes through HBM -- this is the parity mode (the
+// fused fp16-operand kernel is 10-20 x faster and changes the compliance of the config-4 closure by 1e-5).
+static void mlp_forward_f32_impl(vfem_mlp *m, vfem::MlpArgs base, float *o32, double *o64, hipStream_t s) {
+    if (!m->loaded) throw Error("vfem_mlp_load_weights has not been called");
+    const long long V = base.nvox;
+    const int nn = m->nn, K1 = 2 * m->es, nh = m->n_layers - 2;
+    const long long Vc = std::min<long long>(V, 1LL << 14);
+    m->f32_feat.alloc((size_t) Vc * K1);
+    m->f32_h[0].alloc((size_t) Vc * nn);
+    m->f32_h[1].alloc((size_t) Vc * nn);
+    if (!m->rocblas) {
+        rocblas_handle hnd;
+        if (rocblas_create_handle(&hnd) != rocblas_status_success) throw Error("rocblas_create_handle failed");
+        m->rocblas = hnd;
+    }
+    rocblas_handle hnd = (rocblas_handle) m->rocblas;
+    rocblas_set_stream(hnd, s);
+    rocblas_set_pointer_mode(hnd, rocblas_pointer_mode_host);
+    const float one = 1.f, zero = 0.f;
+    // row-major H[rows][n] = X[rows][k] W^T, W row-major [n][k]  <=>  column-major H^T (n x rows) = W^T(op T) ... (k x n)^T (k x rows)
+    auto linear = [&](const float *W, const float *X, float *H, long long rows, int n, int k) {
+        if (rocblas_sgemm(hnd, rocblas_operation_transpose, rocblas_operation_none, n, (rocblas_int) rows, k, &one, W, k, X, k, &zero, H, n)
+            != rocblas_status_success) throw Error("rocblas_sgemm failed");
+    };
+    for (long long c0 = 0; c0 < V; c0 += Vc) {
+        const long long rows = std::min(Vc, V - c0);
+        vfem::MlpArgs a = base;
+        a.v_offset = base.v_offset + c0;
+        if (base.coords) { a.coords = base.coords + 3 * c0; a.v_offset = 0; }
+        a.nvox = rows;
+        launch_mlp_features_f32(a, rows, m->f32_feat.p, s);
+        linear(m->W1f.p, m->f32_feat.p, m->f32_h[0].p, rows, nn, K1);
+        launch_bias_relu_f32(rows, nn, m->f32_h[0].p, m->bias.p, s);
+        int cur = 0;
+        for (int l = 0; l < nh; ++l) {
+            linear(m->Whf.p + (size_t) l * nn * nn, m->f32_h[cur].p, m->f32_h[1 - cur].p, rows, nn, nn);
+            launch_bias_relu_f32(rows, nn, m->f32_h[1 - cur].p, m->bias.p + (size_t) (l + 1) * nn, s);
+            cur = 1 - cur;
+        }
+        launch_mlp_out_f32(rows, nn, m->f32_h[cur].p, m->wout.p, m->bout, m->sigmoid, o32 ? o32 + c0 : nullptr, o64 ? o64 + c0 : nullptr, s);
+    }
+}
+extern "C" {
+int vfem_mlp_forward_f32(vfem_mlp *m, const float *coords, int64_t nvox, float *o32, double *o64, void *stream) {
+    VFEM_TRY
+    MlpArgs a = mlp_base_args(m);
+    a.coords = coords; a.nvox = nvox;
+    mlp_forward_f32_impl(m, a, o32, o64, S(stream));
+    VFEM_CATCH
+}
+int vfem_mlp_forward_grid_range_f32(vfem_mlp *m, const int64_t n[3], const double lo[3], const double hi[3], int64_t first_voxel,
+                                    int64_t num_voxels, float *o32, double *o64, void *stream) {
+    VFEM_TRY
+    MlpArgs a = mlp_base_args(m);
+    mlp_grid_args(a, n, lo, hi);
+    if (first_voxel < 0 || num_voxels < 0 || first_voxel + num_voxels > a.nvox) throw Error("voxel range outside the grid");
+    if (num_voxels == 0) return 0;
+    a.v_offset = first_voxel; a.nvox = num_voxels;
+    mlp_forward_f32_impl(m, a, o32, o64, S(stream));
+    VFEM_CATCH
+}
 }  // extern "C"
 // Gradients of a scalar loss wrt the MLP parameters given dL/d(out) per voxel (what torch.autograd computes for
 // networks.MLP in the reference, train_xdg.py:282-329).  Voxels are processed in chunks: forward pass with saved fp16

@@ -29,6 +29,9 @@ class MLP:
         _lib.require_gpu()
         self._lib = _lib.load()
         self.embedding_size, self.n_neurons, self.n_layers, self.scale = embedding_size, n_neurons, n_layers, scale
+        # "fp16": the fused kernel (fp16 MFMA operands, fp32 accumulation).  "fp32": the reference's arithmetic (fp32 features,
+        # library SGEMMs) -- the parity mode, several times slower; the backward pass is the fp16-operand one in both modes
+        self.precision = "fp16"
         h = ctypes.c_void_p()
         _lib.check(self._lib.vfem_mlp_create(ctypes.byref(h), int(embedding_size), int(n_neurons), int(n_layers),
                                              int(name == "Sigmoid")))
@@ -88,9 +91,16 @@ class MLP:
         hi = (ctypes.c_double * 3)(*[float(d[1]) for d in dom])
         out = torch.empty(int(num_voxels), dtype=torch.float32, device=_dev())
         o64 = _ptr(out_f64) if out_f64 is not None else None
-        _lib.check(self._lib.vfem_mlp_forward_grid_range(self._h, n, lo, hi, int(first_voxel), int(num_voxels), _ptr(out), o64,
-                                                         _stream()))
+        _lib.check(self._entry("vfem_mlp_forward_grid_range")(self._h, n, lo, hi, int(first_voxel), int(num_voxels), _ptr(out), o64,
+                                                              _stream()))
         return out
+
+    def _entry(self, name):
+        if self.precision == "fp16":
+            return getattr(self._lib, name)
+        if self.precision != "fp32":
+            raise RuntimeError("precision must be 'fp16' or 'fp32'")
+        return getattr(self._lib, {"vfem_mlp_forward": "vfem_mlp_forward_f32", "vfem_mlp_forward_grid_range": "vfem_mlp_forward_grid_range_f32"}[name])
 
     # ---- training ----
     def _grad_buffers(self):
@@ -158,7 +168,7 @@ class MLP:
         c = torch.as_tensor(coords, dtype=torch.float32, device=_dev()).contiguous()
         n = c.numel() // 3
         out = torch.empty(n, dtype=torch.float32, device=_dev())
-        _lib.check(self._lib.vfem_mlp_forward(self._h, _ptr(c), n, _ptr(out), None, _stream()))
+        _lib.check(self._entry("vfem_mlp_forward")(self._h, _ptr(c), n, _ptr(out), None, _stream()))
         return out.reshape(c.shape[:-1] + (1,))
 
     __call__ = forward
@@ -173,7 +183,10 @@ class MLP:
         nv = int(np.prod([int(s) for s in sidelen]))
         out = torch.empty(nv, dtype=torch.float32, device=_dev())
         o64 = _ptr(out_f64) if out_f64 is not None else None
-        _lib.check(self._lib.vfem_mlp_forward_grid(self._h, n, lo, hi, _ptr(out), o64, _stream()))
+        if self.precision == "fp16":
+            _lib.check(self._lib.vfem_mlp_forward_grid(self._h, n, lo, hi, _ptr(out), o64, _stream()))
+        else:
+            _lib.check(self._entry("vfem_mlp_forward_grid_range")(self._h, n, lo, hi, 0, nv, _ptr(out), o64, _stream()))
         return out.reshape(tuple(int(s) for s in sidelen))
 
 

@@ -96,6 +96,34 @@ def test_config4_closure_fp16_kernel_vs_fp32_network():
     assert max(gerr) < 2e-2, gerr
 
 
+def test_config4_closure_fp32_mode_meets_the_parity_bar():
+    """the same closure with the kernel in its reference-precision mode (net.kernel.precision = "fp32"): the density agrees
+    with the fp32 torch network to fp32 rounding and the compliance well inside north_star's 1e-5"""
+    from helpers import record_deltas
+    fem, top, net = _setup()
+    net.kernel.precision = "fp32"
+    max_volume = torch.tensor(V0, device="cuda")
+    engine = fem.VoxelFEMFunction.apply
+    res = {}
+    for name in ("kernel", "torch"):
+        net.zero_grad()
+        logits = net.forward_grid() if name == "kernel" else _fp32_logits(net, GRID)
+        density = fem.satisfy_volume_constraint(logits.view(GRID), max_volume, mode="constrained_sigmoid")
+        loss = engine(density.flatten(), top)
+        loss.backward()
+        res[name] = (logits.detach().clone(), density.detach().clone(), 2.0 * top.evaluateObjective(),
+                     [p.grad.detach().clone() for p in net.parameters()])
+    k, r = res["kernel"], res["torch"]
+    d_logit, d_rho = float((k[0] - r[0]).abs().max()), float((k[1] - r[1]).abs().max())
+    d_c = abs(k[2] - r[2]) / abs(r[2])
+    gerr = [float((a - b).norm() / b.norm()) for a, b in zip(k[3][:-1], r[3][:-1])]
+    record_deltas("config4_closure_64x32x32_fp32_mode", {"max_abs_logit": d_logit, "max_abs_density": d_rho,
+                                                        "relative_compliance_delta": d_c, "param_grad_rel_l2": gerr})
+    assert d_logit < 5e-5 and d_rho < 2e-5, (d_logit, d_rho)
+    assert d_c < 1e-6, d_c
+    assert max(gerr) < 2e-2, gerr            # the backward pass keeps fp16 operands in both modes
+
+
 def test_config4_training_steps_reduce_compliance():
     fem, top, net = _setup()
     max_volume = torch.tensor(V0, device="cuda")

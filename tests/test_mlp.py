@@ -121,6 +121,47 @@ def test_hip_mlp_matches_reference(path):
     assert np.abs(rho64.cpu().numpy().reshape(z["out"].shape) - grid).max() < 1e-7
 
 
+TOL_F32 = 5e-5      # fp32 end to end as the reference: only summation order and sin / cos rounding differ
+
+
+@pytest.mark.gpu
+def test_hip_mlp_fp32_mode_matches_reference_to_fp32_rounding():
+    """precision = "fp32" (fp32 features, library SGEMMs, the reference's arithmetic): every fixture, the full-size network,
+    explicit coordinates, the whole grid, a voxel range crossing the 16384-voxel work chunk, and the float64 copy"""
+    import torch
+    from ndr_amd.mlp import MLP
+    from helpers import record_deltas
+    worst = 0.0
+    for path in FIXTURES:
+        z, es, nn_, nl, sig, Ws, bs = _load(path)
+        m = MLP(3, 1, nn_, nl, es, float(z["sigma"][0]), output_act=torch.nn.Sigmoid() if sig else None)
+        m.load_arrays(z["B"], Ws, bs)
+        m.precision = "fp32"
+        got = m.forward(torch.from_numpy(z["coords"]).cuda()).cpu().numpy().reshape(z["out"].shape)
+        side = z["coords"].shape[1:4]
+        rho64 = torch.empty(int(np.prod(side)), dtype=torch.float64, device="cuda")
+        grid = m.forward_grid(side, out_f64=rho64).cpu().numpy().reshape(z["out"].shape)
+        worst = max(worst, float(np.abs(got - z["out"]).max()), float(np.abs(grid - z["out"]).max()))
+        assert np.array_equal(rho64.cpu().numpy().reshape(grid.shape), grid.astype(np.float64))
+    z, es, nn_, nl, B, Ws, bs = _load_full()
+    for sig, key in ((False, "out"), (True, "out_sig")):
+        m = MLP(3, 1, nn_, nl, es, float(z["sigma"][0]), output_act=torch.nn.Sigmoid() if sig else None)
+        m.load_arrays(B, Ws, bs)
+        m.precision = "fp32"
+        got = m.forward(torch.from_numpy(z["coords"]).cuda()).cpu().numpy().reshape(z[key].shape)
+        worst = max(worst, float(np.abs(got - z[key]).max()))
+    record_deltas("mlp_fp32_mode", {"max_abs_error_vs_reference": worst})
+    assert worst < TOL_F32, worst
+    # chunking: a range that starts inside one 16384-voxel chunk and ends in the next equals the slice of the whole grid
+    side = (40, 32, 24)
+    whole = m.forward_grid(side).reshape(-1)
+    part = m.forward_grid_range(side, 9000, 17000)
+    assert float((part - whole[9000:26000]).abs().max()) < 1e-5
+    m.precision = "fp64"
+    with pytest.raises(RuntimeError):
+        m.forward_grid(side)
+
+
 @pytest.mark.gpu
 def test_hip_mlp_requires_weights_and_valid_shapes():
     import torch

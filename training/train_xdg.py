@@ -34,6 +34,8 @@ def main(argv=None):
     ap.add_argument('--cs', default=100, help='a weight checkpoint every iter/cs steps')
     ap.add_argument('--sigma', required=True, help='scale of the Fourier-feature Gaussian')
     ap.add_argument('--out', default='logs')
+    ap.add_argument('--mlp_precision', default='fp16', choices=['fp16', 'fp32'],
+                    help='fp16: fused MFMA kernel (fp16 operands); fp32: the reference network\'s arithmetic (slower)')
     args = ap.parse_args(argv)
     from ndr_amd import fem, pyVoxelFEM
     from ndr_amd.mlp import TrainableMLP
@@ -52,6 +54,7 @@ def main(argv=None):
     top = pyVoxelFEM.TopologyOptimizationProblem(tps, objective, [pyVoxelFEM.TotalVolumeConstraint(v0)], [])
     net = TrainableMLP(3, 1, int(args.nn), int(args.nl), int(args.es), float(args.sigma),
                        output_act=None if hard else torch.nn.Sigmoid())
+    net.kernel.precision = args.mlp_precision
     net.set_grid(grid)
     fem.homogeneous_init(net, v0)
     max_volume = torch.tensor(v0, device="cuda")
