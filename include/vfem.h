@@ -185,6 +185,13 @@ int vfem_mg_pcg(vfem_mg *mg, double *x, const double *b, int max_iter, double to
  * same name. */
 int vfem_gsim_create(vfem_gsim **out, int dim, int degree, const double *bbox_min_host, const double *bbox_max_host,
                      const int64_t *nelems_host);
+/* slab decomposition (no reference counterpart; the domain decomposition north_star asks for, 3-D only): a simulator whose
+ * density / modulus arrays hold elem_extra_lo / _hi further element layers below / above the node grid along x.
+ * vfem_gsim_set_densities then takes all stored layers (vfem_gsim_num_stored_elements values, x slowest); every other entry
+ * point sees the elements of the node grid only. */
+int vfem_gsim_create_padded(vfem_gsim **out, int dim, int degree, const double *bbox_min_host, const double *bbox_max_host,
+                            const int64_t *nelems_host, int64_t elem_extra_lo, int64_t elem_extra_hi);
+int64_t vfem_gsim_num_stored_elements(const vfem_gsim *sim);
 int vfem_gsim_destroy(vfem_gsim *sim);
 int64_t vfem_gsim_num_nodes(const vfem_gsim *sim);
 int64_t vfem_gsim_num_elements(const vfem_gsim *sim);
@@ -200,6 +207,19 @@ int vfem_gsim_apply_k(const vfem_gsim *sim, const double *u, double *out, void *
 int vfem_gsim_compliance_gradient(const vfem_gsim *sim, const double *u, double *g, void *stream);    /* TPS.hh:730-751 */
 int vfem_gsim_compliance(const vfem_gsim *sim, const double *f, const double *u, double *value_host, void *stream);  /* 1/2 f.u */
 int vfem_gmg_create(vfem_gmg **out, vfem_gsim *fine, int num_coarsening_levels);                      /* MG.hh:22-90 */
+/* The same three pieces as vfem_mg_create_slab / vfem_mg_create_partial / vfem_mg_{export,import}_level_ke for the generic path
+ * (degree-2 hexahedra over the GPUs of a node, BASELINE config 5).  A rank's local hierarchy keeps two ghost element layers
+ * (2 p node planes) towards each neighbour on every level: the restriction to an interface node reaches 2 p - 1 fine planes
+ * to either side.  vfem_slab_level.xshift here: local plane of level l-1 = 2 * (local plane of level l) + xshift (<= 0);
+ * xparity must be 0 (slabs start at even global elements on every distributed level).  Element matrices are ke x ke doubles
+ * per element (81 x 81 for degree 2). */
+int vfem_gmg_create_slab(vfem_gmg **out, vfem_gsim *fine_local, int n_levels, const vfem_slab_level *levels_host,
+                         const uint8_t *const *masks_host);
+int vfem_gmg_create_partial(vfem_gmg **out, vfem_gsim *fine, int num_coarsening_levels, int first_active_level);
+int vfem_gmg_smooth_colors(vfem_gmg *mg, int level, double *u, const double *b, int forward, int first, int count, void *stream);
+int vfem_gmg_cycle_from_level(vfem_gmg *mg, int level, double *x, const double *b, int num_smoothing_steps, int fmg, void *stream);
+int vfem_gmg_export_level_ke(vfem_gmg *mg, int level, int64_t child_first_layer, int64_t count_x, double *ke_out, void *stream);
+int vfem_gmg_import_level_ke(vfem_gmg *mg, int level, const double *ke, void *stream);
 int vfem_gmg_destroy(vfem_gmg *mg);
 int vfem_gmg_num_levels(const vfem_gmg *mg);
 int vfem_gmg_level_dims(const vfem_gmg *mg, int level, int64_t nelems_host[3]);

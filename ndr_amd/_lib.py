@@ -84,6 +84,15 @@ SIGNATURES = {
                                              c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vfem_adam_step": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int, c_void_p]),
     "vfem_gsim_create": (c_int, [POINTER(c_void_p), c_int, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
+    "vfem_gsim_create_padded": (c_int, [POINTER(c_void_p), c_int, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_int64),
+                                        c_int64, c_int64]),
+    "vfem_gsim_num_stored_elements": (c_int64, [c_void_p]),
+    "vfem_gmg_create_slab": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p, POINTER(c_void_p)]),
+    "vfem_gmg_create_partial": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
+    "vfem_gmg_smooth_colors": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "vfem_gmg_cycle_from_level": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "vfem_gmg_export_level_ke": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
+    "vfem_gmg_import_level_ke": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "vfem_gsim_destroy": (c_int, [c_void_p]),
     "vfem_gsim_num_nodes": (c_int64, [c_void_p]),
     "vfem_gsim_num_elements": (c_int64, [c_void_p]),

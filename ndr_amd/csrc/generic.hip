@@ -382,13 +382,16 @@ __global__ void __launch_bounds__(256) kg_coarsen_next_q2(GDims f, GDims c, GWei
 // ------------------------------------------------------------------------------------------
 // grid transfers (MG.hh:116-161): thread per node of the level written
 // ------------------------------------------------------------------------------------------
+// `xs` (slab hierarchies): local fine plane = 2 * (local coarse plane) + xs along axis 0 -- the two local grids of a rank need
+// not start at nested positions; xs <= 0 and every fine plane lies inside the coarse local grid.
 __global__ void __launch_bounds__(256) kg_prolong(GDims f, GDims c, GWeights W, const double *__restrict__ cv,
-                                                  double *__restrict__ fv, int accumulate) {
+                                                  double *__restrict__ fv, int accumulate, int xs) {
     const long long n = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= f.nnodes) return;
     const int N = f.N, p = f.p;
     int e[3] = {0, 0, 0}, t[3] = {0, 0, 0};
-    { long long m = n; for (int a = N - 1; a >= 0; --a) { const int i = (int) (m % f.nn[a]); m /= f.nn[a];
+    { long long m = n; for (int a = N - 1; a >= 0; --a) { int i = (int) (m % f.nn[a]); m /= f.nn[a];
+        if (a == 0) i -= xs;
         int ee = i / (2 * p); if (ee > c.ne[a] - 1) ee = c.ne[a] - 1; e[a] = ee; t[a] = i - 2 * p * ee; } }
     double acc[3] = {0.0, 0.0, 0.0};
     const int q1 = p + 1;
@@ -417,17 +420,20 @@ __device__ __forceinline__ double g_restrict_weight(const GWeights &W, int p, in
     return (a < 0 || a > p) ? 0.0 : W.w[t][a];
 }
 
+// (coarse nodes whose fine support leaves the local fine grid -- ghost planes of a slab -- receive partial sums; the driver
+// never reads them)
 __global__ void __launch_bounds__(256) kg_restrict(GDims f, GDims c, GWeights W, const double *__restrict__ fv,
-                                                   double *__restrict__ cv) {
+                                                   double *__restrict__ cv, int xs) {
     const long long n = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= c.nnodes) return;
     const int N = f.N, p = f.p, R = 2 * p - 1;
     int I[3] = {0, 0, 0};
     { long long m = n; for (int a = N - 1; a >= 0; --a) { I[a] = (int) (m % c.nn[a]); m /= c.nn[a]; } }
     int lo[3], hi[3];
-    for (int a = 0; a < 3; ++a) {
-        lo[a] = a < N ? max(0, 2 * I[a] - R) : 0;
-        hi[a] = a < N ? min(f.nn[a] - 1, 2 * I[a] + R) : 0;
+    for (int a = 0; a < 3; ++a) {                 // axis 0 in the coarse grid's doubled coordinates (fine local = that + xs)
+        const int sh = a == 0 ? xs : 0;
+        lo[a] = a < N ? max(-sh, 2 * I[a] - R) : 0;
+        hi[a] = a < N ? min(f.nn[a] - 1 - sh, 2 * I[a] + R) : 0;
     }
     double acc[3] = {0.0, 0.0, 0.0};
     for (int i0 = lo[0]; i0 <= hi[0]; ++i0) {
@@ -439,7 +445,7 @@ __global__ void __launch_bounds__(256) kg_restrict(GDims f, GDims c, GWeights W,
             for (int i2 = lo[2]; i2 <= hi[2]; ++i2) {
                 const double w2 = N == 3 ? w1 * g_restrict_weight(W, p, c.ne[2], I[2], i2) : w1;
                 if (w2 == 0.0) continue;
-                const int g[3] = {i0, i1, i2};
+                const int g[3] = {i0 + xs, i1, i2};
                 const long long fn = g_node_flat(f, g);
                 for (int r = 0; r < N; ++r) acc[r] = fma(w2, fv[N * fn + r], acc[r]);
             }
@@ -572,8 +578,15 @@ struct vfem_gsim {
     int q2_impl = 0;                               // vfem_gsim_set_option(6, v): 0 marching kernel (mode space), 1 dense gather kernel (cross-check), 2 pencil kernel
     DevBuf<uint8_t> dmask;
     std::vector<uint8_t> hmask;
+    // slab decomposition: element layers (axis 0) stored below / above the node grid; they only feed the Galerkin
+    // element matrices of the ghost elements of coarser levels.  rho / E hold ex_lo + ne[0] + ex_hi layers.
+    long long ex_lo = 0, ex_hi = 0;
+    long long layer() const { return (long long) d.ne[1] * d.ne[2]; }
+    long long stored_elems() const { return d.nelems + (ex_lo + ex_hi) * layer(); }
+    const double *E_local() const { return E.p + ex_lo * layer(); }
+    const double *rho_local() const { return rho.p + ex_lo * layer(); }
     void update_k0();
-    void update_E(hipStream_t s) { launch_simp(d.nelems, rho.p, E0, Emin, gamma, E.p, s); }
+    void update_E(hipStream_t s) { launch_simp(stored_elems(), rho.p, E0, Emin, gamma, E.p, s); }
 };
 
 struct GLevel {
@@ -581,12 +594,22 @@ struct GLevel {
     std::vector<uint8_t> hmask;
     DevBuf<uint8_t> mask;
     DevBuf<double> Ke, x, b, r;
+    // slab hierarchies: element layers of Ke stored below / above the node grid (they feed the ghost elements of the next
+    // level), and the plane shift of the transfers to the next FINER level (fine local plane = 2 * local plane + xs)
+    long long pad_lo = 0, pad_hi = 0;
+    int xs = 0;
+    long long layer() const { return (long long) d.ne[1] * d.ne[2]; }
+    long long stored_elems() const { return d.nelems + (pad_lo + pad_hi) * layer(); }
+    const double *Ke_local() const { return Ke.p + (size_t) pad_lo * layer() * d.ke * d.ke; }
 };
 
 struct vfem_gmg {
     vfem_gsim *fine = nullptr;
     int L = 0;
     bool symmetric_gs = true, operators_valid = false;
+    bool slab = false;                 // local hierarchy of one rank: levels 0..L hold fields and transfers, L only serves the transfers
+    int first_active = 0;              // replicated coarse hierarchy: levels below hold no fields or operators
+    int external_ke_level = -1;        // element matrices of this level were imported (vfem_gmg_import_level_ke)
     std::vector<GLevel> lv;
     GWeights W;
     DevBuf<double> cK0, phi, Ainv, pr, pd, pAd, ps, scal, scratch;
@@ -707,15 +730,15 @@ static void g_apply(const GDims &d, const double *K, long long kstride, const do
 }
 
 static void level_op(const vfem_gmg *mg, int l, const double *&K, long long &kstride, const double *&scale) {
-    if (l == 0) { K = mg->fine->dK0.p; kstride = 0; scale = mg->fine->E.p; }
-    else { K = mg->lv[l].Ke.p; kstride = (long long) mg->lv[l].d.ke * mg->lv[l].d.ke; scale = nullptr; }
+    if (l == 0) { K = mg->fine->dK0.p; kstride = 0; scale = mg->fine->E_local(); }
+    else { K = mg->lv[l].Ke_local(); kstride = (long long) mg->lv[l].d.ke * mg->lv[l].d.ke; scale = nullptr; }
 }
 
 static void gmg_apply(vfem_gmg *mg, int l, const double *u, const double *b, int mode, double *out, hipStream_t s) {
     const vfem_gsim *sim = mg->fine;
     if (l == 0 && sim->d.N == 3 && sim->d.p == 2 && sim->q2_fast && sim->q2_impl != 1) {       // finest degree-2 level: mode-space kernels
-        if (sim->q2_impl == 0) launch_apply_q2_march(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E.p, u, out, s);
-        else launch_apply_q2_pencil(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E.p, u, out, s);
+        if (sim->q2_impl == 0) launch_apply_q2_march(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E_local(), u, out, s);
+        else launch_apply_q2_pencil(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E_local(), u, out, s);
         if (mode != 0) launch_q2_residual_fix(sim->d.nnodes, b, mg->lv[0].mask.p, mode, out, s);
         return;
     }
@@ -724,17 +747,20 @@ static void gmg_apply(vfem_gmg *mg, int l, const double *u, const double *b, int
     g_apply(mg->lv[l].d, K, ks, scale, u, b, mg->lv[l].mask.p, mode, out, s);
 }
 
-static void gmg_smooth(vfem_gmg *mg, int l, double *u, const double *b, int forward, hipStream_t s) {
+// colours [first, first + count) of the sweep in visiting order (forward: local node index ascending, MG.hh:293-295); the
+// colours of one x index are consecutive, which is what a slab driver exchanges halos between
+static void gmg_smooth(vfem_gmg *mg, int l, double *u, const double *b, int forward, hipStream_t s, int first = 0, int count = -1) {
     const GDims &d = mg->lv[l].d;
+    if (count < 0) count = 27;
     if (l == 0 && d.N == 3 && d.p == 2 && mg->fine->q2_impl != 1) {                                  // finest degree-2 level: thread per node
-        launch_gs_sweep_q2_level0(d.ne[0], d.ne[1], d.ne[2], mg->fine->dK0.p, mg->fine->E.p, u, b, mg->lv[0].mask.p, forward, s);
+        launch_gs_sweep_q2_level0(d.ne[0], d.ne[1], d.ne[2], mg->fine->dK0.p, mg->fine->E_local(), u, b, mg->lv[0].mask.p, forward, s, first, count);
         return;
     }
     const double *K, *scale; long long ks;
     level_op(mg, l, K, ks, scale);
     int ncol = 1;
     for (int a = 0; a < d.N; ++a) ncol *= d.p + 1;
-    for (int i = 0; i < ncol; ++i) {
+    for (int i = first; i < std::min(ncol, first + count); ++i) {
         const int lni = forward ? i : ncol - 1 - i;                   // MG.hh:293-295
         GColor col{};
         col.total = 1;
@@ -776,12 +802,12 @@ static void gmg_smooth(vfem_gmg *mg, int l, double *u, const double *b, int forw
 
 static void gmg_restrict(vfem_gmg *mg, int l, const double *fine, double *coarse, hipStream_t s) {
     const GDims &f = mg->lv[l].d, &c = mg->lv[l + 1].d;
-    kg_restrict<<<dim3((unsigned) ((c.nnodes + 255) / 256)), dim3(256), 0, s>>>(f, c, mg->W, fine, coarse);
+    kg_restrict<<<dim3((unsigned) ((c.nnodes + 255) / 256)), dim3(256), 0, s>>>(f, c, mg->W, fine, coarse, mg->lv[l + 1].xs);
     VFEM_HIP(hipGetLastError());
 }
 static void gmg_prolong(vfem_gmg *mg, int l, const double *coarse, double *fine, int accumulate, hipStream_t s) {
     const GDims &f = mg->lv[l].d, &c = mg->lv[l + 1].d;
-    kg_prolong<<<dim3((unsigned) ((f.nnodes + 255) / 256)), dim3(256), 0, s>>>(f, c, mg->W, coarse, fine, accumulate);
+    kg_prolong<<<dim3((unsigned) ((f.nnodes + 255) / 256)), dim3(256), 0, s>>>(f, c, mg->W, coarse, fine, accumulate, mg->lv[l + 1].xs);
     VFEM_HIP(hipGetLastError());
 }
 static void g_dirichlet(const GDims &d, const uint8_t *mask, const double *vals, double *u, hipStream_t s) {
@@ -793,35 +819,50 @@ static void gmg_coarsest(vfem_gmg *mg, const double *b, double *x, hipStream_t s
     launch_gemv_sym((long long) mg->lv[mg->L].d.N * mg->lv[mg->L].d.nnodes, mg->Ainv.p, b, x, s);
 }
 
+// Galerkin element matrices of the coarse elements `c` from their 2^N children in `f` (buildPESCoarse, MG.hh:604-669);
+// first: the children are E-scaled copies of K0 (src = moduli), otherwise src = the children's element matrices
+static void g_coarsen(vfem_gmg *mg, const GDims &f, const GDims &c, bool first, const double *src, double *out, hipStream_t s) {
+    const int N = c.N;
+    const size_t kk = (size_t) c.ke * c.ke;
+    if (c.nelems == 0) return;
+    const dim3 grd((unsigned) c.nelems), blk(256);
+    if (first) kg_coarsen_first<<<grd, blk, 0, s>>>(f, c, mg->cK0.p, src, out);
+    else if (N == 3 && c.p == 2) {
+        static bool attr2 = false;
+        if (!attr2) { VFEM_HIP(hipFuncSetAttribute((const void *) kg_coarsen_next_q2, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 81 * 81 * 8)); attr2 = true; }
+        kg_coarsen_next_q2<<<grd, blk, 2 * kk * sizeof(double), s>>>(f, c, mg->W, src, out);
+    } else {
+        const size_t lds = (2 * kk + (size_t) c.npe * c.npe) * sizeof(double);
+        if (N == 3) kg_coarsen_next<3, 1><<<grd, blk, lds, s>>>(f, c, mg->phi.p, src, out);
+        else if (c.p == 2) kg_coarsen_next<2, 2><<<grd, blk, lds, s>>>(f, c, mg->phi.p, src, out);
+        else kg_coarsen_next<2, 1><<<grd, blk, lds, s>>>(f, c, mg->phi.p, src, out);
+    }
+    VFEM_HIP(hipGetLastError());
+}
+// dims of the stored element array of a level (slab hierarchies keep extra layers along axis 0)
+static GDims stored_dims(const vfem_gmg *mg, int l) {
+    const GLevel &lv = mg->lv[l];
+    const long long lo = l == 0 ? mg->fine->ex_lo : lv.pad_lo, hi = l == 0 ? mg->fine->ex_hi : lv.pad_hi;
+    const long long ne[3] = {lv.d.ne[0] + lo + hi, lv.d.ne[1], lv.d.ne[2]};
+    return make_gdims(lv.d.N, lv.d.p, ne);
+}
+
 static void gmg_update(vfem_gmg *mg, hipStream_t s) {
     vfem_gsim *sim = mg->fine;
     const int N = sim->d.N;
-    for (int l = 1; l <= mg->L; ++l) {
+    if (mg->first_active > 0 && mg->external_ke_level != mg->first_active)
+        throw Error("the element matrices of the first active level have not been imported (vfem_gmg_import_level_ke)");
+    const int l_first = mg->first_active > 0 ? mg->first_active + 1 : 1;
+    const int l_last = mg->slab ? mg->L - 1 : mg->L;             // a slab hierarchy's last level only serves the transfers
+    for (int l = l_first; l <= l_last; ++l) {
         GLevel &lv = mg->lv[l];
         const size_t kk = (size_t) lv.d.ke * lv.d.ke;
-        lv.Ke.alloc((size_t) lv.d.nelems * kk);
-        if (l == 1) kg_coarsen_first<<<dim3((unsigned) lv.d.nelems), dim3(256), 0, s>>>(mg->lv[0].d, lv.d, mg->cK0.p, sim->E.p, lv.Ke.p);
-        else {
-            const size_t lds = (2 * kk + (size_t) lv.d.npe * lv.d.npe) * sizeof(double);
-            static bool attr = false;
-            if (!attr) {
-                VFEM_HIP(hipFuncSetAttribute((const void *) kg_coarsen_next<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 81 * 81 + 27 * 27) * 8));
-                attr = true;
-            }
-            const dim3 grd((unsigned) lv.d.nelems), blk(256);
-            const GDims &fd = mg->lv[l - 1].d;
-            const double *Kf = mg->lv[l - 1].Ke.p;
-            if (N == 3 && sim->d.p == 2) {
-                static bool attr2 = false;
-                if (!attr2) { VFEM_HIP(hipFuncSetAttribute((const void *) kg_coarsen_next_q2, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 81 * 81 * 8)); attr2 = true; }
-                kg_coarsen_next_q2<<<grd, blk, 2 * kk * sizeof(double), s>>>(fd, lv.d, mg->W, Kf, lv.Ke.p);
-            }
-            else if (N == 3) kg_coarsen_next<3, 1><<<grd, blk, lds, s>>>(fd, lv.d, mg->phi.p, Kf, lv.Ke.p);
-            else if (sim->d.p == 2) kg_coarsen_next<2, 2><<<grd, blk, lds, s>>>(fd, lv.d, mg->phi.p, Kf, lv.Ke.p);
-            else kg_coarsen_next<2, 1><<<grd, blk, lds, s>>>(fd, lv.d, mg->phi.p, Kf, lv.Ke.p);
-        }
-        VFEM_HIP(hipGetLastError());
+        const GDims cd = stored_dims(mg, l), fd = stored_dims(mg, l - 1);
+        if (fd.ne[0] != 2 * cd.ne[0]) throw Error("stored element layers of consecutive levels must halve exactly");
+        lv.Ke.alloc((size_t) cd.nelems * kk);
+        g_coarsen(mg, fd, cd, l == 1, l == 1 ? sim->E.p : mg->lv[l - 1].Ke.p, lv.Ke.p, s);
     }
+    if (mg->slab) { mg->operators_valid = true; return; }
     // coarsest level: assemble the dense matrix on the host (a few elements), invert with rocSOLVER
     GLevel &cl = mg->lv[mg->L];
     const GDims &d = cl.d;
@@ -838,12 +879,12 @@ static void gmg_update(vfem_gmg *mg, hipStream_t s) {
     std::vector<double> Ke((size_t) d.nelems * kk);
     if (mg->L == 0) {
         std::vector<double> E((size_t) d.nelems);
-        VFEM_HIP(hipMemcpyAsync(E.data(), sim->E.p, E.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        VFEM_HIP(hipMemcpyAsync(E.data(), sim->E_local(), E.size() * sizeof(double), hipMemcpyDeviceToHost, s));
         VFEM_HIP(hipStreamSynchronize(s));
         for (long long e = 0; e < d.nelems; ++e)
             for (size_t q = 0; q < kk; ++q) Ke[e * kk + q] = E[e] * sim->K0[q];
     } else {
-        VFEM_HIP(hipMemcpyAsync(Ke.data(), cl.Ke.p, Ke.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        VFEM_HIP(hipMemcpyAsync(Ke.data(), cl.Ke_local(), Ke.size() * sizeof(double), hipMemcpyDeviceToHost, s));
         VFEM_HIP(hipStreamSynchronize(s));
     }
     std::vector<double> A((size_t) n * n, 0.0);
@@ -954,7 +995,8 @@ static void coarsen_mask(const GDims &f, const std::vector<uint8_t> &fm, const G
 
 extern "C" {
 
-int vfem_gsim_create(vfem_gsim **out, int dim, int degree, const double *bbmin, const double *bbmax, const int64_t *ne) {
+int vfem_gsim_create_padded(vfem_gsim **out, int dim, int degree, const double *bbmin, const double *bbmax, const int64_t *ne,
+                            int64_t ex_lo, int64_t ex_hi) {
     G_TRY
     if (dim != 2 && dim != 3) throw Error("dimension must be 2 or 3");
     if (degree != 1 && degree != 2) throw Error("No template instantiation matching degreesPerDimension!");
@@ -970,8 +1012,10 @@ int vfem_gsim_create(vfem_gsim **out, int dim, int degree, const double *bbmin, 
         if (!(sim->h[a] > 0)) throw Error("empty domain bounding box");
     }
     sim->update_k0();
-    sim->rho.alloc((size_t) sim->d.nelems); sim->rho.zero(nullptr);
-    sim->E.alloc((size_t) sim->d.nelems);
+    if (ex_lo < 0 || ex_hi < 0 || ((ex_lo || ex_hi) && dim != 3)) throw Error("element padding needs a 3-D grid and non-negative layer counts");
+    sim->ex_lo = ex_lo; sim->ex_hi = ex_hi;
+    sim->rho.alloc((size_t) sim->stored_elems()); sim->rho.zero(nullptr);
+    sim->E.alloc((size_t) sim->stored_elems());
     sim->update_E(nullptr);
     sim->hmask.assign((size_t) sim->d.nnodes, 0);
     sim->dmask.alloc((size_t) sim->d.nnodes); sim->dmask.zero(nullptr);
@@ -980,7 +1024,11 @@ int vfem_gsim_create(vfem_gsim **out, int dim, int degree, const double *bbmin, 
     *out = sim.release();
     G_CATCH
 }
+int vfem_gsim_create(vfem_gsim **out, int dim, int degree, const double *bbmin, const double *bbmax, const int64_t *ne) {
+    return vfem_gsim_create_padded(out, dim, degree, bbmin, bbmax, ne, 0, 0);
+}
 int vfem_gsim_destroy(vfem_gsim *sim) { G_TRY delete sim; G_CATCH }
+int64_t vfem_gsim_num_stored_elements(const vfem_gsim *sim) { return sim->stored_elems(); }
 int64_t vfem_gsim_num_nodes(const vfem_gsim *sim) { return sim->d.nnodes; }
 int64_t vfem_gsim_num_elements(const vfem_gsim *sim) { return sim->d.nelems; }
 int vfem_gsim_ke_size(const vfem_gsim *sim) { return sim->d.ke; }
@@ -1012,13 +1060,14 @@ int vfem_gsim_set_dirichlet(vfem_gsim *sim, const uint8_t *mask_host, const doub
 }
 int vfem_gsim_set_densities(vfem_gsim *sim, const double *rho, void *stream) {
     G_TRY
-    VFEM_HIP(hipMemcpyAsync(sim->rho.p, rho, (size_t) sim->d.nelems * sizeof(double), hipMemcpyDeviceToDevice, GS(stream)));
+    // padded simulators take all stored layers (ex_lo + ne[0] + ex_hi), x slowest
+    VFEM_HIP(hipMemcpyAsync(sim->rho.p, rho, (size_t) sim->stored_elems() * sizeof(double), hipMemcpyDeviceToDevice, GS(stream)));
     sim->update_E(GS(stream));
     G_CATCH
 }
 int vfem_gsim_get_densities(const vfem_gsim *sim, double *rho, void *stream) {
     G_TRY
-    VFEM_HIP(hipMemcpyAsync(rho, sim->rho.p, (size_t) sim->d.nelems * sizeof(double), hipMemcpyDeviceToDevice, GS(stream)));
+    VFEM_HIP(hipMemcpyAsync(rho, sim->rho_local(), (size_t) sim->d.nelems * sizeof(double), hipMemcpyDeviceToDevice, GS(stream)));
     G_CATCH
 }
 int vfem_gsim_set_option(vfem_gsim *sim, int key, int value) {
@@ -1030,18 +1079,18 @@ int vfem_gsim_set_option(vfem_gsim *sim, int key, int value) {
 int vfem_gsim_apply_k(const vfem_gsim *sim, const double *u, double *out, void *stream) {
     G_TRY
     if (sim->d.N == 3 && sim->d.p == 2 && sim->q2_fast && sim->q2_impl == 0)
-        launch_apply_q2_march(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E.p, u, out, GS(stream));
+        launch_apply_q2_march(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E_local(), u, out, GS(stream));
     else if (sim->d.N == 3 && sim->d.p == 2 && sim->q2_fast && sim->q2_impl == 2)
-        launch_apply_q2_pencil(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E.p, u, out, GS(stream));
+        launch_apply_q2_pencil(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E_local(), u, out, GS(stream));
     else if (sim->d.N == 3 && sim->d.p == 2)
-        launch_apply_q2(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->dK0.p, sim->E.p, u, out, GS(stream));
+        launch_apply_q2(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->dK0.p, sim->E_local(), u, out, GS(stream));
     else
-        g_apply(sim->d, sim->dK0.p, 0, sim->E.p, u, nullptr, nullptr, 0, out, GS(stream));
+        g_apply(sim->d, sim->dK0.p, 0, sim->E_local(), u, nullptr, nullptr, 0, out, GS(stream));
     G_CATCH
 }
 int vfem_gsim_compliance_gradient(const vfem_gsim *sim, const double *u, double *g, void *stream) {
     G_TRY
-    kg_gradient<<<dim3((unsigned) ((sim->d.nelems + 3) / 4)), dim3(256), 0, GS(stream)>>>(sim->d, sim->dK0.p, sim->rho.p, sim->E0, sim->Emin,
+    kg_gradient<<<dim3((unsigned) ((sim->d.nelems + 3) / 4)), dim3(256), 0, GS(stream)>>>(sim->d, sim->dK0.p, sim->rho_local(), sim->E0, sim->Emin,
                                                                                        sim->gamma, u, g);
     VFEM_HIP(hipGetLastError());
     G_CATCH
@@ -1059,33 +1108,13 @@ int vfem_gsim_compliance(const vfem_gsim *sim, const double *f, const double *u,
     G_CATCH
 }
 
-int vfem_gmg_create(vfem_gmg **out, vfem_gsim *fine, int L) {
-    G_TRY
-    if (L < 0 || L > 16) throw Error("invalid number of coarsening levels");
-    std::unique_ptr<vfem_gmg> mg(new vfem_gmg);
-    mg->fine = fine; mg->L = L;
-    mg->lv.resize(L + 1);
+// interpolation weights, compressed interpolation operators phi[fi](fine_n, coarse_n) (MG.hh:557-583) and
+// cK0[fi] = I_fi^T K0 I_fi (MG.hh:644-648)
+static void gmg_setup_transfer_tables(vfem_gmg *mg) {
+    const vfem_gsim *fine = mg->fine;
     const int N = fine->d.N, p = fine->d.p;
-    long long ne[3] = {fine->d.ne[0], fine->d.ne[1], fine->d.ne[2]};
-    for (int l = 0; l <= L; ++l) {
-        GLevel &lv = mg->lv[l];
-        if (l > 0) {
-            for (int a = 0; a < N; ++a) {
-                if (ne[a] % 2) throw Error("Grid size currently must be divisible by 2^numCoarseningLevels (nonuniform coarsening not yet implemented)");
-                ne[a] /= 2;
-            }
-        }
-        lv.d = make_gdims(N, p, ne);
-        if (l == 0) lv.hmask = fine->hmask; else coarsen_mask(mg->lv[l - 1].d, mg->lv[l - 1].hmask, lv.d, lv.hmask);
-        lv.mask.alloc((size_t) lv.d.nnodes);
-        VFEM_HIP(hipMemcpy(lv.mask.p, lv.hmask.data(), lv.hmask.size(), hipMemcpyHostToDevice));
-        const size_t n = (size_t) lv.d.nnodes * N;
-        lv.x.alloc(n); lv.b.alloc(n); lv.r.alloc(n);
-        lv.x.zero(nullptr); lv.b.zero(nullptr); lv.r.zero(nullptr);
-    }
     for (int t = 0; t < 5; ++t) for (int a = 0; a < 3; ++a) mg->W.w[t][a] = 0.0;
     for (int t = 0; t <= 2 * p; ++t) for (int a = 0; a <= p; ++a) mg->W.w[t][a] = lagrange1d(p, a, (double) t / (2.0 * p));
-    // compressed interpolation operators phi[fi](fine_n, coarse_n) (MG.hh:557-583) and cK0[fi] = I_fi^T K0 I_fi (MG.hh:644-648)
     const int npe = fine->d.npe, ke = fine->d.ke, q1 = p + 1, nch = 1 << N;
     std::vector<double> phi((size_t) nch * npe * npe), cK0((size_t) nch * ke * ke, 0.0), T((size_t) ke * ke);
     for (int fi = 0; fi < nch; ++fi) {
@@ -1120,8 +1149,87 @@ int vfem_gmg_create(vfem_gmg **out, vfem_gsim *fine, int L) {
     mg->phi.alloc(phi.size()); mg->cK0.alloc(cK0.size());
     VFEM_HIP(hipMemcpy(mg->phi.p, phi.data(), phi.size() * sizeof(double), hipMemcpyHostToDevice));
     VFEM_HIP(hipMemcpy(mg->cK0.p, cK0.data(), cK0.size() * sizeof(double), hipMemcpyHostToDevice));
-    const size_t n0 = (size_t) fine->d.nnodes * N;
-    mg->pr.alloc(n0); mg->pd.alloc(n0); mg->pAd.alloc(n0); mg->ps.alloc(n0);
+}
+static void gmg_alloc_level_fields(GLevel &lv) {
+    lv.mask.alloc((size_t) lv.d.nnodes);
+    VFEM_HIP(hipMemcpy(lv.mask.p, lv.hmask.data(), lv.hmask.size(), hipMemcpyHostToDevice));
+    const size_t n = (size_t) lv.d.nnodes * lv.d.N;
+    lv.x.alloc(n); lv.b.alloc(n); lv.r.alloc(n);
+    lv.x.zero(nullptr); lv.b.zero(nullptr); lv.r.zero(nullptr);
+}
+
+// first_active > 0: the replicated coarse part of a slab-decomposed hierarchy -- levels below hold no fields and no operators;
+// the element matrices of level first_active are imported (vfem_gmg_import_level_ke), cycles start there
+// (vfem_gmg_cycle_from_level); `fine` supplies the grid, the material and the Dirichlet mask only.
+static int gmg_create_common(vfem_gmg **out, vfem_gsim *fine, int L, int first_active) {
+    G_TRY
+    if (L < 0 || L > 16) throw Error("invalid number of coarsening levels");
+    if (first_active < 0 || first_active > L) throw Error("first active level out of range");
+    if (fine->ex_lo || fine->ex_hi) throw Error("simulators with element padding need vfem_gmg_create_slab");
+    std::unique_ptr<vfem_gmg> mg(new vfem_gmg);
+    mg->fine = fine; mg->L = L; mg->first_active = first_active;
+    mg->lv.resize(L + 1);
+    const int N = fine->d.N, p = fine->d.p;
+    long long ne[3] = {fine->d.ne[0], fine->d.ne[1], fine->d.ne[2]};
+    for (int l = 0; l <= L; ++l) {
+        GLevel &lv = mg->lv[l];
+        if (l > 0) {
+            for (int a = 0; a < N; ++a) {
+                if (ne[a] % 2) throw Error("Grid size currently must be divisible by 2^numCoarseningLevels (nonuniform coarsening not yet implemented)");
+                ne[a] /= 2;
+            }
+        }
+        lv.d = make_gdims(N, p, ne);
+        if (l == 0) lv.hmask = fine->hmask; else coarsen_mask(mg->lv[l - 1].d, mg->lv[l - 1].hmask, lv.d, lv.hmask);
+        if (l >= first_active) gmg_alloc_level_fields(lv);
+    }
+    gmg_setup_transfer_tables(mg.get());
+    if (first_active == 0) {
+        const size_t n0 = (size_t) fine->d.nnodes * N;
+        mg->pr.alloc(n0); mg->pd.alloc(n0); mg->pAd.alloc(n0); mg->ps.alloc(n0);
+    }
+    mg->scal.alloc(8); mg->scal.zero(nullptr); mg->scratch.alloc(4096);
+    VFEM_HIP(hipDeviceSynchronize());
+    *out = mg.release();
+    G_CATCH
+}
+int vfem_gmg_create(vfem_gmg **out, vfem_gsim *fine, int L) { return gmg_create_common(out, fine, L, 0); }
+int vfem_gmg_create_partial(vfem_gmg **out, vfem_gsim *fine, int L, int first_active_level) {
+    return gmg_create_common(out, fine, L, first_active_level);
+}
+// The local hierarchy of one rank of an x-slab decomposition (3-D).  Level l holds levels_host[l].nx element layers (owned +
+// ghost) of a grid whose other two extents halve from level to level; levels_host[l].elem_extra_lo / _hi further element layers
+// are kept in the element arrays only (level 0: the simulator's padding), so that the stored layers halve exactly and the
+// ghost elements of every level get complete Galerkin matrices; levels_host[l].xshift (l >= 1) places local plane 0 of level l
+// at local plane xshift of level l-1 (in level l-1's planes: fine plane = 2 * coarse plane + xshift).  xparity must be 0: the
+// driver aligns the slabs so that every local grid starts at an even global element (the colours need no offset then).
+// masks_host[l]: the level's Dirichlet masks (slices of the global coarsened masks).  The last level only serves the transfers.
+int vfem_gmg_create_slab(vfem_gmg **out, vfem_gsim *fine, int n_levels, const vfem_slab_level *lv_in, const uint8_t *const *masks_host) {
+    G_TRY
+    if (n_levels < 1) throw Error("need at least one level");
+    if (fine->d.N != 3) throw Error("slab hierarchies are three-dimensional");
+    std::unique_ptr<vfem_gmg> mg(new vfem_gmg);
+    mg->fine = fine; mg->L = n_levels - 1; mg->slab = true;
+    mg->lv.resize((size_t) n_levels);
+    long long ny = fine->d.ne[1], nz = fine->d.ne[2];
+    for (int l = 0; l < n_levels; ++l) {
+        GLevel &lv = mg->lv[l];
+        if (l > 0) {
+            if (ny % 2 || nz % 2) throw Error("Grid size currently must be divisible by 2^numCoarseningLevels (nonuniform coarsening not yet implemented)");
+            ny /= 2; nz /= 2;
+        }
+        if (lv_in[l].xparity != 0) throw Error("slab levels of the generic path must start at an even global element");
+        const long long ne[3] = {lv_in[l].nx, ny, nz};
+        lv.d = make_gdims(3, fine->d.p, ne);
+        lv.pad_lo = lv_in[l].elem_extra_lo; lv.pad_hi = lv_in[l].elem_extra_hi;
+        lv.xs = l > 0 ? (int) lv_in[l].xshift : 0;
+        if (lv.xs > 0) throw Error("xshift must be <= 0");
+        lv.hmask.assign(masks_host[l], masks_host[l] + lv.d.nnodes);
+        gmg_alloc_level_fields(lv);
+    }
+    if (fine->d.ne[0] != mg->lv[0].d.ne[0] || fine->ex_lo != mg->lv[0].pad_lo || fine->ex_hi != mg->lv[0].pad_hi)
+        throw Error("level 0 of the slab hierarchy does not match the simulator");
+    gmg_setup_transfer_tables(mg.get());
     mg->scal.alloc(8); mg->scal.zero(nullptr); mg->scratch.alloc(4096);
     VFEM_HIP(hipDeviceSynchronize());
     *out = mg.release();
@@ -1162,6 +1270,63 @@ int vfem_gmg_residual(vfem_gmg *mg, int level, const double *u, const double *b,
 int vfem_gmg_smooth(vfem_gmg *mg, int level, double *u, const double *b, int forward, void *stream) {
     G_TRY g_check_level(mg, level, true); gmg_smooth(mg, level, u, b, forward, GS(stream)); G_CATCH
 }
+int vfem_gmg_smooth_colors(vfem_gmg *mg, int level, double *u, const double *b, int forward, int first, int count, void *stream) {
+    G_TRY
+    g_check_level(mg, level, true);
+    int ncol = 1;
+    for (int a = 0; a < mg->fine->d.N; ++a) ncol *= mg->fine->d.p + 1;
+    if (first < 0 || count < 0 || first + count > ncol) throw Error("colour range out of bounds");
+    gmg_smooth(mg, level, u, b, forward, GS(stream), first, count);
+    G_CATCH
+}
+// one cycle of the replicated coarse hierarchy on the residual system of `level` (x = 0 initial guess for the full cycle)
+int vfem_gmg_cycle_from_level(vfem_gmg *mg, int level, double *x, const double *b, int nsmooth, int fmg, void *stream) {
+    G_TRY
+    g_check_level(mg, level, false);
+    if (level < mg->first_active) throw Error("level below the first active level of this hierarchy");
+    if (mg->slab) throw Error("slab hierarchies are cycled by the distributed driver");
+    if (!mg->operators_valid) throw Error("coarse operators not built: call vfem_gmg_update_operators first");
+    hipStream_t s = GS(stream);
+    GLevel &L = mg->lv[level];
+    const size_t bytes = (size_t) L.d.nnodes * L.d.N * sizeof(double);
+    VFEM_HIP(hipMemcpyAsync(L.b.p, b, bytes, hipMemcpyDeviceToDevice, s));
+    if (fmg) gmg_fmg(mg, level, nsmooth, true, s);
+    else {
+        VFEM_HIP(hipMemcpyAsync(L.x.p, x, bytes, hipMemcpyDeviceToDevice, s));
+        gmg_vcycle(mg, level, nsmooth, true, s);
+    }
+    VFEM_HIP(hipMemcpyAsync(x, L.x.p, bytes, hipMemcpyDeviceToDevice, s));
+    G_CATCH
+}
+// Galerkin element matrices of `count_x` element layers of `level` computed from their children, which start at stored layer
+// `child_first_layer` of level - 1 (level 1: of the simulator's moduli): what a rank contributes to the first replicated level
+int vfem_gmg_export_level_ke(vfem_gmg *mg, int level, int64_t child_first_layer, int64_t count_x, double *ke_out, void *stream) {
+    G_TRY
+    g_check_level(mg, level, false);
+    if (level < 1) throw Error("level 0 has no stored element matrices");
+    if (level > 1 && !mg->operators_valid) throw Error("coarse operators not built: call vfem_gmg_update_operators first");
+    const GDims fs = stored_dims(mg, level - 1);
+    if (child_first_layer < 0 || count_x < 0 || child_first_layer + 2 * count_x > fs.ne[0]) throw Error("child layers outside the stored element array");
+    const GLevel &lv = mg->lv[level];
+    const long long cne[3] = {count_x, lv.d.ne[1], lv.d.ne[2]}, fne[3] = {2 * count_x, fs.ne[1], fs.ne[2]};
+    const GDims c = make_gdims(3, lv.d.p, cne), f = make_gdims(3, lv.d.p, fne);
+    const size_t child_stride = level == 1 ? 1 : (size_t) lv.d.ke * lv.d.ke;
+    const double *src = (level == 1 ? mg->fine->E.p : mg->lv[level - 1].Ke.p) + (size_t) child_first_layer * fs.ne[1] * fs.ne[2] * child_stride;
+    g_coarsen(mg, f, c, level == 1, src, ke_out, GS(stream));
+    G_CATCH
+}
+int vfem_gmg_import_level_ke(vfem_gmg *mg, int level, const double *ke, void *stream) {
+    G_TRY
+    g_check_level(mg, level, false);
+    if (level < 1 || mg->slab) throw Error("element matrices can be imported into levels >= 1 of a replicated hierarchy");
+    GLevel &lv = mg->lv[level];
+    const size_t n = (size_t) lv.d.nelems * lv.d.ke * lv.d.ke;
+    lv.Ke.alloc(n);
+    VFEM_HIP(hipMemcpyAsync(lv.Ke.p, ke, n * sizeof(double), hipMemcpyDeviceToDevice, GS(stream)));
+    mg->external_ke_level = level;
+    mg->operators_valid = false;
+    G_CATCH
+}
 int vfem_gmg_zero_dirichlet(vfem_gmg *mg, int level, double *u, void *stream) {
     G_TRY g_check_level(mg, level, false); g_dirichlet(mg->lv[level].d, mg->lv[level].mask.p, nullptr, u, GS(stream)); G_CATCH
 }
@@ -1175,6 +1340,7 @@ int vfem_gmg_solve(vfem_gmg *mg, double *x, const double *f, int num_steps, int 
                    int zero_dirichlet, int fmg, void *stream) {
     G_TRY
     hipStream_t s = GS(stream);
+    if (mg->slab || mg->first_active > 0) throw Error("slab / partial hierarchies are cycled by the distributed driver");
     if (!stiffness_updated) gmg_update(mg, s);                         // MG.hh:455
     else if (!mg->operators_valid) throw Error("coarse operators not built");
     if (num_steps == 0) return 0;
@@ -1189,6 +1355,7 @@ int vfem_gmg_pcg(vfem_gmg *mg, double *x, const double *b, int max_iter, double 
                  int fmg, vfem_residual_cb residual_cb, void *cb_user, int *iters_out, double *relres_out, void *stream) {
     G_TRY
     hipStream_t s = GS(stream);
+    if (mg->slab || mg->first_active > 0) throw Error("slab / partial hierarchies are solved by the distributed driver");
     vfem_gsim *sim = mg->fine;
     const long long nn = sim->d.nnodes, n3 = sim->d.N * nn;
     const size_t bytes = (size_t) n3 * sizeof(double);

@@ -668,10 +668,10 @@ __global__ void __launch_bounds__(256) k_gs_q2_level0(DimsQ2 d, Q2Color col, con
 }
 
 void launch_gs_sweep_q2_level0(int nx, int ny, int nz, const double *K0, const double *E, double *u, const double *b,
-                               const uint8_t *mask, int forward, hipStream_t s) {
+                               const uint8_t *mask, int forward, hipStream_t s, int first, int count) {
     DimsQ2 d{nx, ny, nz, 2 * nx + 1, 2 * ny + 1, 2 * nz + 1};
     const int NN[3] = {d.NX, d.NY, d.NZ};
-    for (int ci = 0; ci < 27; ++ci) {
+    for (int ci = first; ci < (first + count < 27 ? first + count : 27); ++ci) {
         const int lni = forward ? ci : 26 - ci;                      // MG.hh:293-295
         const int l[3] = {lni / 9, (lni / 3) % 3, lni % 3};
         Q2Color col;

@@ -88,19 +88,21 @@ class HaloExchanger:
         v = field.view(p.n_planes, -1)
         staged = field.is_cuda and dist.get_backend(self.group) == "gloo"
         ops, recvs = [], []
+        w = getattr(p, "halo_width", 1)        # ghost node planes per side (degree-2 slabs: 4), contiguous in memory
 
-        def add(send_plane, recv_plane, peer):
-            sb = v[send_plane].cpu() if staged else v[send_plane]
-            rb = torch.empty_like(sb) if staged else v[recv_plane]
+        def add(send_first, recv_first, peer):
+            send, recv = slice(send_first, send_first + w), slice(recv_first, recv_first + w)
+            sb = v[send].cpu() if staged else v[send]
+            rb = torch.empty_like(sb) if staged else v[recv]
             ops.append(dist.P2POp(dist.isend, sb, peer, self.group))
             ops.append(dist.P2POp(dist.irecv, rb, peer, self.group))
             if staged:
-                recvs.append((recv_plane, rb))
+                recvs.append((recv, rb))
 
-        if p.gl:   # left neighbour: send my plane first_owned+1, receive my ghost plane 0
-            add(p.first_owned + 1, 0, p.rank - 1)
-        if p.gr:   # right neighbour: send my plane last_owned-1, receive my ghost plane last_owned+1
-            add(p.last_owned - 1, p.last_owned + 1, p.rank + 1)
+        if p.gl:   # left neighbour: send my planes first_owned+1 .., receive my ghost planes 0 ..
+            add(p.first_owned + 1, p.first_owned - w, p.rank - 1)
+        if p.gr:   # right neighbour: send my planes .. last_owned-1, receive my ghost planes last_owned+1 ..
+            add(p.last_owned - w, p.last_owned + 1, p.rank + 1)
         return dist.batch_isend_irecv(ops), recvs, v
 
     def finish(self, handle):
@@ -477,6 +479,20 @@ class DistributedMGSolver:
         self.last_iterations, self.last_relative_residual = 0, 0.0
 
     # ---- small helpers -------------------------------------------------------------------
+    _MG_PREFIX = "vfem_mg_"        # C entry points of the hierarchy handles (the degree-2 subclass uses vfem_gmg_)
+    KE_DOUBLES = 576               # doubles per element matrix of the first replicated level
+    COLOR_GROUPS = ((0, 4), (4, 4))   # colours between two halo refreshes: all colours of one x index
+    MIN_SHARDED_T = 2              # degree 1: level 1 is virtual, the first level with stored matrices is 2
+    ALWAYS_ASSEMBLE = False        # degree 2: the replicated hierarchy never derives its first level from the global moduli
+
+    def _mg(self, name):
+        return getattr(self.lib, self._MG_PREFIX + name)
+
+    def _export_child_level(self):
+        """level whose stored layers the first replicated level's matrices are built from (degree 1: level 1 is virtual, so
+        level 2 is built from the moduli)"""
+        return self.T - 1 if self.T >= 3 else 0
+
     def _s(self):
         return self._ct.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -547,54 +563,55 @@ class DistributedMGSolver:
 
     def _assemble_first_replicated_level(self):
         """element matrices of level T for the whole grid = the ranks' slabs of them, concatenated along x"""
-        gT, child = self.geom[self.T], self.geom[self.T - 1 if self.T >= 3 else 0]
+        gT, child = self.geom[self.T], self.geom[self._export_child_level()]
         nyz = (self.ne[1] >> self.T) * (self.ne[2] >> self.T)
         count = gT.X1 - gT.X0
-        mine = torch.empty(count * nyz * 576, dtype=torch.float64, device=self.dev)
-        self._chk(self.lib.vfem_mg_export_level_ke(self.lmg, self.T, child.gl + child.extra_lo, count, self._p(mine), self._s()))
+        KE = self.KE_DOUBLES
+        mine = torch.empty(count * nyz * KE, dtype=torch.float64, device=self.dev)
+        self._chk(self._mg("export_level_ke")(self.lmg, self.T, child.gl + child.extra_lo, count, self._p(mine), self._s()))
         if self.world == 1:
             whole = mine
         else:
             counts = [(self.part.starts[r + 1] - self.part.starts[r]) >> self.T for r in range(self.world)]
             staged = dist.get_backend(self.group) == "gloo"
-            parts = [torch.empty(c * nyz * 576, dtype=torch.float64, device="cpu" if staged else self.dev) for c in counts]
+            parts = [torch.empty(c * nyz * KE, dtype=torch.float64, device="cpu" if staged else self.dev) for c in counts]
             dist.all_gather(parts, mine.cpu() if staged else mine, group=self.group)
             whole = torch.cat(parts).to(self.dev)
-        self._chk(self.lib.vfem_mg_import_level_ke(self.gmg, self.T, self._p(whole), self._s()))
+        self._chk(self._mg("import_level_ke")(self.gmg, self.T, self._p(whole), self._s()))
         torch.cuda.current_stream().synchronize()
 
     def update_operators(self):
-        self._chk(self.lib.vfem_mg_update_operators(self.lmg, self._s()))
-        if getattr(self, "_sharded", False):
-            if self.T < 2:
+        self._chk(self._mg("update_operators")(self.lmg, self._s()))
+        if getattr(self, "_sharded", False) or self.ALWAYS_ASSEMBLE:
+            if self.T < self.MIN_SHARDED_T:
                 raise RuntimeError("sharded densities need at least two distributed levels (the first replicated level must hold "
                                    "element matrices); use set_global_densities for this configuration")
             self._assemble_first_replicated_level()
-        self._chk(self.lib.vfem_mg_update_operators(self.gmg, self._s()))
+        self._chk(self._mg("update_operators")(self.gmg, self._s()))
 
     # ---- operators on distributed levels -----------------------------------------------------
     def halo(self, l, f):
         self.halos[l].exchange(f)
 
     def smooth(self, l, x, b, forward):
-        for first in (0, 4):
-            self._chk(self.lib.vfem_mg_smooth_colors(self.lmg, l, self._p(x), self._p(b), int(forward), first, 4, self._s()))
+        for first, count in self.COLOR_GROUPS:
+            self._chk(self._mg("smooth_colors")(self.lmg, l, self._p(x), self._p(b), int(forward), first, count, self._s()))
             self.halo(l, x)
 
     def residual(self, l, x, b, out):
-        self._chk(self.lib.vfem_mg_residual(self.lmg, l, self._p(x), self._p(b), self._p(out), self._s()))
+        self._chk(self._mg("residual")(self.lmg, l, self._p(x), self._p(b), self._p(out), self._s()))
         return out
 
     def apply_k(self, d_, out):
-        self._chk(self.lib.vfem_mg_apply_k(self.lmg, 0, self._p(d_), self._p(out), self._s()))
-        self._chk(self.lib.vfem_mg_zero_dirichlet(self.lmg, 0, self._p(out), self._s()))
+        self._chk(self._mg("apply_k")(self.lmg, 0, self._p(d_), self._p(out), self._s()))
+        self._chk(self._mg("zero_dirichlet")(self.lmg, 0, self._p(out), self._s()))
         return out
 
     def restrict(self, l, fine, coarse):
-        self._chk(self.lib.vfem_mg_restrict(self.lmg, l, self._p(fine), self._p(coarse), self._s()))
+        self._chk(self._mg("restrict")(self.lmg, l, self._p(fine), self._p(coarse), self._s()))
 
     def prolong(self, l, coarse, fine, accumulate):
-        self._chk(self.lib.vfem_mg_interpolate(self.lmg, l, self._p(coarse), self._p(fine), int(accumulate), self._s()))
+        self._chk(self._mg("interpolate")(self.lmg, l, self._p(coarse), self._p(fine), int(accumulate), self._s()))
 
     def dot(self, a, b):
         return float(self.halos[0].dot(a, b).item())
@@ -608,7 +625,7 @@ class DistributedMGSolver:
         bv[g.xoffn + lo:g.xoffn + hi] = self.b[self.T].view(g.n_planes, -1)[lo:hi]
         self._allreduce(self.bT)
         self.xT.zero_()
-        self._chk(self.lib.vfem_mg_cycle_from_level(self.gmg, self.T, self._p(self.xT), self._p(self.bT), self._nsmooth,
+        self._chk(self._mg("cycle_from_level")(self.gmg, self.T, self._p(self.xT), self._p(self.bT), self._nsmooth,
                                                    int(fmg), self._s()))
         self.x[self.T].view(g.n_planes, -1).copy_(self.xT.view(-1, g.plane * 3)[g.xoffn:g.xoffn + g.n_planes])
 
@@ -618,7 +635,7 @@ class DistributedMGSolver:
             self.coarse_cycle(False)
             return
         x, b, r = self.x[l], self.b[l], self.r[l]
-        self._chk(self.lib.vfem_mg_zero_dirichlet(self.lmg, l, self._p(x), self._s()))      # residual system
+        self._chk(self._mg("zero_dirichlet")(self.lmg, l, self._p(x), self._s()))      # residual system
         for _ in range(self._nsmooth):
             self.smooth(l, x, b, True)
         self.residual(l, x, b, r)
@@ -658,7 +675,7 @@ class DistributedMGSolver:
     # ---- PCG (MG.hh:679-732) -------------------------------------------------------------------
     def pcg(self, x, b, max_iter, tol, mg_iterations=1, nsmooth=1, fmg=False, callback=None):
         self._nsmooth = nsmooth
-        self._chk(self.lib.vfem_mg_zero_dirichlet(self.lmg, 0, self._p(x), self._s()))      # zero Dirichlet values only
+        self._chk(self._mg("zero_dirichlet")(self.lmg, 0, self._p(x), self._s()))      # zero Dirichlet values only
         self.update_operators()
         bb = self.dot(b, b)
         self.halo(0, x)
@@ -671,7 +688,7 @@ class DistributedMGSolver:
         while it < max_iter and rr > tol * tol * bb:
             it += 1
             s = self.precondition(r, mg_iterations, nsmooth, fmg) if nsmooth > 0 else r.clone()
-            self._chk(self.lib.vfem_mg_zero_dirichlet(self.lmg, 0, self._p(s), self._s()))
+            self._chk(self._mg("zero_dirichlet")(self.lmg, 0, self._p(s), self._s()))
             rMr_old, rMr = rMr, self.dot(r, s)
             if it == 1:
                 d.copy_(s)

@@ -1100,7 +1100,9 @@ class _GenericSimulator:
     N = 3
     P = 1
 
-    def __init__(self, domainBoundingBox, numElemg):
+    def __init__(self, domainBoundingBox, numElemg, _element_padding=(0, 0)):
+        """``_element_padding`` (slab decomposition, ndr_amd/distributed_q2.py): element layers kept below / above the node
+        grid along x in the density array only (``setElementDensities_padded``)"""
         _lib.require_gpu()
         self._lib = _lib.load()
         N, p = self.N, self.P
@@ -1113,9 +1115,11 @@ class _GenericSimulator:
         self._ne = np.array(ne, dtype=np.int64)
         self._nn = p * self._ne + 1
         h = ctypes.c_void_p()
-        _lib.check(self._lib.vfem_gsim_create(
+        self._pad = (int(_element_padding[0]), int(_element_padding[1]))
+        _lib.check(self._lib.vfem_gsim_create_padded(
             ctypes.byref(h), N, p, lo.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
-            hi.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), self._ne.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))))
+            hi.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), self._ne.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+            self._pad[0], self._pad[1]))
         self._h = h
         self._E0, self._Emin, self._gamma = 1.0, 1e-9, 3.0           # TPS.hh:1392-1394
         self._mask = np.zeros((self.numNodes(), N), dtype=bool)
@@ -1225,13 +1229,21 @@ class _GenericSimulator:
 
     # ---- densities ----
     def setElementDensities(self, rho):
+        if self._pad != (0, 0):
+            raise RuntimeError("this simulator stores padding element layers: use setElementDensities_padded")
         t = _to_dev(rho, (self.numElements(),))
+        _lib.check(self._lib.vfem_gsim_set_densities(self._h, _ptr(t), _stream()))
+
+    def setElementDensities_padded(self, rho):
+        """all stored element layers (padding below, the node grid's elements, padding above), x slowest"""
+        t = _to_dev(rho, (int(self._lib.vfem_gsim_num_stored_elements(self._h)),))
         _lib.check(self._lib.vfem_gsim_set_densities(self._h, _ptr(t), _stream()))
 
     def setUniformDensities(self, density):
         if density > 1.0 or density < 0:
             raise RuntimeError("Density value (%f) has to be in between 0 and 1" % density)
-        self.setElementDensities(torch.full((self.numElements(),), float(density), dtype=torch.float64, device=_dev()))
+        n = int(self._lib.vfem_gsim_num_stored_elements(self._h))
+        self.setElementDensities_padded(torch.full((n,), float(density), dtype=torch.float64, device=_dev()))
 
     def getDensities_device(self):
         t = torch.empty(self.numElements(), dtype=torch.float64, device=_dev())

@@ -1,0 +1,98 @@
+"""-m gpu: the slab-decomposed degree-2 multigrid PCG (ndr_amd/distributed_q2.py, BASELINE config 5) against the
+single-process solve of the same kernels.  Ranks share the one GPU of the test box (gloo rendezvous, planes staged through
+the host); the arithmetic per node is the same in both runs, so iteration counts are equal and fields agree to rounding."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, ne, levels, q, sharded):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from helpers import BC_CANTILEVER, MATERIAL, seeded_density
+    from ndr_amd import pyVoxelFEM as pv
+    from ndr_amd.distributed_q2 import DistributedMGSolverQ2
+    dom = ([0.0, 0.0, 0.0], [2.0, 1.0, 1.0])
+    rho = torch.from_numpy(seeded_density(ne, 88)).cuda()
+    ds = DistributedMGSolverQ2(ne, dom[0], dom[1], BC_CANTILEVER, MATERIAL, levels)
+    if sharded:       # owned layers only; ghost and padding layers come from the neighbours
+        ds.set_local_densities(rho.view(ne[0], -1)[ds.part.x0:ds.part.x1].reshape(-1).clone())
+    else:
+        ds.set_global_densities(rho)
+    f = ds.local_loads()
+    hist = []
+    u = ds.pcg(torch.zeros_like(f), f, 100, 1e-8, 1, 2, True, callback=lambda it, r: hist.append(r))
+    comp = 2.0 * ds.compliance(f, u)
+    # single-process reference with the same kernels
+    t = pv.TensorProductSimulator([2, 2, 2], dom, list(ne))
+    t.readMaterial(MATERIAL)
+    t.applyDisplacementsAndLoadsFromFile(BC_CANTILEVER)
+    t.E_min = 1e-4
+    t.setElementDensities(rho)
+    mg = t.multigridSolver(levels)
+    fg = t.buildLoadVector_device()
+    hist_s = []
+    ug = mg.preconditionedConjugateGradient_device(torch.zeros_like(fg), fg, 100, 1e-8, None, 1, 2, True,
+                                                   residual_cb=lambda it, r: hist_s.append(r))
+    cg = float((fg * ug).sum())
+    g = ds.geom[0]
+    mine = u.view(g.n_planes, -1)[g.first_owned:g.last_owned + 1]
+    want = ug.view(2 * ne[0] + 1, -1)[2 * ds.part.x0:2 * ds.part.x1 + 1]
+    err = float((mine - want).abs().max() / want.abs().max())
+    first, count = ds.owned_element_range()
+    gd = ds.compliance_gradient(u)
+    gs = t.complianceGradient_device(ug)[first:first + count]
+    gerr = float((gd - gs).abs().max() / gs.abs().max())
+    n = min(len(hist), len(hist_s))
+    herr = max(abs(a - b) / b for a, b in zip(hist[:n], hist_s[:n])) if n else 0.0
+    q.put((rank, ds.Ld, ds.last_iterations, mg.last_iterations, comp, cg, err, gerr, herr))
+    dist.destroy_process_group()
+
+
+def _run(world, ne, levels, sharded, port_base):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = port_base + (os.getpid() % 1000) + levels + 10 * world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ne, levels, q, sharded)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world,ne,levels,min_ld", [(1, (16, 8, 8), 2, 0), (2, (32, 8, 8), 3, 1), (2, (16, 8, 16), 2, 0),
+                                                    (3, (48, 8, 8), 3, 1), (4, (64, 8, 8), 3, 1)])
+def test_q2_distributed_pcg_matches_single_process(world, ne, levels, min_ld):
+    for rank, Ld, it_d, it_s, comp, cg, err, gerr, herr in _run(world, ne, levels, False, 28800):
+        assert Ld >= min_ld
+        assert it_d == it_s, (it_d, it_s)
+        assert herr < 1e-8, herr                         # the residual history, iteration by iteration
+        assert abs(comp - cg) < 1e-9 * abs(cg), (comp, cg)
+        assert err < 1e-7 and gerr < 1e-7, (err, gerr)
+
+
+@pytest.mark.parametrize("world,ne,levels", [(2, (32, 8, 8), 3), (4, (64, 8, 8), 3)])
+def test_q2_distributed_pcg_with_sharded_densities(world, ne, levels):
+    """no rank holds the whole density field: ghost / padding layers from the neighbours, the replicated hierarchy's first level
+    from an all-gather of the slabs' Galerkin matrices"""
+    for rank, Ld, it_d, it_s, comp, cg, err, gerr, herr in _run(world, ne, levels, True, 28600):
+        assert Ld >= 1
+        assert it_d == it_s, (it_d, it_s)
+        assert herr < 1e-8, herr
+        assert abs(comp - cg) < 1e-9 * abs(cg), (comp, cg)
+        assert err < 1e-7 and gerr < 1e-7, (err, gerr)
