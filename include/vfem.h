@@ -55,7 +55,10 @@ enum {
     VFEM_OPT_DMA_STRIP    = 9,   /* z-remainder strip tiles: 0 off, 1 on, 2 on with the main chunk length */
     VFEM_OPT_GS_PAIR      = 10,  /* level-0 Gauss-Seidel: fused z-colour pairs (1) or one launch per colour (0) */
     VFEM_OPT_L1_DIAG      = 12,  /* level-1 Gauss-Seidel: diagonal blocks precomputed per operator update (1) or inside every sweep (0) */
-    VFEM_OPT_GS_RESIDENT  = 13   /* level-0 Gauss-Seidel: K0 held in SGPRs (1, when K0 has the 36-value structure) or coefficient table (0) */
+    VFEM_OPT_GS_RESIDENT  = 13,  /* level-0 Gauss-Seidel: K0 held in SGPRs (1, when K0 has the 36-value structure) or coefficient table (0) */
+    VFEM_OPT_Q2_L1_VIRTUAL = 14  /* vfem_gsim: level 1 of a degree-2 hierarchy evaluated as sum_f E_f cK0[f] on the fly (1), from stored 81 x 81
+                                    element matrices (0), or chosen by their size (2, default: on the fly above 32 GB); read by the next
+                                    vfem_gmg_update_operators */
 };
 
 /* ---- raw device memory helpers (for callers without their own HIP allocator) ---- */
@@ -219,6 +222,9 @@ int vfem_gmg_create_partial(vfem_gmg **out, vfem_gsim *fine, int num_coarsening_
 int vfem_gmg_smooth_colors(vfem_gmg *mg, int level, double *u, const double *b, int forward, int first, int count, void *stream);
 int vfem_gmg_cycle_from_level(vfem_gmg *mg, int level, double *x, const double *b, int num_smoothing_steps, int fmg, void *stream);
 int vfem_gmg_export_level_ke(vfem_gmg *mg, int level, int64_t child_first_layer, int64_t count_x, double *ke_out, void *stream);
+/* import: into the first active level of a replicated hierarchy -- level `first_active_level` of vfem_gmg_create_partial, or
+ * level 0 of an ordinary hierarchy created on the coarse grid itself (its level 0 then applies the imported matrices instead of
+ * E_e K0; this is how the slab driver keeps every global object at the size of the first replicated level) */
 int vfem_gmg_import_level_ke(vfem_gmg *mg, int level, const double *ke, void *stream);
 int vfem_gmg_destroy(vfem_gmg *mg);
 int vfem_gmg_num_levels(const vfem_gmg *mg);

@@ -575,6 +575,7 @@ struct vfem_gsim {
     DevBuf<double> dK0, rho, E, dvals;
     DevBuf<double> q2tab;                          // degree-2 hexahedra: packed mode-space blocks (q2_modes.h)
     bool q2_fast = false;
+    int q2_l1_virtual = 2;                         // vfem_gsim_set_option(14, v): level 1 of a degree-2 hierarchy 0 stored, 1 virtual, 2 by size
     int q2_impl = 0;                               // vfem_gsim_set_option(6, v): 0 marching kernel (mode space), 1 dense gather kernel (cross-check), 2 pencil kernel
     DevBuf<uint8_t> dmask;
     std::vector<uint8_t> hmask;
@@ -610,6 +611,8 @@ struct vfem_gmg {
     bool slab = false;                 // local hierarchy of one rank: levels 0..L hold fields and transfers, L only serves the transfers
     int first_active = 0;              // replicated coarse hierarchy: levels below hold no fields or operators
     int external_ke_level = -1;        // element matrices of this level were imported (vfem_gmg_import_level_ke)
+    bool l1_virtual = false;           // degree 2: level 1 applies sum_f E_f cK0[f] on the fly, lv[1].Ke is not stored
+    DevBuf<double> ke_scratch;         // ... and its matrices exist a few layers at a time while level 2 is built from them
     std::vector<GLevel> lv;
     GWeights W;
     DevBuf<double> cK0, phi, Ainv, pr, pd, pAd, ps, scal, scratch;
@@ -729,17 +732,24 @@ static void g_apply(const GDims &d, const double *K, long long kstride, const do
     VFEM_HIP(hipGetLastError());
 }
 
+// level 0 normally applies E_e * K0; a hierarchy whose level-0 element matrices were imported (the replicated coarse part of a
+// slab decomposition, created on the grid of its first level) reads them like any coarser level
 static void level_op(const vfem_gmg *mg, int l, const double *&K, long long &kstride, const double *&scale) {
-    if (l == 0) { K = mg->fine->dK0.p; kstride = 0; scale = mg->fine->E_local(); }
+    if (l == 0 && mg->external_ke_level != 0) { K = mg->fine->dK0.p; kstride = 0; scale = mg->fine->E_local(); }
     else { K = mg->lv[l].Ke_local(); kstride = (long long) mg->lv[l].d.ke * mg->lv[l].d.ke; scale = nullptr; }
 }
 
 static void gmg_apply(vfem_gmg *mg, int l, const double *u, const double *b, int mode, double *out, hipStream_t s) {
     const vfem_gsim *sim = mg->fine;
-    if (l == 0 && sim->d.N == 3 && sim->d.p == 2 && sim->q2_fast && sim->q2_impl != 1) {       // finest degree-2 level: mode-space kernels
+    if (l == 0 && mg->external_ke_level != 0 && sim->d.N == 3 && sim->d.p == 2 && sim->q2_fast && sim->q2_impl != 1) {       // finest degree-2 level: mode-space kernels
         if (sim->q2_impl == 0) launch_apply_q2_march(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E_local(), u, out, s);
         else launch_apply_q2_pencil(sim->d.ne[0], sim->d.ne[1], sim->d.ne[2], sim->q2tab.p, sim->E_local(), u, out, s);
         if (mode != 0) launch_q2_residual_fix(sim->d.nnodes, b, mg->lv[0].mask.p, mode, out, s);
+        return;
+    }
+    if (l == 1 && mg->l1_virtual) {
+        const GDims &d = mg->lv[1].d;
+        launch_apply_q2_level1(d.ne[0], d.ne[1], d.ne[2], mg->cK0.p, sim->E.p, (int) (2 * mg->lv[1].pad_lo), u, b, mg->lv[1].mask.p, mode, out, s);
         return;
     }
     const double *K, *scale; long long ks;
@@ -752,8 +762,13 @@ static void gmg_apply(vfem_gmg *mg, int l, const double *u, const double *b, int
 static void gmg_smooth(vfem_gmg *mg, int l, double *u, const double *b, int forward, hipStream_t s, int first = 0, int count = -1) {
     const GDims &d = mg->lv[l].d;
     if (count < 0) count = 27;
-    if (l == 0 && d.N == 3 && d.p == 2 && mg->fine->q2_impl != 1) {                                  // finest degree-2 level: thread per node
+    if (l == 0 && mg->external_ke_level != 0 && d.N == 3 && d.p == 2 && mg->fine->q2_impl != 1) {  // finest degree-2 level: thread per node
         launch_gs_sweep_q2_level0(d.ne[0], d.ne[1], d.ne[2], mg->fine->dK0.p, mg->fine->E_local(), u, b, mg->lv[0].mask.p, forward, s, first, count);
+        return;
+    }
+    if (l == 1 && mg->l1_virtual) {
+        launch_gs_sweep_q2_level1(d.ne[0], d.ne[1], d.ne[2], mg->cK0.p, mg->fine->E.p, (int) (2 * mg->lv[1].pad_lo), u, b, mg->lv[1].mask.p, forward, s,
+                                  first, count);
         return;
     }
     const double *K, *scale; long long ks;
@@ -847,6 +862,25 @@ static GDims stored_dims(const vfem_gmg *mg, int l) {
     return make_gdims(lv.d.N, lv.d.p, ne);
 }
 
+// Element matrices of `count` x-layers of level 2, starting at stored layer `first2`, when level 1 is virtual: the level-1
+// matrices of two level-2 layers' worth of children are formed in a scratch buffer, coarsened, and overwritten by the next chunk
+static void coarsen_through_virtual_level1(vfem_gmg *mg, long long first2, long long count, double *out, hipStream_t s) {
+    const GDims d0 = stored_dims(mg, 0), d1 = stored_dims(mg, 1), d2 = stored_dims(mg, 2);
+    const size_t kk = (size_t) d1.ke * d1.ke;
+    const long long layer0 = (long long) d0.ne[1] * d0.ne[2], layer1 = (long long) d1.ne[1] * d1.ne[2], layer2 = (long long) d2.ne[1] * d2.ne[2];
+    long long chunk = (long long) ((size_t) 1 << 31) / (long long) (2 * layer1 * kk * sizeof(double));      // ~2 GB of level-1 matrices
+    if (chunk < 1) chunk = 1;
+    if (chunk > count) chunk = count;
+    mg->ke_scratch.alloc((size_t) (2 * chunk * layer1) * kk);
+    for (long long c0 = 0; c0 < count; c0 += chunk) {
+        const long long n2 = std::min(chunk, count - c0);
+        const long long ne2[3] = {n2, d2.ne[1], d2.ne[2]}, ne1[3] = {2 * n2, d1.ne[1], d1.ne[2]}, ne0[3] = {4 * n2, d0.ne[1], d0.ne[2]};
+        const GDims c2 = make_gdims(3, 2, ne2), c1 = make_gdims(3, 2, ne1), c0d = make_gdims(3, 2, ne0);
+        g_coarsen(mg, c0d, c1, true, mg->fine->E.p + (size_t) (4 * (first2 + c0)) * layer0, mg->ke_scratch.p, s);
+        g_coarsen(mg, c1, c2, false, mg->ke_scratch.p, out + (size_t) (c0 * layer2) * kk, s);
+    }
+}
+
 static void gmg_update(vfem_gmg *mg, hipStream_t s) {
     vfem_gsim *sim = mg->fine;
     const int N = sim->d.N;
@@ -854,13 +888,23 @@ static void gmg_update(vfem_gmg *mg, hipStream_t s) {
         throw Error("the element matrices of the first active level have not been imported (vfem_gmg_import_level_ke)");
     const int l_first = mg->first_active > 0 ? mg->first_active + 1 : 1;
     const int l_last = mg->slab ? mg->L - 1 : mg->L;             // a slab hierarchy's last level only serves the transfers
+    // level 1 stays virtual when it is an operator level that is not the coarsest one and level 0 applies E K0
+    // (measured, tools/q2_level1_probe.py: stored matrices are faster while they are small -- 9.3 against 7.8 CG-MG iterations/s at
+    // 128^3, 14 GB -- and slower, besides not fitting, when they are large -- 1.54 against 1.61 at 256^3, 110 GB)
+    mg->l1_virtual = N == 3 && sim->d.p == 2 && mg->first_active == 0 && mg->external_ke_level != 0 && mg->L >= 2 &&
+                     (sim->q2_l1_virtual == 1 ||
+                      (sim->q2_l1_virtual == 2 && (double) stored_dims(mg, 1).nelems * 81 * 81 * sizeof(double) > 32e9));
+    if (mg->l1_virtual) mg->lv[1].Ke.release();
     for (int l = l_first; l <= l_last; ++l) {
         GLevel &lv = mg->lv[l];
         const size_t kk = (size_t) lv.d.ke * lv.d.ke;
         const GDims cd = stored_dims(mg, l), fd = stored_dims(mg, l - 1);
         if (fd.ne[0] != 2 * cd.ne[0]) throw Error("stored element layers of consecutive levels must halve exactly");
+        if (mg->l1_virtual && l == 1) continue;
         lv.Ke.alloc((size_t) cd.nelems * kk);
-        g_coarsen(mg, fd, cd, l == 1, l == 1 ? sim->E.p : mg->lv[l - 1].Ke.p, lv.Ke.p, s);
+        if (mg->l1_virtual && l == 2) { coarsen_through_virtual_level1(mg, 0, cd.ne[0], lv.Ke.p, s); continue; }
+        const bool from_moduli = l == 1 && mg->external_ke_level != 0;
+        g_coarsen(mg, fd, cd, from_moduli, from_moduli ? sim->E.p : mg->lv[l - 1].Ke.p, lv.Ke.p, s);
     }
     if (mg->slab) { mg->operators_valid = true; return; }
     // coarsest level: assemble the dense matrix on the host (a few elements), invert with rocSOLVER
@@ -877,7 +921,7 @@ static void gmg_update(vfem_gmg *mg, hipStream_t s) {
     }
     const size_t kk = (size_t) d.ke * d.ke;
     std::vector<double> Ke((size_t) d.nelems * kk);
-    if (mg->L == 0) {
+    if (mg->L == 0 && mg->external_ke_level != 0) {
         std::vector<double> E((size_t) d.nelems);
         VFEM_HIP(hipMemcpyAsync(E.data(), sim->E_local(), E.size() * sizeof(double), hipMemcpyDeviceToHost, s));
         VFEM_HIP(hipStreamSynchronize(s));
@@ -1073,6 +1117,7 @@ int vfem_gsim_get_densities(const vfem_gsim *sim, double *rho, void *stream) {
 int vfem_gsim_set_option(vfem_gsim *sim, int key, int value) {
     G_TRY
     if (key == 6 && value >= 0 && value <= 2) sim->q2_impl = value;
+    else if (key == 14 && value >= 0 && value <= 2) sim->q2_l1_virtual = value;
     else throw Error("unknown option or value out of range");
     G_CATCH
 }
@@ -1259,7 +1304,7 @@ int vfem_gmg_set_symmetric_gauss_seidel(vfem_gmg *mg, int symmetric) { mg->symme
 int vfem_gmg_update_operators(vfem_gmg *mg, void *stream) { G_TRY gmg_update(mg, GS(stream)); G_CATCH }
 static void g_check_level(const vfem_gmg *mg, int level, bool need_ops) {
     if (level < 0 || level > mg->L) throw Error("level out of range");
-    if (need_ops && level > 0 && !mg->operators_valid) throw Error("coarse operators not built: call updateElementStiffnessMatrices first");
+    if (need_ops && (level > 0 || mg->external_ke_level == 0) && !mg->operators_valid) throw Error("coarse operators not built: call updateElementStiffnessMatrices first");
 }
 int vfem_gmg_apply_k(vfem_gmg *mg, int level, const double *u, double *out, void *stream) {
     G_TRY g_check_level(mg, level, true); gmg_apply(mg, level, u, nullptr, 0, out, GS(stream)); G_CATCH
@@ -1310,6 +1355,11 @@ int vfem_gmg_export_level_ke(vfem_gmg *mg, int level, int64_t child_first_layer,
     const GLevel &lv = mg->lv[level];
     const long long cne[3] = {count_x, lv.d.ne[1], lv.d.ne[2]}, fne[3] = {2 * count_x, fs.ne[1], fs.ne[2]};
     const GDims c = make_gdims(3, lv.d.p, cne), f = make_gdims(3, lv.d.p, fne);
+    if (level == 2 && mg->l1_virtual) {
+        if (child_first_layer % 2) throw Error("child layers must start at an even stored layer");
+        coarsen_through_virtual_level1(mg, child_first_layer / 2, count_x, ke_out, GS(stream));
+        return 0;
+    }
     const size_t child_stride = level == 1 ? 1 : (size_t) lv.d.ke * lv.d.ke;
     const double *src = (level == 1 ? mg->fine->E.p : mg->lv[level - 1].Ke.p) + (size_t) child_first_layer * fs.ne[1] * fs.ne[2] * child_stride;
     g_coarsen(mg, f, c, level == 1, src, ke_out, GS(stream));
@@ -1318,7 +1368,8 @@ int vfem_gmg_export_level_ke(vfem_gmg *mg, int level, int64_t child_first_layer,
 int vfem_gmg_import_level_ke(vfem_gmg *mg, int level, const double *ke, void *stream) {
     G_TRY
     g_check_level(mg, level, false);
-    if (level < 1 || mg->slab) throw Error("element matrices can be imported into levels >= 1 of a replicated hierarchy");
+    if (mg->slab) throw Error("element matrices are imported into replicated hierarchies only");
+    if (level != mg->first_active) throw Error("element matrices are imported into the first active level (level 0 of a hierarchy created on the coarse grid itself)");
     GLevel &lv = mg->lv[level];
     const size_t n = (size_t) lv.d.nelems * lv.d.ke * lv.d.ke;
     lv.Ke.alloc(n);

@@ -700,6 +700,152 @@ void launch_gs_sweep_q2_level0(int nx, int ny, int nz, const double *K0, const d
     VFEM_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Level 1 of the degree-2 hierarchy without stored element matrices.  The Galerkin matrix of a level-1 element is
+// Ke = sum_f E_f cK0[f] over its eight children (buildPESCoarse, MG.hh:604-669, with cK0[f] = I_f^T K0 I_f constant); stored it
+// is 81 x 81 doubles = 52 KB per element -- 110 GB at 256^3 fine elements, read once per sweep.  Here a thread owns a node as
+// on level 0 and evaluates   S = sum_e sum_f E_f (cK0[f] u_e)[rows of the node]   directly: the rows of cK0[f] are the same
+// for every node of a launch (one colour, or one parity class of the apply), so they arrive by scalar loads; per incident
+// element a lane reads the element's 27 node values once and keeps 8 x 3 partial sums, one per child.  1944 multiply-adds
+// per incident element instead of 243 loaded matrix entries.
+// MODE 0: relax the nodes of the colour (MG.hh:254-264); 1: out = K u; 2: out = zeroDirichlet(b - K u); 3: out = zeroDirichlet(K u)
+// ------------------------------------------------------------------------------------------------------
+struct Q2L1 {
+    DimsQ2 d;                 // the level-1 grid
+    Q2Color col;              // nodes visited: start / stride / count per axis
+    const double *cK0;        // [8][81][81], child index bit a = upper half along axis a (bit 0: x)
+    const double *Ef;         // moduli of the level-0 elements, stored array (x slowest)
+    int fny, fnz;             // level-0 elements per y / z
+    int fx0;                  // stored level-0 layer of the first child of local level-1 layer 0
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_q2_level1(Q2L1 a, double *__restrict__ u, const double *__restrict__ b,
+                                                   const uint8_t *__restrict__ mask, int forward, double *__restrict__ out) {
+    const DimsQ2 &d = a.d;
+    const int c = blockIdx.x * 64 + threadIdx.x, bq = blockIdx.y * 4 + threadIdx.y, ai = blockIdx.z;
+    if (c >= a.col.cnt[2] || bq >= a.col.cnt[1] || ai >= a.col.cnt[0]) return;
+    const int i = a.col.start[0] + ai * a.col.inc[0], j = a.col.start[1] + bq * a.col.inc[1], k = a.col.start[2] + c * a.col.inc[2];
+    // parity of the launch's nodes per axis (uniform): odd = mid node of one element, even = on an element boundary
+    const int px = a.col.start[0] & 1, py = a.col.start[1] & 1, pz = a.col.start[2] & 1;
+    const int nex = px ? 1 : 2, ney = py ? 1 : 2, nez = pz ? 1 : 2;
+    double S[3] = {0.0, 0.0, 0.0}, M[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) M[q] = 0.0;
+    for (int sx = 0; sx < nex; ++sx) {
+        const int ex = px ? i / 2 : i / 2 - 1 + sx, lx = px ? 1 : (sx ? 0 : 2);
+        for (int sy = 0; sy < ney; ++sy) {
+            const int ey = py ? j / 2 : j / 2 - 1 + sy, ly = py ? 1 : (sy ? 0 : 2);
+            for (int sz = 0; sz < nez; ++sz) {
+                const int ez = pz ? k / 2 : k / 2 - 1 + sz, lz = pz ? 1 : (sz ? 0 : 2);
+                if (ex < 0 || ex >= d.nx || ey < 0 || ey >= d.ny || ez < 0 || ez >= d.nz) continue;
+                const int ln = 9 * lx + 3 * ly + lz;                                      // uniform over the launch
+                double E8[8];
+#pragma unroll
+                for (int f = 0; f < 8; ++f)
+                    E8[f] = a.Ef[((long long) (a.fx0 + 2 * ex + (f & 1)) * a.fny + (2 * ey + ((f >> 1) & 1))) * a.fnz + 2 * ez + ((f >> 2) & 1)];
+                double t[8][3];
+#pragma unroll
+                for (int f = 0; f < 8; ++f) t[f][0] = t[f][1] = t[f][2] = 0.0;
+                const double *rows = a.cK0 + (size_t) (3 * ln) * 81;
+#pragma unroll
+                for (int ma = 0; ma < 3; ++ma)
+#pragma unroll
+                    for (int mb = 0; mb < 3; ++mb) {
+                        const long long rowbase = ((long long) (2 * ex + ma) * d.NY + (2 * ey + mb)) * d.NZ + 2 * ez;
+#pragma unroll
+                        for (int mc = 0; mc < 3; ++mc) {
+                            const int m = 9 * ma + 3 * mb + mc;
+                            const double *um = u + 3 * (rowbase + mc);
+                            const double u0 = um[0], u1 = um[1], u2 = um[2];
+#pragma unroll
+                            for (int f = 0; f < 8; ++f) {
+                                const double *r0 = rows + (size_t) f * 6561 + 3 * m;
+#pragma unroll
+                                for (int r = 0; r < 3; ++r)
+                                    t[f][r] = fma(r0[81 * r], u0, fma(r0[81 * r + 1], u1, fma(r0[81 * r + 2], u2, t[f][r])));
+                            }
+                        }
+                    }
+#pragma unroll
+                for (int f = 0; f < 8; ++f) {
+                    const double *dg = rows + (size_t) f * 6561 + 3 * ln;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        S[r] = fma(E8[f], t[f][r], S[r]);
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc) M[3 * r + cc] = fma(E8[f], dg[81 * r + cc], M[3 * r + cc]);
+                    }
+                }
+            }
+        }
+    }
+    const long long n = ((long long) i * d.NY + j) * d.NZ + k;
+    if (MODE == 0) {
+        double bms[3], ud[3];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) bms[cc] = b[3 * n + cc] - S[cc];
+        gs_solve(bms, M, mask ? mask[n] : (uint8_t) 0, forward != 0, ud);
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) u[3 * n + cc] += ud[cc];
+    } else {
+        const uint8_t mk = (MODE >= 2 && mask) ? mask[n] : (uint8_t) 0;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            double v = MODE == 2 ? b[3 * n + cc] - S[cc] : S[cc];
+            if ((mk >> cc) & 1) v = 0.0;
+            out[3 * n + cc] = v;
+        }
+    }
+}
+
+static Q2L1 q2l1_args(int nx, int ny, int nz, const double *cK0, const double *Ef, int fx0) {
+    Q2L1 a{};
+    a.d = DimsQ2{nx, ny, nz, 2 * nx + 1, 2 * ny + 1, 2 * nz + 1};
+    a.cK0 = cK0; a.Ef = Ef; a.fny = 2 * ny; a.fnz = 2 * nz; a.fx0 = fx0;
+    return a;
+}
+// colours [first, first + count) of the sweep in visiting order (as launch_gs_sweep_q2_level0)
+void launch_gs_sweep_q2_level1(int nx, int ny, int nz, const double *cK0, const double *Ef, int fx0, double *u, const double *b,
+                               const uint8_t *mask, int forward, hipStream_t s, int first, int count) {
+    Q2L1 a = q2l1_args(nx, ny, nz, cK0, Ef, fx0);
+    const int NN[3] = {a.d.NX, a.d.NY, a.d.NZ};
+    for (int ci = first; ci < (first + count < 27 ? first + count : 27); ++ci) {
+        const int lni = forward ? ci : 26 - ci;                      // MG.hh:293-295
+        const int l[3] = {lni / 9, (lni / 3) % 3, lni % 3};
+        bool empty = false;
+        for (int ax = 0; ax < 3; ++ax) {
+            a.col.start[ax] = l[ax];
+            a.col.inc[ax] = (l[ax] == 1) ? 2 : 4;                    // MG.hh:301-305
+            a.col.cnt[ax] = l[ax] > NN[ax] - 1 ? 0 : (NN[ax] - 1 - l[ax]) / a.col.inc[ax] + 1;
+            empty = empty || a.col.cnt[ax] == 0;
+        }
+        if (empty) continue;
+        const dim3 grd((a.col.cnt[2] + 63) / 64, (a.col.cnt[1] + 3) / 4, a.col.cnt[0]), blk(64, 4, 1);
+        k_q2_level1<0><<<grd, blk, 0, s>>>(a, u, b, mask, forward, nullptr);
+    }
+    VFEM_HIP(hipGetLastError());
+}
+// mode 0: out = K u; 1: out = zeroDirichlet(b - K u); 2: out = zeroDirichlet(K u) -- one launch per node-parity class
+void launch_apply_q2_level1(int nx, int ny, int nz, const double *cK0, const double *Ef, int fx0, const double *u, const double *b,
+                            const uint8_t *mask, int mode, double *out, hipStream_t s) {
+    Q2L1 a = q2l1_args(nx, ny, nz, cK0, Ef, fx0);
+    const int NN[3] = {a.d.NX, a.d.NY, a.d.NZ};
+    for (int pc = 0; pc < 8; ++pc) {
+        const int par[3] = {(pc >> 2) & 1, (pc >> 1) & 1, pc & 1};
+        for (int ax = 0; ax < 3; ++ax) {
+            a.col.start[ax] = par[ax]; a.col.inc[ax] = 2;
+            a.col.cnt[ax] = (NN[ax] - 1 - par[ax]) / 2 + 1;
+        }
+        const dim3 grd((a.col.cnt[2] + 63) / 64, (a.col.cnt[1] + 3) / 4, a.col.cnt[0]), blk(64, 4, 1);
+        double *uu = const_cast<double *>(u);
+        if (mode == 0) k_q2_level1<1><<<grd, blk, 0, s>>>(a, uu, b, mask, 1, out);
+        else if (mode == 1) k_q2_level1<2><<<grd, blk, 0, s>>>(a, uu, b, mask, 1, out);
+        else k_q2_level1<3><<<grd, blk, 0, s>>>(a, uu, b, mask, 1, out);
+    }
+    VFEM_HIP(hipGetLastError());
+}
+
 // r = zeroDirichlet(b - Ku) (mode 1) or zeroDirichlet(Ku) (mode 2) in place on Ku
 __global__ void __launch_bounds__(256) k_q2_residual_fix(long long nn, const double *__restrict__ b, const uint8_t *__restrict__ mask, int mode,
                                                          double *__restrict__ out) {

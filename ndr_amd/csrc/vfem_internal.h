@@ -158,6 +158,10 @@ void launch_apply_q2_pencil(int nx, int ny, int nz, const double *mode_table, co
 void launch_apply_q2_march(int nx, int ny, int nz, const double *mode_table, const double *E, const double *u, double *out, hipStream_t s);
 void launch_gs_sweep_q2_level0(int nx, int ny, int nz, const double *K0, const double *E, double *u, const double *b,
                                const uint8_t *mask, int forward, hipStream_t s, int first = 0, int count = 27);
+void launch_gs_sweep_q2_level1(int nx, int ny, int nz, const double *cK0, const double *Ef, int fx0, double *u, const double *b,
+                               const uint8_t *mask, int forward, hipStream_t s, int first = 0, int count = 27);
+void launch_apply_q2_level1(int nx, int ny, int nz, const double *cK0, const double *Ef, int fx0, const double *u, const double *b,
+                            const uint8_t *mask, int mode, double *out, hipStream_t s);
 void launch_q2_residual_fix(long long nn, const double *b, const uint8_t *mask, int mode, double *out, hipStream_t s);
 void launch_gradient_q2(int nx, int ny, int nz, const double *K0, const double *rho, double E0, double Emin, double gamma,
                         const double *u, double *g, hipStream_t s);

@@ -301,6 +301,22 @@ def bench_mlp(side=(512, 256, 256), es=1024, nn_=512, nl=4, sigma=4.0, reps=3):
             "voxels_per_s": nv / sec, "tflops": flop / sec / 1e12, "checksum": float(chk.item())}
 
 
+def _bench_q2(world):
+    """degree-2 CG-MG over the ranks (config 5's path): 256^3 elements = 135 M nodes from 2 ranks on (its level-1 element
+    matrices alone are 110 GB, divided over the ranks), 512^3 = 1.08 G nodes on 8"""
+    from .distributed_q2 import bench_pcg_q2
+    out = []
+    for q2ne, levels, need in (((256, 256, 256), 6, 2), ((512, 512, 512), 7, 8)):
+        if world < need:
+            continue
+        try:
+            torch.cuda.empty_cache()
+            out.append(bench_pcg_q2(q2ne, levels))
+        except RuntimeError as e:              # reported, never hidden
+            out.append({"grid": "%dx%dx%d" % q2ne, "degree": 2, "error": str(e)})
+    return out
+
+
 def bench_apply(ne, steps, warmup, with_cg=True):
     """bench.py's N > 1 leg: K steps of {halo exchange + local apply}, max over ranks, whole-grid GVoxel/s."""
     init_process_group_from_env()
@@ -356,6 +372,7 @@ def bench_apply(ne, steps, warmup, with_cg=True):
         "checksum_KuKu": float(chk.item()),
         "cg_mg": cg,
         "mlp_forward": bench_mlp() if with_cg else None,
+        "degree2_cg_mg": _bench_q2(world) if with_cg else None,
     }
 
 
@@ -488,6 +505,10 @@ class DistributedMGSolver:
     def _mg(self, name):
         return getattr(self.lib, self._MG_PREFIX + name)
 
+    def _replicated_level(self):
+        """index of level T in the replicated hierarchy's own numbering (degree 1: that hierarchy spans all levels)"""
+        return self.T
+
     def _export_child_level(self):
         """level whose stored layers the first replicated level's matrices are built from (degree 1: level 1 is virtual, so
         level 2 is built from the moduli)"""
@@ -574,10 +595,15 @@ class DistributedMGSolver:
         else:
             counts = [(self.part.starts[r + 1] - self.part.starts[r]) >> self.T for r in range(self.world)]
             staged = dist.get_backend(self.group) == "gloo"
-            parts = [torch.empty(c * nyz * KE, dtype=torch.float64, device="cpu" if staged else self.dev) for c in counts]
-            dist.all_gather(parts, mine.cpu() if staged else mine, group=self.group)
-            whole = torch.cat(parts).to(self.dev)
-        self._chk(self._mg("import_level_ke")(self.gmg, self.T, self._p(whole), self._s()))
+            where = "cpu" if staged else self.dev
+            # equal-size buffers (slabs may differ by one aligned block; RCCL's all-gather wants one size)
+            most = max(counts) * nyz * KE
+            send = torch.zeros(most, dtype=torch.float64, device=where)
+            send[:mine.numel()].copy_(mine)
+            parts = [torch.empty(most, dtype=torch.float64, device=where) for _ in counts]
+            dist.all_gather(parts, send, group=self.group)
+            whole = torch.cat([b[:c * nyz * KE] for b, c in zip(parts, counts)]).to(self.dev)
+        self._chk(self._mg("import_level_ke")(self.gmg, self._replicated_level(), self._p(whole), self._s()))
         torch.cuda.current_stream().synchronize()
 
     def update_operators(self):
@@ -625,7 +651,7 @@ class DistributedMGSolver:
         bv[g.xoffn + lo:g.xoffn + hi] = self.b[self.T].view(g.n_planes, -1)[lo:hi]
         self._allreduce(self.bT)
         self.xT.zero_()
-        self._chk(self._mg("cycle_from_level")(self.gmg, self.T, self._p(self.xT), self._p(self.bT), self._nsmooth,
+        self._chk(self._mg("cycle_from_level")(self.gmg, self._replicated_level(), self._p(self.xT), self._p(self.bT), self._nsmooth,
                                                    int(fmg), self._s()))
         self.x[self.T].view(g.n_planes, -1).copy_(self.xT.view(-1, g.plane * 3)[g.xoffn:g.xoffn + g.n_planes])
 

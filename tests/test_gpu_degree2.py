@@ -81,3 +81,41 @@ def test_unknown_degrees_are_refused():
     from ndr_amd import pyVoxelFEM as pv
     with pytest.raises(RuntimeError):
         pv.TensorProductSimulator([3, 3, 3], ([0, 0, 0], [1, 1, 1]), (2, 2, 2))
+
+
+@pytest.mark.parametrize("ne,levels", [((8, 8, 8), 2), ((16, 12, 8), 2), ((16, 16, 16), 3)])
+def test_q2_level1_on_the_fly_equals_stored_element_matrices(ne, levels):
+    """VFEM_OPT_Q2_L1_VIRTUAL: level 1 evaluated as sum_f E_f cK0[f] per node (k_q2_level1) against the stored 81 x 81 Galerkin
+    matrices (MG.hh:604-669): the same operator, sweep, residual, level-2 matrices (built through the scratch buffer) and
+    therefore the same PCG run"""
+    import torch
+    from helpers import BC_CANTILEVER
+    from ndr_amd import _lib, pyVoxelFEM as pv
+    lib = _lib.load()
+    t = pv.TensorProductSimulator([2, 2, 2], ([0, 0, 0], [2, 1, 1]), list(ne))
+    t.readMaterial(MATERIAL)
+    t.applyDisplacementsAndLoadsFromFile(BC_CANTILEVER)
+    t.E_min = 1e-4
+    g = torch.Generator(device="cuda").manual_seed(4)
+    t.setElementDensities(torch.rand(t.numElements(), dtype=torch.float64, device="cuda", generator=g))
+    mg = t.multigridSolver(levels)
+    n1 = mg._nn(1)
+    u = torch.randn((n1, 3), dtype=torch.float64, device="cuda", generator=g)
+    b = torch.randn((n1, 3), dtype=torch.float64, device="cuda", generator=g)
+    f = t.buildLoadVector_device()
+    got = {}
+    for mode in (0, 1):
+        _lib.check(lib.vfem_gsim_set_option(t._h, 14, mode))
+        mg.updateElementStiffnessMatrices()
+        hist = []
+        x = mg.preconditionedConjugateGradient_device(torch.zeros_like(f), f, 50, 1e-9, None, 1, 2, True,
+                                                      residual_cb=lambda it, r: hist.append(r))
+        got[mode] = (mg.applyK_device(1, u), mg.computeResidual_device(1, u, b), mg.smoothing_device(1, u, b, True),
+                     mg.smoothing_device(1, u, b, False), mg.applyK_device(2, mg.restriction_device(1, u)) if levels >= 2 else u,
+                     x, hist)
+    for a, c in zip(got[0][:6], got[1][:6]):
+        assert float((a - c).abs().max()) < 1e-12 * float(a.abs().max())
+    assert len(got[0][6]) == len(got[1][6])
+    assert max(abs(p - q) / p for p, q in zip(got[0][6], got[1][6])) < 1e-8
+    with pytest.raises(RuntimeError):
+        _lib.check(lib.vfem_gsim_set_option(t._h, 14, 3))

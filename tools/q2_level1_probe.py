@@ -1,0 +1,73 @@
+"""Level 1 of the degree-2 hierarchy: virtual (sum_f E_f cK0[f] on the fly) against stored 81 x 81 element matrices.
+Times one Gauss-Seidel sweep and one residual on level 1, checks that both forms give the same fields, and times the
+operator update and a whole CG-MG solve in both modes.   python tools/q2_level1_probe.py N LEVELS"""
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from helpers import BC_CANTILEVER, MATERIAL  # noqa: E402
+from ndr_amd import _lib, pyVoxelFEM as pv  # noqa: E402
+
+n, levels = int(sys.argv[1]), int(sys.argv[2])
+lib = _lib.load()
+t = pv.TensorProductSimulator([2, 2, 2], ([0, 0, 0], [2, 1, 1]), [n, n, n])
+t.readMaterial(MATERIAL)
+t.applyDisplacementsAndLoadsFromFile(BC_CANTILEVER)
+t.E_min = 1e-4
+g = torch.Generator(device="cuda").manual_seed(88)
+t.setElementDensities(torch.rand(t.numElements(), dtype=torch.float64, device="cuda", generator=g))
+mg = t.multigridSolver(levels)
+nn1 = mg._nn(1)
+u0 = torch.randn((nn1, 3), dtype=torch.float64, device="cuda", generator=g)
+b = torch.randn((nn1, 3), dtype=torch.float64, device="cuda", generator=g)
+out = {"grid": n, "levels": levels, "level1_nodes": nn1}
+fields = {}
+for mode in (0, 1):
+    _lib.check(lib.vfem_gsim_set_option(t._h, 14, mode))
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    t0 = time.perf_counter()
+    mg.updateElementStiffnessMatrices()
+    torch.cuda.synchronize()
+    upd = time.perf_counter() - t0
+    used = (free0 - torch.cuda.mem_get_info()[0]) / 1e9
+    u = u0.clone()
+    s = pv._stream()
+    for _ in range(2):
+        _lib.check(lib.vfem_gmg_smooth(mg._h, 1, pv._ptr(u), pv._ptr(b), 1, s))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        _lib.check(lib.vfem_gmg_smooth(mg._h, 1, pv._ptr(u), pv._ptr(b), 1, s))
+    torch.cuda.synchronize()
+    sweep = (time.perf_counter() - t0) / 3
+    r = torch.empty_like(u)
+    _lib.check(lib.vfem_gmg_residual(mg._h, 1, pv._ptr(u), pv._ptr(b), pv._ptr(r), s))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        _lib.check(lib.vfem_gmg_residual(mg._h, 1, pv._ptr(u), pv._ptr(b), pv._ptr(r), s))
+    torch.cuda.synchronize()
+    res = (time.perf_counter() - t0) / 3
+    fields[mode] = (u.clone(), r.clone())
+    f = t.buildLoadVector_device()
+    mg.preconditionedConjugateGradient_device(torch.zeros_like(f), f, 1, 1e-4, None, 1, 2, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x = mg.preconditionedConjugateGradient_device(torch.zeros_like(f), f, 100, 1e-4, None, 1, 2, True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["virtual" if mode else "stored"] = {"operator_update_s": upd, "device_GB_taken_by_update": used, "sweep_ms": sweep * 1e3,
+                                            "residual_ms": res * 1e3, "pcg_iterations": mg.last_iterations, "pcg_s": dt,
+                                            "iterations_per_s": mg.last_iterations / dt, "compliance": float((f * x).sum())}
+    print(json.dumps(out), flush=True)
+du = float((fields[0][0] - fields[1][0]).abs().max() / fields[0][0].abs().max())
+dr = float((fields[0][1] - fields[1][1]).abs().max() / fields[0][1].abs().max())
+out["max_rel_diff_after_5_sweeps"], out["max_rel_diff_residual"] = du, dr
+print(json.dumps(out), flush=True)
