@@ -616,6 +616,7 @@ struct vfem_gmg {
     std::vector<GLevel> lv;
     GWeights W;
     DevBuf<double> cK0, phi, Ainv, pr, pd, pAd, ps, scal, scratch;
+    DevBuf<double> l1tab;              // degree-2 hexahedra: cK0 regrouped for k_q2_level1, [ln][m][f][r][c]
     DevBuf<int> info;
     void *rocblas = nullptr;
 };
@@ -749,7 +750,7 @@ static void gmg_apply(vfem_gmg *mg, int l, const double *u, const double *b, int
     }
     if (l == 1 && mg->l1_virtual) {
         const GDims &d = mg->lv[1].d;
-        launch_apply_q2_level1(d.ne[0], d.ne[1], d.ne[2], mg->cK0.p, sim->E.p, (int) (2 * mg->lv[1].pad_lo), u, b, mg->lv[1].mask.p, mode, out, s);
+        launch_apply_q2_level1(d.ne[0], d.ne[1], d.ne[2], mg->l1tab.p, sim->E.p, (int) (2 * mg->lv[1].pad_lo), u, b, mg->lv[1].mask.p, mode, out, s);
         return;
     }
     const double *K, *scale; long long ks;
@@ -767,7 +768,7 @@ static void gmg_smooth(vfem_gmg *mg, int l, double *u, const double *b, int forw
         return;
     }
     if (l == 1 && mg->l1_virtual) {
-        launch_gs_sweep_q2_level1(d.ne[0], d.ne[1], d.ne[2], mg->cK0.p, mg->fine->E.p, (int) (2 * mg->lv[1].pad_lo), u, b, mg->lv[1].mask.p, forward, s,
+        launch_gs_sweep_q2_level1(d.ne[0], d.ne[1], d.ne[2], mg->l1tab.p, mg->fine->E.p, (int) (2 * mg->lv[1].pad_lo), u, b, mg->lv[1].mask.p, forward, s,
                                   first, count);
         return;
     }
@@ -889,11 +890,12 @@ static void gmg_update(vfem_gmg *mg, hipStream_t s) {
     const int l_first = mg->first_active > 0 ? mg->first_active + 1 : 1;
     const int l_last = mg->slab ? mg->L - 1 : mg->L;             // a slab hierarchy's last level only serves the transfers
     // level 1 stays virtual when it is an operator level that is not the coarsest one and level 0 applies E K0
-    // (measured, tools/q2_level1_probe.py: stored matrices are faster while they are small -- 9.3 against 7.8 CG-MG iterations/s at
-    // 128^3, 14 GB -- and slower, besides not fitting, when they are large -- 1.54 against 1.61 at 256^3, 110 GB)
+    // (measured, tools/q2_level1_probe.py: from 64^3 fine elements on the on-the-fly form is the faster one -- CG-MG iterations/s
+    // 43.3 against 42.1 at 64^3, 11.0 against 9.3 at 128^3, 2.19 against 1.54 at 256^3, where the stored matrices are 110 GB;
+    // below, a launch has too few waves to hide its scalar-load latency)
     mg->l1_virtual = N == 3 && sim->d.p == 2 && mg->first_active == 0 && mg->external_ke_level != 0 && mg->L >= 2 &&
                      (sim->q2_l1_virtual == 1 ||
-                      (sim->q2_l1_virtual == 2 && (double) stored_dims(mg, 1).nelems * 81 * 81 * sizeof(double) > 32e9));
+                      (sim->q2_l1_virtual == 2 && (double) stored_dims(mg, 1).nelems * 81 * 81 * sizeof(double) > 1.5e9));
     if (mg->l1_virtual) mg->lv[1].Ke.release();
     for (int l = l_first; l <= l_last; ++l) {
         GLevel &lv = mg->lv[l];
@@ -1190,6 +1192,17 @@ static void gmg_setup_transfer_tables(vfem_gmg *mg) {
                 for (int pn = 0; pn < npe; ++pn) v += ph[pn * npe + n] * T[(size_t) (N * pn + a) * ke + j];
                 cK[(size_t) i * ke + j] = v;
             }
+    }
+    if (N == 3 && p == 2) {
+        std::vector<double> tab((size_t) 27 * 27 * 72);
+        for (int ln = 0; ln < 27; ++ln)
+            for (int m = 0; m < 27; ++m)
+                for (int f = 0; f < 8; ++f)
+                    for (int r = 0; r < 3; ++r)
+                        for (int c = 0; c < 3; ++c)
+                            tab[((size_t) (ln * 27 + m) * 8 + f) * 9 + 3 * r + c] = cK0[(size_t) f * 6561 + (size_t) (3 * ln + r) * 81 + 3 * m + c];
+        mg->l1tab.alloc(tab.size());
+        VFEM_HIP(hipMemcpy(mg->l1tab.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     mg->phi.alloc(phi.size()); mg->cK0.alloc(cK0.size());
     VFEM_HIP(hipMemcpy(mg->phi.p, phi.data(), phi.size() * sizeof(double), hipMemcpyHostToDevice));

@@ -713,15 +713,68 @@ void launch_gs_sweep_q2_level0(int nx, int ny, int nz, const double *K0, const d
 struct Q2L1 {
     DimsQ2 d;                 // the level-1 grid
     Q2Color col;              // nodes visited: start / stride / count per axis
-    const double *cK0;        // [8][81][81], child index bit a = upper half along axis a (bit 0: x)
+    const double *tab;        // [27 ln][27 m][8 f][3 r][3 c] = cK0[f][(3 ln + r) * 81 + 3 m + c]; child index bit a = upper half along axis a (bit 0: x)
     const double *Ef;         // moduli of the level-0 elements, stored array (x slowest)
     int fny, fnz;             // level-0 elements per y / z
     int fx0;                  // stored level-0 layer of the first child of local level-1 layer 0
 };
 
-template <int MODE>
-__global__ void __launch_bounds__(256) k_q2_level1(Q2L1 a, double *__restrict__ u, const double *__restrict__ b,
-                                                   const uint8_t *__restrict__ mask, int forward, double *__restrict__ out) {
+// The 1944 coefficients of one incident element are consumed in 216 groups of nine (node m of the element, child f), each read
+// once from the table by scalar loads.  Left to itself the compiler requests all of them up front and parks the overflow in
+// VGPR lanes (1.9 k v_writelane + 1.9 k v_readlane per element, more issue slots than the multiply-adds).  The groups are
+// therefore requested Q2L1_AHEAD groups before their use and scheduling barriers keep requests and uses in that order: at most
+// (Q2L1_AHEAD + 1) x 18 SGPRs of coefficients are live.
+constexpr int Q2L1_AHEAD = 3;
+
+// contribution of one incident element (ex, ey, ez), in which the node has local index ln (uniform over the wave), to S and M
+__device__ __forceinline__ void q2l1_element(const Q2L1 &a, const double *__restrict__ u, int ex, int ey, int ez, int ln, double S[3], double M[9]) {
+    const DimsQ2 &d = a.d;
+    double t[8][3];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) t[f][0] = t[f][1] = t[f][2] = 0.0;
+    const double *tab = a.tab + (size_t) ln * (27 * 72);
+    const long long nbase = ((long long) (2 * ex) * d.NY + 2 * ey) * d.NZ + 2 * ez;
+    double cf[Q2L1_AHEAD + 1][9], uv[2][3];
+    static_for<216 + Q2L1_AHEAD>([&](auto gc) {                             // compile-time group index: every array index below folds
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g < 216) {                                             // request group g
+#pragma unroll
+            for (int q = 0; q < 9; ++q) cf[g % (Q2L1_AHEAD + 1)][q] = tab[9 * g + q];
+            if constexpr (g % 8 == 0) {                                      // ... and the values of its node
+                constexpr int m = g / 8;
+                const double *um = u + 3 * (nbase + ((long long) (m / 9) * d.NY + (m / 3) % 3) * d.NZ + m % 3);
+                uv[m & 1][0] = um[0]; uv[m & 1][1] = um[1]; uv[m & 1][2] = um[2];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g >= Q2L1_AHEAD) {                                     // use group g - AHEAD
+            constexpr int gg = g - Q2L1_AHEAD, m = gg / 8, f = gg % 8;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                t[f][r] = fma(cf[gg % (Q2L1_AHEAD + 1)][3 * r], uv[m & 1][0],
+                              fma(cf[gg % (Q2L1_AHEAD + 1)][3 * r + 1], uv[m & 1][1],
+                                  fma(cf[gg % (Q2L1_AHEAD + 1)][3 * r + 2], uv[m & 1][2], t[f][r])));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    const double *dg = tab + (size_t) ln * 72;                               // the groups of the node itself: diagonal block
+    double E8[8];                                                            // (read here: eight register pairs fewer live in the loop above)
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+        E8[f] = a.Ef[((long long) (a.fx0 + 2 * ex + (f & 1)) * a.fny + (2 * ey + ((f >> 1) & 1))) * a.fnz + 2 * ez + ((f >> 2) & 1)];
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            S[r] = fma(E8[f], t[f][r], S[r]);
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) M[3 * r + cc] = fma(E8[f], dg[9 * f + 3 * r + cc], M[3 * r + cc]);
+        }
+}
+
+template <int MODE>      // 1: out = K u; 2: out = zeroDirichlet(b - K u); 3: out = zeroDirichlet(K u) for the nodes of one parity class
+__global__ void __launch_bounds__(256) k_q2_level1(Q2L1 a, const double *__restrict__ u, const double *__restrict__ b,
+                                                   const uint8_t *__restrict__ mask, double *__restrict__ out) {
     const DimsQ2 &d = a.d;
     const int c = blockIdx.x * 64 + threadIdx.x, bq = blockIdx.y * 4 + threadIdx.y, ai = blockIdx.z;
     if (c >= a.col.cnt[2] || bq >= a.col.cnt[1] || ai >= a.col.cnt[0]) return;
@@ -739,76 +792,76 @@ __global__ void __launch_bounds__(256) k_q2_level1(Q2L1 a, double *__restrict__ 
             for (int sz = 0; sz < nez; ++sz) {
                 const int ez = pz ? k / 2 : k / 2 - 1 + sz, lz = pz ? 1 : (sz ? 0 : 2);
                 if (ex < 0 || ex >= d.nx || ey < 0 || ey >= d.ny || ez < 0 || ez >= d.nz) continue;
-                const int ln = 9 * lx + 3 * ly + lz;                                      // uniform over the launch
-                double E8[8];
-#pragma unroll
-                for (int f = 0; f < 8; ++f)
-                    E8[f] = a.Ef[((long long) (a.fx0 + 2 * ex + (f & 1)) * a.fny + (2 * ey + ((f >> 1) & 1))) * a.fnz + 2 * ez + ((f >> 2) & 1)];
-                double t[8][3];
-#pragma unroll
-                for (int f = 0; f < 8; ++f) t[f][0] = t[f][1] = t[f][2] = 0.0;
-                const double *rows = a.cK0 + (size_t) (3 * ln) * 81;
-#pragma unroll
-                for (int ma = 0; ma < 3; ++ma)
-#pragma unroll
-                    for (int mb = 0; mb < 3; ++mb) {
-                        const long long rowbase = ((long long) (2 * ex + ma) * d.NY + (2 * ey + mb)) * d.NZ + 2 * ez;
-#pragma unroll
-                        for (int mc = 0; mc < 3; ++mc) {
-                            const int m = 9 * ma + 3 * mb + mc;
-                            const double *um = u + 3 * (rowbase + mc);
-                            const double u0 = um[0], u1 = um[1], u2 = um[2];
-#pragma unroll
-                            for (int f = 0; f < 8; ++f) {
-                                const double *r0 = rows + (size_t) f * 6561 + 3 * m;
-#pragma unroll
-                                for (int r = 0; r < 3; ++r)
-                                    t[f][r] = fma(r0[81 * r], u0, fma(r0[81 * r + 1], u1, fma(r0[81 * r + 2], u2, t[f][r])));
-                            }
-                        }
-                    }
-#pragma unroll
-                for (int f = 0; f < 8; ++f) {
-                    const double *dg = rows + (size_t) f * 6561 + 3 * ln;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        S[r] = fma(E8[f], t[f][r], S[r]);
-#pragma unroll
-                        for (int cc = 0; cc < 3; ++cc) M[3 * r + cc] = fma(E8[f], dg[81 * r + cc], M[3 * r + cc]);
-                    }
-                }
+                q2l1_element(a, u, ex, ey, ez, 9 * lx + 3 * ly + lz, S, M);
             }
         }
     }
     const long long n = ((long long) i * d.NY + j) * d.NZ + k;
-    if (MODE == 0) {
-        double bms[3], ud[3];
+    const uint8_t mk = (MODE >= 2 && mask) ? mask[n] : (uint8_t) 0;
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) bms[cc] = b[3 * n + cc] - S[cc];
-        gs_solve(bms, M, mask ? mask[n] : (uint8_t) 0, forward != 0, ud);
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) u[3 * n + cc] += ud[cc];
-    } else {
-        const uint8_t mk = (MODE >= 2 && mask) ? mask[n] : (uint8_t) 0;
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-            double v = MODE == 2 ? b[3 * n + cc] - S[cc] : S[cc];
-            if ((mk >> cc) & 1) v = 0.0;
-            out[3 * n + cc] = v;
-        }
+    for (int cc = 0; cc < 3; ++cc) {
+        double v = MODE == 2 ? b[3 * n + cc] - S[cc] : S[cc];
+        if ((mk >> cc) & 1) v = 0.0;
+        out[3 * n + cc] = v;
     }
 }
 
-static Q2L1 q2l1_args(int nx, int ny, int nz, const double *cK0, const double *Ef, int fx0) {
+// One colour of the sweep (MG.hh:254-264).  A block holds 64 nodes of a z-row and one wave per incident element of such a node
+// (1, 2, 4 or 8 by the colour): every colour touches every element once, so all 27 launches have about the same number of waves
+// (elements / 64) whatever the colour, and a node's chain of dependent multiply-adds is one element long.  Partial sums meet
+// in LDS and are added in the order of the element loops above.
+__global__ void __launch_bounds__(512) k_q2_level1_gs(Q2L1 a, double *__restrict__ u, const double *__restrict__ b,
+                                                      const uint8_t *__restrict__ mask, int forward) {
+    extern __shared__ double q2l1_part[];               // [waves][12][64] (nothing for a colour with one incident element)
+    double (*part)[12][64] = reinterpret_cast<double (*)[12][64]>(q2l1_part);
+    const DimsQ2 &d = a.d;
+    const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y), c = blockIdx.x * 64 + lane, bq = blockIdx.y, ai = blockIdx.z;
+    const bool live = c < a.col.cnt[2];
+    const int i = a.col.start[0] + ai * a.col.inc[0], j = a.col.start[1] + bq * a.col.inc[1], k = a.col.start[2] + (live ? c : 0) * a.col.inc[2];
+    const int px = a.col.start[0] & 1, py = a.col.start[1] & 1, pz = a.col.start[2] & 1;
+    const int ney = py ? 1 : 2, nez = pz ? 1 : 2;
+    const int sx = w / (ney * nez), sy = (w / nez) % ney, sz = w % nez;      // this wave's incident element (uniform)
+    const int ex = px ? i / 2 : i / 2 - 1 + sx, lx = px ? 1 : (sx ? 0 : 2);
+    const int ey = py ? j / 2 : j / 2 - 1 + sy, ly = py ? 1 : (sy ? 0 : 2);
+    const int ez = pz ? k / 2 : k / 2 - 1 + sz, lz = pz ? 1 : (sz ? 0 : 2);
+    double S[3] = {0.0, 0.0, 0.0}, M[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) M[q] = 0.0;
+    if (live && ex >= 0 && ex < d.nx && ey >= 0 && ey < d.ny && ez >= 0 && ez < d.nz) q2l1_element(a, u, ex, ey, ez, 9 * lx + 3 * ly + lz, S, M);
+    if (blockDim.y > 1) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) part[w][q][lane] = S[q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) part[w][3 + q][lane] = M[q];
+        __syncthreads();
+        if (w != 0) return;
+        for (int o = 1; o < (int) blockDim.y; ++o) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) S[q] += part[o][q][lane];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) M[q] += part[o][3 + q][lane];
+        }
+    }
+    if (!live) return;
+    const long long n = ((long long) i * d.NY + j) * d.NZ + k;
+    double bms[3], ud[3];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) bms[cc] = b[3 * n + cc] - S[cc];
+    gs_solve(bms, M, mask ? mask[n] : (uint8_t) 0, forward != 0, ud);
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) u[3 * n + cc] += ud[cc];
+}
+
+static Q2L1 q2l1_args(int nx, int ny, int nz, const double *tab, const double *Ef, int fx0) {
     Q2L1 a{};
     a.d = DimsQ2{nx, ny, nz, 2 * nx + 1, 2 * ny + 1, 2 * nz + 1};
-    a.cK0 = cK0; a.Ef = Ef; a.fny = 2 * ny; a.fnz = 2 * nz; a.fx0 = fx0;
+    a.tab = tab; a.Ef = Ef; a.fny = 2 * ny; a.fnz = 2 * nz; a.fx0 = fx0;
     return a;
 }
 // colours [first, first + count) of the sweep in visiting order (as launch_gs_sweep_q2_level0)
-void launch_gs_sweep_q2_level1(int nx, int ny, int nz, const double *cK0, const double *Ef, int fx0, double *u, const double *b,
+void launch_gs_sweep_q2_level1(int nx, int ny, int nz, const double *tab, const double *Ef, int fx0, double *u, const double *b,
                                const uint8_t *mask, int forward, hipStream_t s, int first, int count) {
-    Q2L1 a = q2l1_args(nx, ny, nz, cK0, Ef, fx0);
+    Q2L1 a = q2l1_args(nx, ny, nz, tab, Ef, fx0);
     const int NN[3] = {a.d.NX, a.d.NY, a.d.NZ};
     for (int ci = first; ci < (first + count < 27 ? first + count : 27); ++ci) {
         const int lni = forward ? ci : 26 - ci;                      // MG.hh:293-295
@@ -821,15 +874,16 @@ void launch_gs_sweep_q2_level1(int nx, int ny, int nz, const double *cK0, const 
             empty = empty || a.col.cnt[ax] == 0;
         }
         if (empty) continue;
-        const dim3 grd((a.col.cnt[2] + 63) / 64, (a.col.cnt[1] + 3) / 4, a.col.cnt[0]), blk(64, 4, 1);
-        k_q2_level1<0><<<grd, blk, 0, s>>>(a, u, b, mask, forward, nullptr);
+        const int waves = (l[0] == 1 ? 1 : 2) * (l[1] == 1 ? 1 : 2) * (l[2] == 1 ? 1 : 2);
+        const dim3 grd((a.col.cnt[2] + 63) / 64, a.col.cnt[1], a.col.cnt[0]), blk(64, waves, 1);
+        k_q2_level1_gs<<<grd, blk, waves > 1 ? (size_t) waves * 12 * 64 * sizeof(double) : 0, s>>>(a, u, b, mask, forward);
     }
     VFEM_HIP(hipGetLastError());
 }
 // mode 0: out = K u; 1: out = zeroDirichlet(b - K u); 2: out = zeroDirichlet(K u) -- one launch per node-parity class
-void launch_apply_q2_level1(int nx, int ny, int nz, const double *cK0, const double *Ef, int fx0, const double *u, const double *b,
+void launch_apply_q2_level1(int nx, int ny, int nz, const double *tab, const double *Ef, int fx0, const double *u, const double *b,
                             const uint8_t *mask, int mode, double *out, hipStream_t s) {
-    Q2L1 a = q2l1_args(nx, ny, nz, cK0, Ef, fx0);
+    Q2L1 a = q2l1_args(nx, ny, nz, tab, Ef, fx0);
     const int NN[3] = {a.d.NX, a.d.NY, a.d.NZ};
     for (int pc = 0; pc < 8; ++pc) {
         const int par[3] = {(pc >> 2) & 1, (pc >> 1) & 1, pc & 1};
@@ -838,10 +892,9 @@ void launch_apply_q2_level1(int nx, int ny, int nz, const double *cK0, const dou
             a.col.cnt[ax] = (NN[ax] - 1 - par[ax]) / 2 + 1;
         }
         const dim3 grd((a.col.cnt[2] + 63) / 64, (a.col.cnt[1] + 3) / 4, a.col.cnt[0]), blk(64, 4, 1);
-        double *uu = const_cast<double *>(u);
-        if (mode == 0) k_q2_level1<1><<<grd, blk, 0, s>>>(a, uu, b, mask, 1, out);
-        else if (mode == 1) k_q2_level1<2><<<grd, blk, 0, s>>>(a, uu, b, mask, 1, out);
-        else k_q2_level1<3><<<grd, blk, 0, s>>>(a, uu, b, mask, 1, out);
+        if (mode == 0) k_q2_level1<1><<<grd, blk, 0, s>>>(a, u, b, mask, out);
+        else if (mode == 1) k_q2_level1<2><<<grd, blk, 0, s>>>(a, u, b, mask, out);
+        else k_q2_level1<3><<<grd, blk, 0, s>>>(a, u, b, mask, out);
     }
     VFEM_HIP(hipGetLastError());
 }

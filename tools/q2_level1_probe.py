@@ -28,7 +28,8 @@ u0 = torch.randn((nn1, 3), dtype=torch.float64, device="cuda", generator=g)
 b = torch.randn((nn1, 3), dtype=torch.float64, device="cuda", generator=g)
 out = {"grid": n, "levels": levels, "level1_nodes": nn1}
 fields = {}
-for mode in (0, 1):
+MODES = (1,) if "--virtual-only" in sys.argv else (0, 1)
+for mode in MODES:
     _lib.check(lib.vfem_gsim_set_option(t._h, 14, mode))
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
@@ -67,6 +68,8 @@ for mode in (0, 1):
                                             "residual_ms": res * 1e3, "pcg_iterations": mg.last_iterations, "pcg_s": dt,
                                             "iterations_per_s": mg.last_iterations / dt, "compliance": float((f * x).sum())}
     print(json.dumps(out), flush=True)
+if len(MODES) < 2:
+    raise SystemExit(0)
 du = float((fields[0][0] - fields[1][0]).abs().max() / fields[0][0].abs().max())
 dr = float((fields[0][1] - fields[1][1]).abs().max() / fields[0][1].abs().max())
 out["max_rel_diff_after_5_sweeps"], out["max_rel_diff_residual"] = du, dr
