@@ -260,11 +260,15 @@ static void update_operators(vfem_mg *mg, hipStream_t s) {
     if (!mg->rocblas) {
         rocblas_handle hnd;
         if (rocblas_create_handle(&hnd) != rocblas_status_success) throw Error("rocblas_create_handle failed");
+        // the dense coarsest inverse must not depend on the order in which atomic partial sums happen to land (rocBLAS allows
+        // atomics by default): the same densities must give the same preconditioner, bit for bit, in every run and on every rank
+        rocblas_set_atomics_mode(hnd, rocblas_atomics_not_allowed);
         mg->rocblas = hnd;
         mg->info.alloc(1);
     }
     rocblas_handle hnd = (rocblas_handle) mg->rocblas;
     rocblas_set_stream(hnd, s);
+    vfem::DenseFactorisationLock dense_lock;      // released after the stream has drained (end of this function)
     if (rocsolver_dpotrf(hnd, rocblas_fill_lower, (rocblas_int) n, mg->Ainv.p, (rocblas_int) n, mg->info.p) != rocblas_status_success)
         throw Error("rocsolver_dpotrf failed");
     int info = 0;

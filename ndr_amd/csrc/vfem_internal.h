@@ -158,6 +158,14 @@ void launch_apply_q2_pencil(int nx, int ny, int nz, const double *mode_table, co
 void launch_apply_q2_march(int nx, int ny, int nz, const double *mode_table, const double *E, const double *u, double *out, hipStream_t s);
 void launch_gs_sweep_q2_level0(int nx, int ny, int nz, const double *K0, const double *E, double *u, const double *b,
                                const uint8_t *mask, int forward, hipStream_t s, int first = 0, int count = 27);
+// held around rocsolver_dpotrf / dpotri (kernels_vec.hip): serialises the dense factorisations of processes sharing a device
+struct DenseFactorisationLock {
+    int fd = -1;
+    DenseFactorisationLock();
+    ~DenseFactorisationLock();
+    DenseFactorisationLock(const DenseFactorisationLock &) = delete;
+    DenseFactorisationLock &operator=(const DenseFactorisationLock &) = delete;
+};
 void launch_gs_sweep_q2_level1(int nx, int ny, int nz, const double *cK0, const double *Ef, int fx0, double *u, const double *b,
                                const uint8_t *mask, int forward, hipStream_t s, int first = 0, int count = 27);
 void launch_apply_q2_level1(int nx, int ny, int nz, const double *cK0, const double *Ef, int fx0, const double *u, const double *b,
