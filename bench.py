@@ -399,10 +399,13 @@ def main():
             result["mlp_forward"] = mlp_rate()
         except RuntimeError as e:
             result["mlp_forward"] = {"error": str(e)}
-        try:
-            result["degree2_cg_mg"] = degree2_pcg_rate()
-        except RuntimeError as e:
-            result["degree2_cg_mg"] = {"error": str(e)}
+        result["degree2_cg_mg"] = []
+        for q2n, q2l in ((128, 5), (256, 6)):      # 256^3: 135 M nodes; level 1 on the fly (its stored matrices would be 110 GB)
+            torch.cuda.empty_cache()
+            try:
+                result["degree2_cg_mg"].append(degree2_pcg_rate(q2n, q2l))
+            except RuntimeError as e:
+                result["degree2_cg_mg"].append({"grid": "%dx%dx%d" % (q2n, q2n, q2n), "error": str(e)})
         result["degree2_spmv"] = []
         for q2ne in ((256, 256, 256), (512, 512, 512)):
             torch.cuda.empty_cache()
