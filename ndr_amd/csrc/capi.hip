@@ -882,15 +882,14 @@ int vfem_mg_pcg(vfem_mg *mg, double *x, const double *b, int max_iter, double to
             mg->lv[0].x.zero(s);
             mg_cycles(mg, mg_iterations, mg_smoothing, true, fmg != 0, s);
         }
-        launch_zero_dirichlet(nn, mask, sv, s);
+        // the vector work between the cycle and the apply, three passes fewer than one kernel per line of MG.hh:713-725 (same
+        // sums in the same order: iterates and residuals are unchanged bit for bit)
         launch_shift_scalar(sc, s);                                     // rMr_old = rMr
-        launch_dot(n3, r, sv, mg->scratch.p, sc + 0, s);                // rMr = r . s
+        launch_dot_zero_dirichlet(n3, r, sv, mask, mg->scratch.p, sc + 0, s);   // s = zeroDirichlet(s); rMr = r . s
         launch_pcg_direction(n3, sv, d, sc, it == 1, s);
         mg_apply(mg, 0, d, nullptr, 0, Ad, s);                          // Ad = K d
-        launch_zero_dirichlet(nn, mask, Ad, s);
-        launch_dot(n3, d, Ad, mg->scratch.p, sc + 2, s);
-        launch_pcg_step(n3, x, r, d, Ad, sc, s);
-        launch_dot(n3, r, r, mg->scratch.p, sc + 3, s);
+        launch_dot_zero_dirichlet(n3, d, Ad, mask, mg->scratch.p, sc + 2, s);   // Ad = zeroDirichlet(Ad); d . Ad
+        launch_pcg_step_dot(n3, x, r, d, Ad, sc, mg->scratch.p, sc + 3, s);      // x += alpha d, r -= alpha Ad, ||r||^2
         VFEM_HIP(hipMemcpyAsync(host_sc, sc + 3, sizeof(double), hipMemcpyDeviceToHost, s));
         VFEM_HIP(hipStreamSynchronize(s));
         rr = host_sc[0];

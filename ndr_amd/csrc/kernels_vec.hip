@@ -133,6 +133,51 @@ __global__ void __launch_bounds__(256) k_dot_final(int nparts, const double *__r
     if (threadIdx.x == 0) *out = t;
 }
 
+// zeroDirichlet(bm) and a . bm in one pass over both (bm is written only where a component is constrained); same partition and
+// order of the sum as k_dot_partial, so the value equals launch_zero_dirichlet + launch_dot bit for bit
+__global__ void __launch_bounds__(256) k_dot_masked_partial(long long n, const double *__restrict__ a, double *__restrict__ bm,
+                                                            const uint8_t *__restrict__ mask, double *__restrict__ partial) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+        double v = bm[i];
+        const long long node = i / 3;
+        if ((mask[node] >> (int) (i - 3 * node)) & 1) { v = 0.0; bm[i] = 0.0; }
+        acc = fma(a[i], v, acc);
+    }
+    const double t = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+void launch_dot_zero_dirichlet(long long n, const double *a, double *bm, const uint8_t *mask, double *scratch, double *out, hipStream_t s) {
+    k_dot_masked_partial<<<DOT_BLOCKS, 256, 0, s>>>(n, a, bm, mask, scratch);
+    k_dot_final<<<1, 256, 0, s>>>(DOT_BLOCKS, scratch, out);
+    VFEM_HIP(hipGetLastError());
+}
+
+// x += alpha d, r -= alpha Ad and ||r||^2 of the new residual in one pass (alpha = sc[0] / sc[2]); the sum is partitioned and
+// ordered as k_dot_partial's
+__global__ void __launch_bounds__(256) k_pcg_step_dot(long long n, double *__restrict__ x, double *__restrict__ r,
+                                                      const double *__restrict__ dv, const double *__restrict__ Ad,
+                                                      const double *__restrict__ sc, double *__restrict__ partial) {
+    __shared__ double sh[4];
+    const double alpha = sc[0] / sc[2];
+    double acc = 0.0;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+        x[i] = fma(alpha, dv[i], x[i]);
+        const double rn = fma(-alpha, Ad[i], r[i]);
+        r[i] = rn;
+        acc = fma(rn, rn, acc);
+    }
+    const double t = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+void launch_pcg_step_dot(long long n, double *x, double *r, const double *dv, const double *Ad, const double *sc, double *scratch,
+                         double *rr_out, hipStream_t s) {
+    k_pcg_step_dot<<<DOT_BLOCKS, 256, 0, s>>>(n, x, r, dv, Ad, sc, scratch);
+    k_dot_final<<<1, 256, 0, s>>>(DOT_BLOCKS, scratch, rr_out);
+    VFEM_HIP(hipGetLastError());
+}
+
 void launch_dot(long long n, const double *a, const double *b, double *scratch, double *out, hipStream_t s) {
     k_dot_partial<<<DOT_BLOCKS, 256, 0, s>>>(n, a, b, scratch);
     k_dot_final<<<1, 256, 0, s>>>(DOT_BLOCKS, scratch, out);

@@ -142,6 +142,9 @@ void launch_compliance_gradient(const Dims &d, const double *K0, const double *r
 
 // reductions: out[slot] = sum a[i]*b[i]; deterministic two-pass. scratch holds >= 2048 doubles.
 void launch_dot(long long n, const double *a, const double *b, double *scratch, double *out, hipStream_t s);
+void launch_dot_zero_dirichlet(long long n3, const double *a, double *b_masked_in_place, const uint8_t *mask, double *scratch, double *out, hipStream_t s);
+void launch_pcg_step_dot(long long n3, double *x, double *r, const double *dv, const double *Ad, const double *sc, double *scratch,
+                         double *rr_out, hipStream_t s);
 // PCG vector updates with device-resident scalars (sc: [0]=rMr [1]=rMr_old [2]=dAd [3]=rr)
 void launch_pcg_direction(long long n, const double *sv, double *dv, const double *sc, int first, hipStream_t s);
 void launch_pcg_step(long long n, double *x, double *r, const double *dv, const double *Ad, const double *sc,
