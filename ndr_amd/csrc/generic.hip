@@ -574,6 +574,8 @@ struct vfem_gsim {
     std::vector<double> K0;
     DevBuf<double> dK0, rho, E, dvals;
     DevBuf<double> q2tab;                          // degree-2 hexahedra: packed mode-space blocks (q2_modes.h)
+    DevBuf<double> q2gstab;                        // ... and K0 regrouped for the finest-level sweep ordered by neighbour node
+    int q2_gs_impl = 1;                            // vfem_gsim_set_option(16, v): finest-level sweep 0 by element, 1 by neighbour node
     bool q2_fast = false;
     int q2_l1_virtual = 2;                         // vfem_gsim_set_option(14, v): level 1 of a degree-2 hierarchy 0 stored, 1 virtual, 2 by size
     int q2_impl = 0;                               // vfem_gsim_set_option(6, v): 0 marching kernel (mode space), 1 dense gather kernel (cross-check), 2 pencil kernel
@@ -677,6 +679,10 @@ void vfem_gsim::update_k0() {
     VFEM_HIP(hipMemcpy(dK0.p, K0.data(), K0.size() * sizeof(double), hipMemcpyHostToDevice));
     q2_fast = false;
     if (N == 3 && p == 2) {
+        std::vector<double> gst;
+        build_q2_gs_table(K0.data(), gst);
+        q2gstab.alloc(gst.size());
+        VFEM_HIP(hipMemcpy(q2gstab.p, gst.data(), gst.size() * sizeof(double), hipMemcpyHostToDevice));
         // mode-space matrix Kt = T^-T K0 T^-1 (q2_modes.h); T^-1 per axis: u0 = (s - a)/2, u1 = m, u2 = (s + a)/2
         static const double Ti[3][3] = {{0.5, 0.0, -0.5}, {0.0, 1.0, 0.0}, {0.5, 0.0, 0.5}};      // [node][mode]
         std::vector<double> T3(27 * 27), A((size_t) 81 * 81), Kt((size_t) 81 * 81);
@@ -764,7 +770,10 @@ static void gmg_smooth(vfem_gmg *mg, int l, double *u, const double *b, int forw
     const GDims &d = mg->lv[l].d;
     if (count < 0) count = 27;
     if (l == 0 && mg->external_ke_level != 0 && d.N == 3 && d.p == 2 && mg->fine->q2_impl != 1) {  // finest degree-2 level: thread per node
-        launch_gs_sweep_q2_level0(d.ne[0], d.ne[1], d.ne[2], mg->fine->dK0.p, mg->fine->E_local(), u, b, mg->lv[0].mask.p, forward, s, first, count);
+        if (mg->fine->q2_gs_impl == 1)
+            launch_gs_sweep_q2_level0_nodes(d.ne[0], d.ne[1], d.ne[2], mg->fine->q2gstab.p, mg->fine->E_local(), u, b, mg->lv[0].mask.p, forward, s, first, count);
+        else
+            launch_gs_sweep_q2_level0(d.ne[0], d.ne[1], d.ne[2], mg->fine->dK0.p, mg->fine->E_local(), u, b, mg->lv[0].mask.p, forward, s, first, count);
         return;
     }
     if (l == 1 && mg->l1_virtual) {
@@ -1125,6 +1134,7 @@ int vfem_gsim_set_option(vfem_gsim *sim, int key, int value) {
     G_TRY
     if (key == 6 && value >= 0 && value <= 2) sim->q2_impl = value;
     else if (key == 14 && value >= 0 && value <= 2) sim->q2_l1_virtual = value;
+    else if (key == 16 && (value == 0 || value == 1)) sim->q2_gs_impl = value;
     else throw Error("unknown option or value out of range");
     G_CATCH
 }

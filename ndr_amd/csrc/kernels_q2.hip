@@ -701,6 +701,179 @@ void launch_gs_sweep_q2_level0(int nx, int ny, int nz, const double *K0, const d
 }
 
 // ------------------------------------------------------------------------------------------------------
+// The same colour sweep with the sum ordered by NEIGHBOUR NODE instead of by element.  k_gs_q2_level0 reads the 27 nodes of each
+// of a node's incident elements (8 x 81 = 648 values for a vertex node, at a lane stride of 96 bytes) although the elements
+// overlap in only 5^3 = 125 distinct nodes: the sweep is bound by the load instructions a CU's address unit processes, not by
+// its 1944 multiply-adds (4 % of the fp64 peak).  Here a lane walks the distinct neighbour nodes, reads each one's three values
+// once, and adds K0[rows of the node in e][columns of the neighbour in e] u to a partial sum per incident element e containing
+// both (8 x 3 partial sums, scaled by the elements' moduli at the end -- the structure of k_q2_level1 with the incident
+// elements in the role of the children): 375 values instead of 648 for a vertex node, the same 1944 multiply-adds.  The
+// coefficients are wave-uniform and arrive by scalar loads in the order of use, groups of nine requested three groups ahead.
+// ------------------------------------------------------------------------------------------------------
+struct Q2Grp { int ox, oy, oz, e, ln, lm, first, last, nb; };     // neighbour offset, element slot sx*4+sy*2+sz, local indices, flags, neighbour ordinal
+__host__ __device__ constexpr int q2a_noff(int P) { return P ? 3 : 5; }
+__host__ __device__ constexpr int q2a_off(int P, int idx) { return P ? idx - 1 : idx - 2; }
+__host__ __device__ constexpr int q2a_nopt(int P, int o) { return (P == 0 && o == 0) ? 2 : 1; }
+__host__ __device__ constexpr int q2a_sel(int P, int o, int t) { return P ? 0 : (o < 0 ? 0 : (o > 0 ? 1 : t)); }          // lower / upper element
+__host__ __device__ constexpr int q2a_ln(int P, int o, int t) { return P ? 1 : (q2a_sel(P, o, t) ? 0 : 2); }
+__host__ __device__ constexpr int q2a_lm(int P, int o, int t) { return P ? 1 + o : (q2a_sel(P, o, t) ? o : 2 + o); }
+__host__ __device__ constexpr int q2_ngroups(int PX, int PY, int PZ) { return (PX ? 3 : 6) * (PY ? 3 : 6) * (PZ ? 3 : 6); }
+__host__ __device__ constexpr Q2Grp q2_group(int PX, int PY, int PZ, int g) {
+    int n = 0, nb = 0;
+    for (int ix = 0; ix < q2a_noff(PX); ++ix)
+        for (int iy = 0; iy < q2a_noff(PY); ++iy)
+            for (int iz = 0; iz < q2a_noff(PZ); ++iz, ++nb) {
+                const int ox = q2a_off(PX, ix), oy = q2a_off(PY, iy), oz = q2a_off(PZ, iz);
+                const int cnt = q2a_nopt(PX, ox) * q2a_nopt(PY, oy) * q2a_nopt(PZ, oz);
+                if (g < n + cnt) {
+                    const int w = g - n, tz = w % q2a_nopt(PZ, oz), ty = (w / q2a_nopt(PZ, oz)) % q2a_nopt(PY, oy),
+                              tx = w / (q2a_nopt(PZ, oz) * q2a_nopt(PY, oy));
+                    return Q2Grp{ox, oy, oz, 4 * q2a_sel(PX, ox, tx) + 2 * q2a_sel(PY, oy, ty) + q2a_sel(PZ, oz, tz),
+                                 9 * q2a_ln(PX, ox, tx) + 3 * q2a_ln(PY, oy, ty) + q2a_ln(PZ, oz, tz),
+                                 9 * q2a_lm(PX, ox, tx) + 3 * q2a_lm(PY, oy, ty) + q2a_lm(PZ, oz, tz), w == 0, w == cnt - 1, nb};
+                }
+                n += cnt;
+            }
+    return Q2Grp{0, 0, 0, 0, 0, 0, 0, 0, 0};
+}
+__host__ __device__ constexpr int q2_center_group(int PX, int PY, int PZ) {      // first group of the neighbour (0, 0, 0)
+    for (int g = 0; g < q2_ngroups(PX, PY, PZ); ++g) {
+        const Q2Grp q = q2_group(PX, PY, PZ, g);
+        if (q.ox == 0 && q.oy == 0 && q.oz == 0) return g;
+    }
+    return 0;
+}
+// coefficient table of one parity class: [group][3 r][3 c] = K0[(3 ln + r) * 81 + 3 lm + c]; classes follow each other in the
+// order 4 PX + 2 PY + PZ (offsets: q2_table_offset)
+__host__ __device__ constexpr int q2_table_offset(int cls) {
+    int o = 0;
+    for (int c = 0; c < cls; ++c) o += 9 * q2_ngroups((c >> 2) & 1, (c >> 1) & 1, c & 1);
+    return o;
+}
+void build_q2_gs_table(const double *K0, std::vector<double> &tab) {
+    tab.assign((size_t) q2_table_offset(8), 0.0);
+    for (int cls = 0; cls < 8; ++cls) {
+        const int PX = (cls >> 2) & 1, PY = (cls >> 1) & 1, PZ = cls & 1;
+        for (int g = 0; g < q2_ngroups(PX, PY, PZ); ++g) {
+            const Q2Grp q = q2_group(PX, PY, PZ, g);
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c)
+                    tab[(size_t) q2_table_offset(cls) + 9 * g + 3 * r + c] = K0[(size_t) (3 * q.ln + r) * 81 + 3 * q.lm + c];
+        }
+    }
+}
+
+constexpr int Q2N_AHEAD = 3;
+template <int PX, int PY, int PZ>
+__global__ void __launch_bounds__(256) k_gs_q2_level0_nodes(DimsQ2 d, Q2Color col, const double *__restrict__ tabc, const double *__restrict__ E,
+                                                            double *__restrict__ u, const double *__restrict__ b,
+                                                            const uint8_t *__restrict__ mask, int forward) {
+    const int c = blockIdx.x * 64 + threadIdx.x, bq = blockIdx.y * 4 + threadIdx.y, a = blockIdx.z;
+    if (c >= col.cnt[2] || bq >= col.cnt[1] || a >= col.cnt[0]) return;
+    const int i = col.start[0] + a * col.inc[0], j = col.start[1] + bq * col.inc[1], k = col.start[2] + c * col.inc[2];
+    constexpr int NG = q2_ngroups(PX, PY, PZ);
+    // moduli of the incident elements (slot sx*4 + sy*2 + sz; a mid node has one element along that axis: slot bit 0)
+    double Ee[8];
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+        const int sx = (sl >> 2) & 1, sy = (sl >> 1) & 1, sz = sl & 1;
+        const int ex = PX ? i / 2 : i / 2 - 1 + sx, ey = PY ? j / 2 : j / 2 - 1 + sy, ez = PZ ? k / 2 : k / 2 - 1 + sz;
+        const bool used = (!PX || sx == 0) && (!PY || sy == 0) && (!PZ || sz == 0);
+        const bool ok = used && ex >= 0 && ex < d.nx && ey >= 0 && ey < d.ny && ez >= 0 && ez < d.nz;
+        Ee[sl] = ok ? E[((long long) ex * d.ny + ey) * d.nz + ez] : 0.0;
+    }
+    // t[e][r]: rows of the node in element e against the neighbours visited so far (unscaled); S = sum_e E_e t[e]
+    double t[8][3], cf[Q2N_AHEAD + 1][9], uv[Q2N_AHEAD + 1][3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e][0] = t[e][1] = t[e][2] = 0.0;
+    static_for<NG + Q2N_AHEAD>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g < NG) {                                              // request group g ...
+#pragma unroll
+            for (int q = 0; q < 9; ++q) cf[g % (Q2N_AHEAD + 1)][q] = tabc[9 * g + q];
+            constexpr Q2Grp G = q2_group(PX, PY, PZ, g);
+            if constexpr (G.first) {                                         // ... and the values of its neighbour node
+                // a neighbour outside the grid belongs to no existing element (moduli 0): any finite value will do -- the
+                // address is clamped into the grid, no divergent control flow
+                const int ni = min(max(i + G.ox, 0), d.NX - 1), nj = min(max(j + G.oy, 0), d.NY - 1), nk = min(max(k + G.oz, 0), d.NZ - 1);
+                const double *um = u + 3 * (((long long) ni * d.NY + nj) * d.NZ + nk);
+                uv[G.nb % (Q2N_AHEAD + 1)][0] = um[0]; uv[G.nb % (Q2N_AHEAD + 1)][1] = um[1]; uv[G.nb % (Q2N_AHEAD + 1)][2] = um[2];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g >= Q2N_AHEAD) {                                      // use group g - AHEAD
+            constexpr int gg = g - Q2N_AHEAD;
+            constexpr Q2Grp G = q2_group(PX, PY, PZ, gg);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                t[G.e][r] = fma(cf[gg % (Q2N_AHEAD + 1)][3 * r], uv[G.nb % (Q2N_AHEAD + 1)][0],
+                                fma(cf[gg % (Q2N_AHEAD + 1)][3 * r + 1], uv[G.nb % (Q2N_AHEAD + 1)][1],
+                                    fma(cf[gg % (Q2N_AHEAD + 1)][3 * r + 2], uv[G.nb % (Q2N_AHEAD + 1)][2], t[G.e][r])));
+            // (arithmetic carries no ordering of its own: instruction selection may sink it below every barrier, which keeps all
+            // coefficients alive; the empty statement ties the group's multiply-adds to this place)
+            asm volatile("" : "+v"(t[G.e][0]), "+v"(t[G.e][1]), "+v"(t[G.e][2]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    // the groups of the node with itself (offset 0, 0, 0): diagonal block M = sum_e E_e K0[ln_e][ln_e]
+    constexpr int G0 = q2_center_group(PX, PY, PZ);
+    double S[3] = {0.0, 0.0, 0.0}, M[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) M[q] = 0.0;
+    static_for<q2a_nopt(PX, 0) * q2a_nopt(PY, 0) * q2a_nopt(PZ, 0)>([&](auto wc) {
+        constexpr Q2Grp G = q2_group(PX, PY, PZ, G0 + decltype(wc)::value);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) M[q] = fma(Ee[G.e], tabc[9 * (G0 + decltype(wc)::value) + q], M[q]);
+    });
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) S[r] = fma(Ee[e], t[e][r], S[r]);
+    const long long n = ((long long) i * d.NY + j) * d.NZ + k;
+    double bms[3], ud[3];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) bms[cc] = b[3 * n + cc] - S[cc];
+    gs_solve(bms, M, mask ? mask[n] : (uint8_t) 0, forward != 0, ud);
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) u[3 * n + cc] += ud[cc];
+}
+
+void launch_gs_sweep_q2_level0_nodes(int nx, int ny, int nz, const double *tab, const double *E, double *u, const double *b,
+                                     const uint8_t *mask, int forward, hipStream_t s, int first, int count) {
+    DimsQ2 d{nx, ny, nz, 2 * nx + 1, 2 * ny + 1, 2 * nz + 1};
+    const int NN[3] = {d.NX, d.NY, d.NZ};
+    for (int ci = first; ci < (first + count < 27 ? first + count : 27); ++ci) {
+        const int lni = forward ? ci : 26 - ci;                      // MG.hh:293-295
+        const int l[3] = {lni / 9, (lni / 3) % 3, lni % 3};
+        Q2Color col;
+        bool empty = false;
+        for (int a = 0; a < 3; ++a) {
+            col.start[a] = l[a];
+            col.inc[a] = (l[a] == 1) ? 2 : 4;                        // MG.hh:301-305
+            col.cnt[a] = l[a] > NN[a] - 1 ? 0 : (NN[a] - 1 - l[a]) / col.inc[a] + 1;
+            empty = empty || col.cnt[a] == 0;
+        }
+        if (empty) continue;
+        const dim3 grd((col.cnt[2] + 63) / 64, (col.cnt[1] + 3) / 4, col.cnt[0]), blk(64, 4, 1);
+        const int cls = 4 * (l[0] & 1) + 2 * (l[1] & 1) + (l[2] & 1);
+        const double *tc = tab + q2_table_offset(cls);
+#define VFEM_Q2GSN(X, Y, Z) k_gs_q2_level0_nodes<X, Y, Z><<<grd, blk, 0, s>>>(d, col, tc, E, u, b, mask, forward)
+        switch (cls) {
+            case 0: VFEM_Q2GSN(0, 0, 0); break;
+            case 1: VFEM_Q2GSN(0, 0, 1); break;
+            case 2: VFEM_Q2GSN(0, 1, 0); break;
+            case 3: VFEM_Q2GSN(0, 1, 1); break;
+            case 4: VFEM_Q2GSN(1, 0, 0); break;
+            case 5: VFEM_Q2GSN(1, 0, 1); break;
+            case 6: VFEM_Q2GSN(1, 1, 0); break;
+            default: VFEM_Q2GSN(1, 1, 1);
+        }
+#undef VFEM_Q2GSN
+    }
+    VFEM_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Level 1 of the degree-2 hierarchy without stored element matrices.  The Galerkin matrix of a level-1 element is
 // Ke = sum_f E_f cK0[f] over its eight children (buildPESCoarse, MG.hh:604-669, with cK0[f] = I_f^T K0 I_f constant); stored it
 // is 81 x 81 doubles = 52 KB per element -- 110 GB at 256^3 fine elements, read once per sweep.  Here a thread owns a node as

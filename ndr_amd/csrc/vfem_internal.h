@@ -173,6 +173,10 @@ void launch_gs_sweep_q2_level1(int nx, int ny, int nz, const double *cK0, const 
                                const uint8_t *mask, int forward, hipStream_t s, int first = 0, int count = 27);
 void launch_apply_q2_level1(int nx, int ny, int nz, const double *cK0, const double *Ef, int fx0, const double *u, const double *b,
                             const uint8_t *mask, int mode, double *out, hipStream_t s);
+// the same sweep ordered by neighbour node (each distinct neighbour read once); tab from build_q2_gs_table
+void build_q2_gs_table(const double *K0_host, std::vector<double> &tab);
+void launch_gs_sweep_q2_level0_nodes(int nx, int ny, int nz, const double *tab, const double *E, double *u, const double *b,
+                                     const uint8_t *mask, int forward, hipStream_t s, int first = 0, int count = 27);
 void launch_q2_residual_fix(long long nn, const double *b, const uint8_t *mask, int mode, double *out, hipStream_t s);
 void launch_gradient_q2(int nx, int ny, int nz, const double *K0, const double *rho, double E0, double Emin, double gamma,
                         const double *u, double *g, hipStream_t s);

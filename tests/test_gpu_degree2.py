@@ -119,3 +119,34 @@ def test_q2_level1_on_the_fly_equals_stored_element_matrices(ne, levels):
     assert max(abs(p - q) / p for p, q in zip(got[0][6], got[1][6])) < 1e-8
     with pytest.raises(RuntimeError):
         _lib.check(lib.vfem_gsim_set_option(t._h, 14, 3))
+
+
+def test_q2_finest_level_sweep_orders_agree():
+    """VFEM_OPT_Q2_GS_IMPL: the sweep ordered by neighbour node (each distinct neighbour read once) against the element-by-element
+    gather and against the dense gather kernels of the generic path, forward and backward, on a grid with every colour class and
+    Dirichlet nodes"""
+    import torch
+    from helpers import BC_CANTILEVER
+    from ndr_amd import _lib, pyVoxelFEM as pv
+    lib = _lib.load()
+    t = pv.TensorProductSimulator([2, 2, 2], ([0, 0, 0], [2, 1, 1]), [6, 4, 10])
+    t.readMaterial(MATERIAL)
+    t.applyDisplacementsAndLoadsFromFile(BC_CANTILEVER)
+    t.E_min = 1e-4
+    g = torch.Generator(device="cuda").manual_seed(9)
+    t.setElementDensities(torch.rand(t.numElements(), dtype=torch.float64, device="cuda", generator=g))
+    mg = t.multigridSolver(1)
+    mg.updateElementStiffnessMatrices()
+    u = torch.randn((t.numNodes(), 3), dtype=torch.float64, device="cuda", generator=g)
+    b = torch.randn((t.numNodes(), 3), dtype=torch.float64, device="cuda", generator=g)
+    got = {}
+    for name, opts in (("nodes", ((16, 1),)), ("elements", ((16, 0),)), ("dense", ((6, 1),))):
+        for k, v in opts:
+            _lib.check(lib.vfem_gsim_set_option(t._h, k, v))
+        got[name] = (mg.smoothing_device(0, u, b, True), mg.smoothing_device(0, u, b, False))
+        _lib.check(lib.vfem_gsim_set_option(t._h, 6, 0))
+        _lib.check(lib.vfem_gsim_set_option(t._h, 16, 1))
+    for w in (0, 1):
+        scale = float(got["dense"][w].abs().max())
+        assert float((got["nodes"][w] - got["dense"][w]).abs().max()) < 1e-12 * scale
+        assert float((got["nodes"][w] - got["elements"][w]).abs().max()) < 1e-13 * scale
