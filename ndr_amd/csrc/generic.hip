@@ -575,7 +575,7 @@ struct vfem_gsim {
     DevBuf<double> dK0, rho, E, dvals;
     DevBuf<double> q2tab;                          // degree-2 hexahedra: packed mode-space blocks (q2_modes.h)
     DevBuf<double> q2gstab;                        // ... and K0 regrouped for the finest-level sweep ordered by neighbour node
-    int q2_gs_impl = 1;                            // vfem_gsim_set_option(16, v): finest-level sweep 0 by element, 1 by neighbour node
+    int q2_gs_impl = 2;                            // vfem_gsim_set_option(16, v): finest-level sweep 0 by element, 1 by neighbour node, 2 the same with the neighbour rows staged through LDS
     bool q2_fast = false;
     int q2_l1_virtual = 2;                         // vfem_gsim_set_option(14, v): level 1 of a degree-2 hierarchy 0 stored, 1 virtual, 2 by size
     int q2_impl = 0;                               // vfem_gsim_set_option(6, v): 0 marching kernel (mode space), 1 dense gather kernel (cross-check), 2 pencil kernel
@@ -770,8 +770,9 @@ static void gmg_smooth(vfem_gmg *mg, int l, double *u, const double *b, int forw
     const GDims &d = mg->lv[l].d;
     if (count < 0) count = 27;
     if (l == 0 && mg->external_ke_level != 0 && d.N == 3 && d.p == 2 && mg->fine->q2_impl != 1) {  // finest degree-2 level: thread per node
-        if (mg->fine->q2_gs_impl == 1)
-            launch_gs_sweep_q2_level0_nodes(d.ne[0], d.ne[1], d.ne[2], mg->fine->q2gstab.p, mg->fine->E_local(), u, b, mg->lv[0].mask.p, forward, s, first, count);
+        if (mg->fine->q2_gs_impl >= 1)
+            launch_gs_sweep_q2_level0_nodes(d.ne[0], d.ne[1], d.ne[2], mg->fine->q2gstab.p, mg->fine->E_local(), u, b, mg->lv[0].mask.p, forward, s, first, count,
+                                            mg->fine->q2_gs_impl == 2);
         else
             launch_gs_sweep_q2_level0(d.ne[0], d.ne[1], d.ne[2], mg->fine->dK0.p, mg->fine->E_local(), u, b, mg->lv[0].mask.p, forward, s, first, count);
         return;
@@ -1134,7 +1135,7 @@ int vfem_gsim_set_option(vfem_gsim *sim, int key, int value) {
     G_TRY
     if (key == 6 && value >= 0 && value <= 2) sim->q2_impl = value;
     else if (key == 14 && value >= 0 && value <= 2) sim->q2_l1_virtual = value;
-    else if (key == 16 && (value == 0 || value == 1)) sim->q2_gs_impl = value;
+    else if (key == 16 && value >= 0 && value <= 2) sim->q2_gs_impl = value;
     else throw Error("unknown option or value out of range");
     G_CATCH
 }

@@ -838,8 +838,121 @@ __global__ void __launch_bounds__(256) k_gs_q2_level0_nodes(DimsQ2 d, Q2Color co
     for (int cc = 0; cc < 3; ++cc) u[3 * n + cc] += ud[cc];
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The neighbour-node sweep with the neighbour ROWS staged through LDS.  A wave relaxes 64 nodes of one colour in a z-row; they
+// are 2 or 4 nodes apart, so every load of k_gs_q2_level0_nodes fetches 8 of 128 bytes per cache line it touches and a vertex
+// node costs 263 such instructions.  Here the wave copies each of its (up to 25) neighbour rows once, as one contiguous run
+// (the z-extent of its 64 nodes plus the stencil reach: 771 doubles at most, 13 coalesced 8-byte loads per lane), into its
+// own LDS buffer and the lanes pick their three to five neighbours of that row from there; the next row's loads are in flight
+// while the current row is used.  The image is padded by one double per lane stride (13 or 7 doubles between lanes: two-way
+// bank conflicts instead of sixteen-way).  No block-level synchronisation: a wave only reads what it wrote itself, and the
+// LDS queue of a wave is in order.
+// ------------------------------------------------------------------------------------------------------
+template <int PX, int PY, int PZ>
+__global__ void __launch_bounds__(256) k_gs_q2_level0_rows(DimsQ2 d, Q2Color col, const double *__restrict__ tabc, const double *__restrict__ E,
+                                                           double *__restrict__ u, const double *__restrict__ b,
+                                                           const uint8_t *__restrict__ mask, int forward) {
+    constexpr int SZ = PZ ? 2 : 4, R = PZ ? 1 : 2, NOZ = 2 * R + 1;           // lane stride in nodes, stencil reach, neighbours per row
+    constexpr int SPAN3 = 3 * (63 * SZ + NOZ), NLD = (SPAN3 + 63) / 64;          // doubles of a row segment, loads per lane
+    constexpr int IMG = SPAN3 + SPAN3 / (3 * SZ) + 2;                            // padded image: one double of padding per 3 SZ doubles
+    constexpr int NROWS = q2a_noff(PX) * q2a_noff(PY), NG = q2_ngroups(PX, PY, PZ);
+    __shared__ double img[4][2][IMG];
+    const int lane = threadIdx.x, w = threadIdx.y;
+    const int bq = blockIdx.y * 4 + w, a = blockIdx.z;
+    if (bq >= col.cnt[1] || a >= col.cnt[0]) return;                             // (whole wave)
+    const int c = blockIdx.x * 64 + lane;
+    const bool live = c < col.cnt[2];
+    const int i = col.start[0] + a * col.inc[0], j = col.start[1] + bq * col.inc[1];
+    const int k = col.start[2] + (live ? c : col.cnt[2] - 1) * col.inc[2];
+    const int kseg = col.start[2] + blockIdx.x * 64 * col.inc[2] - R;          // first node of the staged segment (may be < 0: clamped loads)
+    double Ee[8];
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+        const int sx = (sl >> 2) & 1, sy = (sl >> 1) & 1, sz = sl & 1;
+        const int ex = PX ? i / 2 : i / 2 - 1 + sx, ey = PY ? j / 2 : j / 2 - 1 + sy, ez = PZ ? k / 2 : k / 2 - 1 + sz;
+        const bool used = (!PX || sx == 0) && (!PY || sy == 0) && (!PZ || sz == 0);
+        const bool ok = used && ex >= 0 && ex < d.nx && ey >= 0 && ey < d.ny && ez >= 0 && ez < d.nz;
+        Ee[sl] = ok ? E[((long long) ex * d.ny + ey) * d.nz + ez] : 0.0;
+    }
+    double stage[NLD];
+    // row rho = (ix, iy) of the neighbour enumeration; rows outside the grid are read at the clamped row (their elements have
+    // modulus 0, any finite value will do)
+    auto load_row = [&](int rho) {
+        const int ox = q2a_off(PX, rho / q2a_noff(PY)), oy = q2a_off(PY, rho % q2a_noff(PY));
+        const int ni = min(max(i + ox, 0), d.NX - 1), nj = min(max(j + oy, 0), d.NY - 1);
+        const double *row = u + 3 * (((long long) ni * d.NY + nj) * d.NZ);
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int q = m * 64 + lane;
+            const int gz = min(max(3 * kseg + q, 0), 3 * d.NZ - 1);
+            stage[m] = row[gz];
+        }
+    };
+    auto store_row = [&](int buf) {
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int q = m * 64 + lane;
+            if (q < SPAN3) img[w][buf][q + q / (3 * SZ)] = stage[m];
+        }
+    };
+    load_row(0);
+    store_row(0);
+    double t[8][3], cf[Q2N_AHEAD + 1][9], uv[Q2N_AHEAD + 1][3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e][0] = t[e][1] = t[e][2] = 0.0;
+    static_for<NG + Q2N_AHEAD>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g < NG) {                                              // request group g ...
+#pragma unroll
+            for (int q = 0; q < 9; ++q) cf[g % (Q2N_AHEAD + 1)][q] = tabc[9 * g + q];
+            constexpr Q2Grp G = q2_group(PX, PY, PZ, g);
+            constexpr int rho = G.nb / NOZ, tz = G.nb % NOZ;
+            if constexpr (G.first && tz == 0 && rho + 1 < NROWS) load_row(rho + 1);   // next row: in flight while this one is used
+            if constexpr (G.first) {                                         // ... and the values of its neighbour node, from the image
+                const double *src = &img[w][rho & 1][3 * (lane * SZ + tz) + lane + tz / SZ];
+                uv[G.nb % (Q2N_AHEAD + 1)][0] = src[0]; uv[G.nb % (Q2N_AHEAD + 1)][1] = src[1]; uv[G.nb % (Q2N_AHEAD + 1)][2] = src[2];
+            }
+            // the last neighbour of the row has been read: the other buffer (row rho - 1, fully consumed) takes the next row
+            if constexpr (G.last && tz == NOZ - 1 && rho + 1 < NROWS) store_row((rho + 1) & 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g >= Q2N_AHEAD) {                                      // use group g - AHEAD
+            constexpr int gg = g - Q2N_AHEAD;
+            constexpr Q2Grp G = q2_group(PX, PY, PZ, gg);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                t[G.e][r] = fma(cf[gg % (Q2N_AHEAD + 1)][3 * r], uv[G.nb % (Q2N_AHEAD + 1)][0],
+                                fma(cf[gg % (Q2N_AHEAD + 1)][3 * r + 1], uv[G.nb % (Q2N_AHEAD + 1)][1],
+                                    fma(cf[gg % (Q2N_AHEAD + 1)][3 * r + 2], uv[G.nb % (Q2N_AHEAD + 1)][2], t[G.e][r])));
+            asm volatile("" : "+v"(t[G.e][0]), "+v"(t[G.e][1]), "+v"(t[G.e][2]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    constexpr int G0 = q2_center_group(PX, PY, PZ);
+    double S[3] = {0.0, 0.0, 0.0}, M[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) M[q] = 0.0;
+    static_for<q2a_nopt(PX, 0) * q2a_nopt(PY, 0) * q2a_nopt(PZ, 0)>([&](auto wc) {
+        constexpr Q2Grp G = q2_group(PX, PY, PZ, G0 + decltype(wc)::value);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) M[q] = fma(Ee[G.e], tabc[9 * (G0 + decltype(wc)::value) + q], M[q]);
+    });
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) S[r] = fma(Ee[e], t[e][r], S[r]);
+    if (!live) return;
+    const long long n = ((long long) i * d.NY + j) * d.NZ + k;
+    double bms[3], ud[3];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) bms[cc] = b[3 * n + cc] - S[cc];
+    gs_solve(bms, M, mask ? mask[n] : (uint8_t) 0, forward != 0, ud);
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) u[3 * n + cc] += ud[cc];
+}
+
 void launch_gs_sweep_q2_level0_nodes(int nx, int ny, int nz, const double *tab, const double *E, double *u, const double *b,
-                                     const uint8_t *mask, int forward, hipStream_t s, int first, int count) {
+                                     const uint8_t *mask, int forward, hipStream_t s, int first, int count, int rows_in_lds) {
     DimsQ2 d{nx, ny, nz, 2 * nx + 1, 2 * ny + 1, 2 * nz + 1};
     const int NN[3] = {d.NX, d.NY, d.NZ};
     for (int ci = first; ci < (first + count < 27 ? first + count : 27); ++ci) {
@@ -857,7 +970,8 @@ void launch_gs_sweep_q2_level0_nodes(int nx, int ny, int nz, const double *tab, 
         const dim3 grd((col.cnt[2] + 63) / 64, (col.cnt[1] + 3) / 4, col.cnt[0]), blk(64, 4, 1);
         const int cls = 4 * (l[0] & 1) + 2 * (l[1] & 1) + (l[2] & 1);
         const double *tc = tab + q2_table_offset(cls);
-#define VFEM_Q2GSN(X, Y, Z) k_gs_q2_level0_nodes<X, Y, Z><<<grd, blk, 0, s>>>(d, col, tc, E, u, b, mask, forward)
+#define VFEM_Q2GSN(X, Y, Z) do { if (rows_in_lds) k_gs_q2_level0_rows<X, Y, Z><<<grd, blk, 0, s>>>(d, col, tc, E, u, b, mask, forward); \
+                                else k_gs_q2_level0_nodes<X, Y, Z><<<grd, blk, 0, s>>>(d, col, tc, E, u, b, mask, forward); } while (0)
         switch (cls) {
             case 0: VFEM_Q2GSN(0, 0, 0); break;
             case 1: VFEM_Q2GSN(0, 0, 1); break;

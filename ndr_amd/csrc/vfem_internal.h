@@ -176,7 +176,7 @@ void launch_apply_q2_level1(int nx, int ny, int nz, const double *cK0, const dou
 // the same sweep ordered by neighbour node (each distinct neighbour read once); tab from build_q2_gs_table
 void build_q2_gs_table(const double *K0_host, std::vector<double> &tab);
 void launch_gs_sweep_q2_level0_nodes(int nx, int ny, int nz, const double *tab, const double *E, double *u, const double *b,
-                                     const uint8_t *mask, int forward, hipStream_t s, int first = 0, int count = 27);
+                                     const uint8_t *mask, int forward, hipStream_t s, int first = 0, int count = 27, int rows_in_lds = 0);
 void launch_q2_residual_fix(long long nn, const double *b, const uint8_t *mask, int mode, double *out, hipStream_t s);
 void launch_gradient_q2(int nx, int ny, int nz, const double *K0, const double *rho, double E0, double Emin, double gamma,
                         const double *u, double *g, hipStream_t s);
