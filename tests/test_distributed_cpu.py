@@ -124,3 +124,50 @@ def test_partition_properties():
         assert planes == 513
     with pytest.raises(RuntimeError):
         SlabPartition((6, 4, 4), 4, 0, align=2)
+
+
+def _halo4_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ndr_amd import distributed as vd
+    from ndr_amd.distributed_q2 import G, P, _LevelGeomQ2
+    ne = (8 * world, 2, 3)
+    part = vd.SlabPartition(ne, world, rank, align=4)
+    g = _LevelGeomQ2(part, 0, 1, ne)
+    # every global node plane carries its own index; ghost planes start poisoned
+    field = torch.empty((g.n_planes * g.plane, 3), dtype=torch.float64)
+    v = field.view(g.n_planes, -1)
+    for pl in range(g.n_planes):
+        v[pl] = float(g.xoffn + pl)
+    if g.gl:
+        v[:g.first_owned] = -1e30
+    if g.gr:
+        v[g.last_owned + 1:] = 1e30
+    vd.HaloExchanger(g).exchange(field)          # CPU tensors: the plane views go out as they are (the path RCCL takes)
+    want = torch.arange(g.xoffn, g.xoffn + g.n_planes, dtype=torch.float64)
+    ok = bool(torch.equal(v[:, 0], want)) and bool(torch.equal(v.min(dim=1).values, want))
+    ones = torch.ones_like(field)
+    cnt = float(vd.HaloExchanger(g).dot(ones, ones).item())       # every global node counted once
+    q.put((rank, ok, g.halo_width == P * G, cnt, 3.0 * (P * ne[0] + 1) * g.plane))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_four_plane_halo_of_the_degree2_slabs(world):
+    """the degree-2 slab geometry (two ghost element layers = four ghost node planes per neighbour) through the same
+    HaloExchanger: ghost planes receive the neighbours' owned planes, reductions count every plane once"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() % 500) + world
+    procs = [ctx.Process(target=_halo4_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok, width_ok, cnt, total in res:
+        assert ok and width_ok, rank
+        assert cnt == total, (cnt, total)
