@@ -465,6 +465,34 @@ __device__ __forceinline__ long long g_child(const GDims &f, const GDims &c, lon
     return e;
 }
 
+// Level 2 of the degree-2 hierarchy straight from the fine moduli when level 1 is virtual: Ke2 = sum_g I_g^T (sum_f E_{g,f} cK0[f]) I_g
+//   = sum_{g,f} E_{g,f} c2K0[g][f],   c2K0[g][f] = I_g^T cK0[f] I_g  (64 constant 81 x 81 matrices, built on the host).
+// A lane owns one level-2 element and keeps its 64 fine moduli in registers; the 64 constants of an entry q are the same for
+// every lane and arrive by scalar loads (table laid out [q][64]); 64 multiply-adds per entry, the entry stored per lane.
+// Replaces forming level-1 matrices in a scratch buffer and coarsening them (206 of 3200 ms of a 256^3 solve).
+__global__ void __launch_bounds__(256) kg_coarsen_level2_q2(GDims f0, GDims c2, const double *__restrict__ tab /* [6561][64] */,
+                                                            const double *__restrict__ Ef, double *__restrict__ Kec) {
+    const long long e2 = (long long) blockIdx.x * 256 + threadIdx.x;
+    const bool live = e2 < c2.nelems;
+    const long long ee = live ? e2 : c2.nelems - 1;
+    const int z2 = (int) (ee % c2.ne[2]), y2 = (int) ((ee / c2.ne[2]) % c2.ne[1]), x2 = (int) (ee / ((long long) c2.ne[2] * c2.ne[1]));
+    double E[64];                                            // index 8 g + f, child bits as g_child: bit a = upper half along axis a (bit 0: x)
+#pragma unroll
+    for (int q = 0; q < 64; ++q) {
+        const int g = q >> 3, f = q & 7;
+        const int fx = 4 * x2 + 2 * (g & 1) + (f & 1), fy = 4 * y2 + 2 * ((g >> 1) & 1) + ((f >> 1) & 1), fz = 4 * z2 + 2 * ((g >> 2) & 1) + ((f >> 2) & 1);
+        E[q] = Ef[((long long) fx * f0.ne[1] + fy) * f0.ne[2] + fz];
+    }
+    double *dst = Kec + (size_t) ee * 6561;
+    for (int q = 0; q < 6561; ++q) {
+        const double *c = tab + (size_t) q * 64;
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int t = 0; t < 64; t += 2) { acc0 = fma(E[t], c[t], acc0); acc1 = fma(E[t + 1], c[t + 1], acc1); }
+        if (live) dst[q] = acc0 + acc1;
+    }
+}
+
 // level 1: Ke_c = sum_f E_f * cK0[f]
 __global__ void __launch_bounds__(256) kg_coarsen_first(GDims f, GDims c, const double *__restrict__ cK0,
                                                         const double *__restrict__ Ef, double *__restrict__ Kec) {
@@ -614,10 +642,10 @@ struct vfem_gmg {
     int first_active = 0;              // replicated coarse hierarchy: levels below hold no fields or operators
     int external_ke_level = -1;        // element matrices of this level were imported (vfem_gmg_import_level_ke)
     bool l1_virtual = false;           // degree 2: level 1 applies sum_f E_f cK0[f] on the fly, lv[1].Ke is not stored
-    DevBuf<double> ke_scratch;         // ... and its matrices exist a few layers at a time while level 2 is built from them
     std::vector<GLevel> lv;
     GWeights W;
     DevBuf<double> cK0, phi, Ainv, pr, pd, pAd, ps, scal, scratch;
+    DevBuf<double> c2tab;              // degree-2 hexahedra: c2K0[g][f] = I_g^T cK0[f] I_g as [entry][64] (level 2 straight from the moduli)
     DevBuf<double> l1tab;              // degree-2 hexahedra: cK0 regrouped for k_q2_level1, [ln][m][f][r][c]
     DevBuf<int> info;
     void *rocblas = nullptr;
@@ -873,23 +901,16 @@ static GDims stored_dims(const vfem_gmg *mg, int l) {
     return make_gdims(lv.d.N, lv.d.p, ne);
 }
 
-// Element matrices of `count` x-layers of level 2, starting at stored layer `first2`, when level 1 is virtual: the level-1
-// matrices of two level-2 layers' worth of children are formed in a scratch buffer, coarsened, and overwritten by the next chunk
+// Element matrices of `count` x-layers of level 2, starting at stored layer `first2`, when level 1 is virtual: straight from
+// the fine moduli (kg_coarsen_level2_q2)
 static void coarsen_through_virtual_level1(vfem_gmg *mg, long long first2, long long count, double *out, hipStream_t s) {
-    const GDims d0 = stored_dims(mg, 0), d1 = stored_dims(mg, 1), d2 = stored_dims(mg, 2);
-    const size_t kk = (size_t) d1.ke * d1.ke;
-    const long long layer0 = (long long) d0.ne[1] * d0.ne[2], layer1 = (long long) d1.ne[1] * d1.ne[2], layer2 = (long long) d2.ne[1] * d2.ne[2];
-    long long chunk = (long long) ((size_t) 1 << 31) / (long long) (2 * layer1 * kk * sizeof(double));      // ~2 GB of level-1 matrices
-    if (chunk < 1) chunk = 1;
-    if (chunk > count) chunk = count;
-    mg->ke_scratch.alloc((size_t) (2 * chunk * layer1) * kk);
-    for (long long c0 = 0; c0 < count; c0 += chunk) {
-        const long long n2 = std::min(chunk, count - c0);
-        const long long ne2[3] = {n2, d2.ne[1], d2.ne[2]}, ne1[3] = {2 * n2, d1.ne[1], d1.ne[2]}, ne0[3] = {4 * n2, d0.ne[1], d0.ne[2]};
-        const GDims c2 = make_gdims(3, 2, ne2), c1 = make_gdims(3, 2, ne1), c0d = make_gdims(3, 2, ne0);
-        g_coarsen(mg, c0d, c1, true, mg->fine->E.p + (size_t) (4 * (first2 + c0)) * layer0, mg->ke_scratch.p, s);
-        g_coarsen(mg, c1, c2, false, mg->ke_scratch.p, out + (size_t) (c0 * layer2) * kk, s);
-    }
+    const GDims d0 = stored_dims(mg, 0), d2 = stored_dims(mg, 2);
+    if (count <= 0) return;
+    const long long ne2[3] = {count, d2.ne[1], d2.ne[2]}, ne0[3] = {4 * count, d0.ne[1], d0.ne[2]};
+    const GDims c2 = make_gdims(3, 2, ne2), c0 = make_gdims(3, 2, ne0);
+    const long long layer0 = (long long) d0.ne[1] * d0.ne[2];
+    kg_coarsen_level2_q2<<<dim3((unsigned) ((c2.nelems + 255) / 256)), dim3(256), 0, s>>>(c0, c2, mg->c2tab.p, mg->fine->E.p + (size_t) (4 * first2) * layer0, out);
+    VFEM_HIP(hipGetLastError());
 }
 
 static void gmg_update(vfem_gmg *mg, hipStream_t s) {
@@ -1219,6 +1240,32 @@ static void gmg_setup_transfer_tables(vfem_gmg *mg) {
                             tab[((size_t) (ln * 27 + m) * 8 + f) * 9 + 3 * r + c] = cK0[(size_t) f * 6561 + (size_t) (3 * ln + r) * 81 + 3 * m + c];
         mg->l1tab.alloc(tab.size());
         VFEM_HIP(hipMemcpy(mg->l1tab.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (N == 3 && p == 2) {
+        // c2K0[g][f] = I_g^T cK0[f] I_g, stored [entry][8 g + f] for kg_coarsen_level2_q2
+        std::vector<double> t2((size_t) 6561 * 64), T2((size_t) ke * ke);
+        for (int g = 0; g < 8; ++g) {
+            const double *ph = phi.data() + (size_t) g * npe * npe;
+            for (int f = 0; f < 8; ++f) {
+                const double *A = cK0.data() + (size_t) f * ke * ke;
+                for (int i = 0; i < ke; ++i)
+                    for (int j = 0; j < ke; ++j) {
+                        const int m = j / N, b = j % N;
+                        double v = 0.0;
+                        for (int qn = 0; qn < npe; ++qn) v += A[(size_t) i * ke + N * qn + b] * ph[qn * npe + m];
+                        T2[(size_t) i * ke + j] = v;
+                    }
+                for (int i = 0; i < ke; ++i)
+                    for (int j = 0; j < ke; ++j) {
+                        const int n = i / N, a = i % N;
+                        double v = 0.0;
+                        for (int pn = 0; pn < npe; ++pn) v += ph[pn * npe + n] * T2[(size_t) (N * pn + a) * ke + j];
+                        t2[((size_t) i * ke + j) * 64 + 8 * g + f] = v;
+                    }
+            }
+        }
+        mg->c2tab.alloc(t2.size());
+        VFEM_HIP(hipMemcpy(mg->c2tab.p, t2.data(), t2.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     mg->phi.alloc(phi.size()); mg->cK0.alloc(cK0.size());
     VFEM_HIP(hipMemcpy(mg->phi.p, phi.data(), phi.size() * sizeof(double), hipMemcpyHostToDevice));
