@@ -763,7 +763,13 @@ void build_q2_gs_table(const double *K0, std::vector<double> &tab) {
     }
 }
 
-constexpr int Q2N_AHEAD = 3;
+#ifndef VFEM_Q2N_AHEAD
+#define VFEM_Q2N_AHEAD 3
+#endif
+#ifndef VFEM_Q2ROWS_WAVES
+#define VFEM_Q2ROWS_WAVES 4            // waves (z-rows of nodes) per block of k_gs_q2_level0_rows: LDS per block = waves x 13.4 KB
+#endif
+constexpr int Q2N_AHEAD = VFEM_Q2N_AHEAD;
 template <int PX, int PY, int PZ>
 __global__ void __launch_bounds__(256) k_gs_q2_level0_nodes(DimsQ2 d, Q2Color col, const double *__restrict__ tabc, const double *__restrict__ E,
                                                             double *__restrict__ u, const double *__restrict__ b,
@@ -856,9 +862,9 @@ __global__ void __launch_bounds__(256) k_gs_q2_level0_rows(DimsQ2 d, Q2Color col
     constexpr int SPAN3 = 3 * (63 * SZ + NOZ), NLD = (SPAN3 + 63) / 64;          // doubles of a row segment, loads per lane
     constexpr int IMG = SPAN3 + SPAN3 / (3 * SZ) + 2;                            // padded image: one double of padding per 3 SZ doubles
     constexpr int NROWS = q2a_noff(PX) * q2a_noff(PY), NG = q2_ngroups(PX, PY, PZ);
-    __shared__ double img[4][2][IMG];
+    __shared__ double img[VFEM_Q2ROWS_WAVES][2][IMG];
     const int lane = threadIdx.x, w = threadIdx.y;
-    const int bq = blockIdx.y * 4 + w, a = blockIdx.z;
+    const int bq = blockIdx.y * VFEM_Q2ROWS_WAVES + w, a = blockIdx.z;
     if (bq >= col.cnt[1] || a >= col.cnt[0]) return;                             // (whole wave)
     const int c = blockIdx.x * 64 + lane;
     const bool live = c < col.cnt[2];
@@ -970,7 +976,8 @@ void launch_gs_sweep_q2_level0_nodes(int nx, int ny, int nz, const double *tab, 
         const dim3 grd((col.cnt[2] + 63) / 64, (col.cnt[1] + 3) / 4, col.cnt[0]), blk(64, 4, 1);
         const int cls = 4 * (l[0] & 1) + 2 * (l[1] & 1) + (l[2] & 1);
         const double *tc = tab + q2_table_offset(cls);
-#define VFEM_Q2GSN(X, Y, Z) do { if (rows_in_lds) k_gs_q2_level0_rows<X, Y, Z><<<grd, blk, 0, s>>>(d, col, tc, E, u, b, mask, forward); \
+        const dim3 grdr((col.cnt[2] + 63) / 64, (col.cnt[1] + VFEM_Q2ROWS_WAVES - 1) / VFEM_Q2ROWS_WAVES, col.cnt[0]), blkr(64, VFEM_Q2ROWS_WAVES, 1);
+#define VFEM_Q2GSN(X, Y, Z) do { if (rows_in_lds) k_gs_q2_level0_rows<X, Y, Z><<<grdr, blkr, 0, s>>>(d, col, tc, E, u, b, mask, forward); \
                                 else k_gs_q2_level0_nodes<X, Y, Z><<<grd, blk, 0, s>>>(d, col, tc, E, u, b, mask, forward); } while (0)
         switch (cls) {
             case 0: VFEM_Q2GSN(0, 0, 0); break;
@@ -1011,7 +1018,10 @@ struct Q2L1 {
 // VGPR lanes (1.9 k v_writelane + 1.9 k v_readlane per element, more issue slots than the multiply-adds).  The groups are
 // therefore requested Q2L1_AHEAD groups before their use and scheduling barriers keep requests and uses in that order: at most
 // (Q2L1_AHEAD + 1) x 18 SGPRs of coefficients are live.
-constexpr int Q2L1_AHEAD = 3;
+#ifndef VFEM_Q2L1_AHEAD
+#define VFEM_Q2L1_AHEAD 3
+#endif
+constexpr int Q2L1_AHEAD = VFEM_Q2L1_AHEAD;
 
 // contribution of one incident element (ex, ey, ez), in which the node has local index ln (uniform over the wave), to S and M
 __device__ __forceinline__ void q2l1_element(const Q2L1 &a, const double *__restrict__ u, int ex, int ey, int ez, int ln, double S[3], double M[9]) {
