@@ -58,6 +58,7 @@ enum {
     VFEM_OPT_GS_RESIDENT  = 13,  /* level-0 Gauss-Seidel: K0 held in SGPRs (1, when K0 has the 36-value structure) or coefficient table (0) */
     VFEM_OPT_Q2_GS_IMPL   = 16,  /* vfem_gsim: finest-level degree-2 sweep 0 element by element, 1 neighbour node by neighbour node, 2 the same with
                                     the neighbour rows staged through LDS by coalesced loads (default) */
+    VFEM_OPT_TRANSFER_AXIS = 17, /* vfem_gsim: restriction / interpolation of 3-D levels above 100 k nodes axis by axis (1, default) or in one pass (0) */
     VFEM_OPT_Q2_L1_VIRTUAL = 14  /* vfem_gsim: level 1 of a degree-2 hierarchy evaluated as sum_f E_f cK0[f] on the fly (1), from stored 81 x 81
                                     element matrices (0), or chosen by their size (2, default: on the fly above 32 GB); read by the next
                                     vfem_gmg_update_operators */

@@ -51,6 +51,7 @@ struct DevBuf {
         VFEM_HIP(hipMalloc((void **) &p, count * sizeof(T)));
         n = count;
     }
+    void reserve(size_t count) { if (!(p && n >= count)) alloc(count); }          // scratch: grows, never shrinks
     void zero(hipStream_t s) { if (p) VFEM_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
 };
 

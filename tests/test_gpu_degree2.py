@@ -152,3 +152,27 @@ def test_q2_finest_level_sweep_orders_agree(ne):
         assert float((got["nodes"][w] - got["dense"][w]).abs().max()) < 1e-12 * scale
         assert float((got["nodes"][w] - got["elements"][w]).abs().max()) < 1e-13 * scale
         assert float((got["rows"][w] - got["elements"][w]).abs().max()) < 1e-13 * scale
+
+
+def test_q2_axis_by_axis_transfers_equal_the_single_pass():
+    """VFEM_OPT_TRANSFER_AXIS: restriction and interpolation as three one-dimensional passes (levels above 100 k nodes) against
+    the single-pass gathers, plus the adjoint relation <R r, c> = <r, P c> between the two"""
+    import torch
+    from ndr_amd import _lib, pyVoxelFEM as pv
+    lib = _lib.load()
+    t = pv.TensorProductSimulator([2, 2, 2], ([0, 0, 0], [1.0, 0.8, 1.2]), [24, 20, 36])      # 49 x 41 x 73 = 147 k nodes
+    t.readMaterial(MATERIAL)
+    mg = t.multigridSolver(2)
+    g = torch.Generator(device="cuda").manual_seed(21)
+    r = torch.randn((mg._nn(0), 3), dtype=torch.float64, device="cuda", generator=g)
+    c = torch.randn((mg._nn(1), 3), dtype=torch.float64, device="cuda", generator=g)
+    base = torch.randn((mg._nn(0), 3), dtype=torch.float64, device="cuda", generator=g)
+    got = {}
+    for mode in (1, 0):
+        _lib.check(lib.vfem_gsim_set_option(t._h, 17, mode))
+        got[mode] = (mg.restriction_device(0, r), mg.interpolation_device(0, c), mg.interpolation_device(0, c, out=base.clone()))
+    _lib.check(lib.vfem_gsim_set_option(t._h, 17, 1))
+    for a, b in zip(got[1], got[0]):
+        assert float((a - b).abs().max()) < 1e-13 * float(b.abs().max())
+    lhs, rhs = float((got[1][0] * c).sum()), float((r * got[1][1]).sum())
+    assert abs(lhs - rhs) < 1e-11 * max(abs(lhs), abs(rhs), 1.0)

@@ -107,10 +107,11 @@ def test_q2_distributed_pcg_matches_single_process(world, ne, levels, min_ld):
         assert err < 1e-7 and gerr < 1e-7, (err, gerr)
 
 
-@pytest.mark.parametrize("world,ne,levels", [(2, (32, 8, 8), 3), (4, (64, 8, 8), 3)])
+@pytest.mark.parametrize("world,ne,levels", [(2, (32, 8, 8), 3), (4, (64, 8, 8), 3), (2, (32, 24, 40), 3)])
 def test_q2_distributed_pcg_with_sharded_densities(world, ne, levels):
     """no rank holds the whole density field: ghost / padding layers from the neighbours, the replicated hierarchy's first level
-    from an all-gather of the slabs' Galerkin matrices"""
+    from an all-gather of the slabs' Galerkin matrices.  (32, 24, 40): local grids above 100 k nodes, i.e. the axis-by-axis
+    transfers with the plane shift between the local grids of two levels"""
     for rank, Ld, it_d, it_s, comp, cg, err, gerr, herr in _run(world, ne, levels, True, 28600):
         assert Ld >= 1
         assert abs(it_d - it_s) <= 1, (it_d, it_s)          # equal unless the last residual sits on the tolerance
