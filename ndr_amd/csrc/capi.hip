@@ -957,29 +957,23 @@ int vfem_mlp_load_weights(vfem_mlp *m, const float *B, const float *W1, const fl
         d.alloc(n);
         if (n) VFEM_HIP(hipMemcpy(d.p, h, n * sizeof(float), hipMemcpyDefault));
     };
-    auto up16 = [](DevBuf<uint16_t> &d, const float *h, size_t n) {
-        d.alloc(n);
-        if (!n) return;
-        DevBuf<float> tmp; tmp.alloc(n);
-        VFEM_HIP(hipMemcpy(tmp.p, h, n * sizeof(float), hipMemcpyDefault));
-        launch_f32_to_f16((long long) n, tmp.p, d.p, nullptr);
-        VFEM_HIP(hipDeviceSynchronize());
-    };
+    // fp32 copies first (the reference-precision forward uses them); the fp16 operands and the transposed hidden weights are
+    // converted from those on the device: no temporary allocations, no device-wide synchronisation per training step
     up(m->B, B, (size_t) m->es * 3);
-    up(m->W1f, W1, (size_t) m->nn * 2 * m->es);            // fp32 copies for the reference-precision forward
+    up(m->W1f, W1, (size_t) m->nn * 2 * m->es);
     up(m->Whf, Wh, (size_t) nh * m->nn * m->nn);
-    up16(m->W1, W1, (size_t) m->nn * 2 * m->es);
-    up16(m->Wh, Wh, (size_t) nh * m->nn * m->nn);
+    m->W1.alloc((size_t) m->nn * 2 * m->es);
+    launch_f32_to_f16((long long) m->nn * 2 * m->es, m->W1f.p, m->W1.p, nullptr);
+    m->Wh.alloc((size_t) nh * m->nn * m->nn);
     m->WhT.alloc((size_t) nh * m->nn * m->nn);
     if (nh) {
-        DevBuf<float> tmp; tmp.alloc((size_t) nh * m->nn * m->nn);
-        VFEM_HIP(hipMemcpy(tmp.p, Wh, tmp.n * sizeof(float), hipMemcpyDefault));
+        launch_f32_to_f16((long long) nh * m->nn * m->nn, m->Whf.p, m->Wh.p, nullptr);
         for (int l = 0; l < nh; ++l)
-            launch_transpose_f32_to_f16(m->nn, m->nn, tmp.p + (size_t) l * m->nn * m->nn, m->WhT.p + (size_t) l * m->nn * m->nn, nullptr);
-        VFEM_HIP(hipDeviceSynchronize());
+            launch_transpose_f32_to_f16(m->nn, m->nn, m->Whf.p + (size_t) l * m->nn * m->nn, m->WhT.p + (size_t) l * m->nn * m->nn, nullptr);
     }
     up(m->bias, biases, (size_t) (nh + 1) * m->nn);
     up(m->wout, wout, (size_t) m->nn);
+    VFEM_HIP(hipStreamSynchronize(nullptr));      // the conversions ran on the null stream; consumers may launch on any stream
     m->bout = bout;
     m->loaded = true;
     VFEM_CATCH

@@ -641,6 +641,7 @@ struct vfem_gsim {
     double E0 = 1.0, Emin = 1e-9, gamma = 3.0;     // TPS.hh:1392-1394
     std::vector<double> K0;
     DevBuf<double> dK0, rho, E, dvals;
+    DevBuf<double> red;                            // scratch of the compliance reduction
     DevBuf<double> q2tab;                          // degree-2 hexahedra: packed mode-space blocks (q2_modes.h)
     DevBuf<double> q2gstab;                        // ... and K0 regrouped for the finest-level sweep ordered by neighbour node
     int transfer_axis = 1;                         // vfem_gsim_set_option(17, v): 3-D grid transfers axis by axis (1) or in one pass (0)
@@ -1244,8 +1245,8 @@ int vfem_gsim_compliance_gradient(const vfem_gsim *sim, const double *u, double 
 
 int vfem_gsim_compliance(const vfem_gsim *sim, const double *f, const double *u, double *value_host, void *stream) {
     G_TRY
-    DevBuf<double> tmp;
-    tmp.alloc(4096 + 1);
+    DevBuf<double> &tmp = const_cast<vfem_gsim *>(sim)->red;      // persistent reduction scratch (an allocation per call synchronises the device)
+    tmp.reserve(4096 + 1);
     launch_dot((long long) sim->d.N * sim->d.nnodes, f, u, tmp.p, tmp.p + 4096, GS(stream));
     double v = 0.0;
     VFEM_HIP(hipMemcpyAsync(&v, tmp.p + 4096, sizeof(double), hipMemcpyDeviceToHost, GS(stream)));
