@@ -100,10 +100,9 @@ template <int KIND, bool RES>
 __global__ void __launch_bounds__(256) k_apply_gather(Dims d, const double *__restrict__ K, const double *__restrict__ E,
                                                       const double *__restrict__ u, const double *__restrict__ b,
                                                       const uint8_t *__restrict__ mask, double *__restrict__ out) {
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    const int j = blockIdx.y * 4 + threadIdx.y;
-    const int i = blockIdx.z;
-    if (k >= d.NZ || j >= d.NY) return;
+    const int q = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x;       // lanes packed over the nodes of an x-plane (rows of 2^k + 1 nodes)
+    if (q >= d.NY * d.NZ) return;
+    const int j = q / d.NZ, k = q - j * d.NZ, i = blockIdx.z;
     double S[3], M[9];
     mf_node<KIND, false>(d, K, E, u, i, j, k, S, M);
     const long long n = nidx(d, i, j, k);
@@ -119,7 +118,7 @@ __global__ void __launch_bounds__(256) k_apply_gather(Dims d, const double *__re
 
 void launch_apply_gather(const Dims &d, OpKind kind, const double *K, const double *E, const double *u,
                          const double *b, const uint8_t *mask, int res, double *out, hipStream_t s) {
-    dim3 blk(64, 4, 1), grd((d.NZ + 63) / 64, (d.NY + 3) / 4, d.NX);
+    dim3 blk(64, 4, 1), grd((d.NY * d.NZ + 255) / 256, 1, d.NX);
     if (kind == OP_MF0) {
         if (res) k_apply_gather<0, true><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, out);
         else     k_apply_gather<0, false><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, out);
@@ -669,10 +668,14 @@ __global__ void __launch_bounds__(256, 4) k_gs_color_mf1_sym(Dims d, const doubl
                                                              const double *__restrict__ Mdiag, const double *__restrict__ E, double *__restrict__ u,
                                                              const double *__restrict__ b, const uint8_t *__restrict__ mask, int cx,
                                                              int cy, int cz, int forward) {
-    const int k = 2 * (blockIdx.x * 64 + threadIdx.x) + cz;
-    const int j = 2 * (blockIdx.y * 4 + threadIdx.y) + cy;
-    const int i = 2 * blockIdx.z + cx;
-    if (j >= d.NY || i >= d.NX) return;
+    // lanes are packed over the colour's nodes of an x-plane (row after row): a row of 2^k + 1 nodes has one even-colour node
+    // more than a whole number of waves, and a wave per row segment left every third (second) wave of such a row with a single
+    // useful lane doing the full 5184 multiply-adds
+    const int cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
+    const int q = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x;
+    if (q >= cnty * cntz) return;
+    const int jq = q / cntz;
+    const int k = 2 * (q - jq * cntz) + cz, j = 2 * jq + cy, i = 2 * blockIdx.z + cx;
     gs_node_mf1_sym(d, K0c, Dtab, Mdiag, E, u, b, mask, i, j, k, forward);
 }
 
@@ -724,7 +727,8 @@ void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const doubl
         if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab && res && d.nz >= 2) k_gs_rows_mf0<true><<<grd, blk, 0, s>>>(d, gs_tab + GS_TABLE_DOUBLES, E, u, b, mask, cx, cy, cz, forward);
         else if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab && d.nz >= 2) k_gs_rows_mf0<false><<<grd, blk, 0, s>>>(d, gs_tab, E, u, b, mask, cx, cy, cz, forward);
         else if (kind == OP_MF0) k_gs_color_mf<0><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
-        else if (g_mf1_sym && g_gs_variant == 0 && gs_tab) k_gs_color_mf1_sym<<<grd, blk, 0, s>>>(d, K, gs_tab, mdiag, E, u, b, mask, cx, cy, cz, forward);
+        else if (g_mf1_sym && g_gs_variant == 0 && gs_tab)
+            k_gs_color_mf1_sym<<<dim3((cnty * cntz + 255) / 256, 1, cntx), blk, 0, s>>>(d, K, gs_tab, mdiag, E, u, b, mask, cx, cy, cz, forward);
         else                k_gs_color_mf<1><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
     }
     VFEM_HIP(hipGetLastError());
@@ -846,10 +850,13 @@ void launch_apply_stencil(const Dims &d, const double *S, const double *u, const
 __global__ void __launch_bounds__(256) k_gs_color_stencil(Dims d, const double *__restrict__ St, double *__restrict__ u,
                                                           const double *__restrict__ b, const uint8_t *__restrict__ mask,
                                                           int cx, int cy, int cz, int forward) {
-    const int k = 2 * (blockIdx.x * 64 + threadIdx.x) + cz;
-    const int j = 2 * (blockIdx.y * 4 + threadIdx.y) + cy;
-    const int i = 2 * blockIdx.z + cx;
-    if (k >= d.NZ || j >= d.NY || i >= d.NX) return;
+    // lanes follow the colour-local node index of the stencil storage (cm_index): a wave is one 64-node tile, whole waves
+    // whatever the row length
+    const int cntx = (d.NX - 1 - cx) / 2 + 1, cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
+    const long long q = (long long) blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x;
+    if (q >= (long long) cntx * cnty * cntz) return;
+    const int iq = (int) (q / ((long long) cnty * cntz)), rem = (int) (q - (long long) iq * cnty * cntz), jq = rem / cntz;
+    const int i = 2 * iq + cx, j = 2 * jq + cy, k = 2 * (rem - jq * cntz) + cz;
     const long long n = nidx(d, i, j, k);
     // right-hand side and mask requested ahead of the stencil loads, the node's own value taken from the stencil centre: on the
     // small levels a launch lasts little more than its chain of dependent round trips
@@ -874,7 +881,7 @@ void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const do
         const int cx = ((lni >> 2) & 1) ^ (xparity & 1), cy = (lni >> 1) & 1, cz = lni & 1;
         if (cx > d.NX - 1) continue;
         const int cntx = (d.NX - 1 - cx) / 2 + 1, cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
-        dim3 blk(64, 4, 1), grd((cntz + 63) / 64, (cnty + 3) / 4, cntx);
+        dim3 blk(64, 4, 1), grd((unsigned) (((long long) cntx * cnty * cntz + 255) / 256), 1, 1);
         k_gs_color_stencil<<<grd, blk, 0, s>>>(d, S, u, b, mask, cx, cy, cz, forward);
     }
     VFEM_HIP(hipGetLastError());
@@ -885,10 +892,9 @@ void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const do
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_restrict(Dims c, int FX, int shift, const double *__restrict__ fine,
                                                   double *__restrict__ coarse) {
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    const int j = blockIdx.y * 4 + threadIdx.y;
-    const int i = blockIdx.z;
-    if (k >= c.NZ || j >= c.NY) return;
+    const int q = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x;       // lanes packed over the nodes of an x-plane
+    if (q >= c.NY * c.NZ) return;
+    const int j = q / c.NZ, k = q - j * c.NZ, i = blockIdx.z;
     const int FY = 2 * c.ny + 1, FZ = 2 * c.nz + 1;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     for (int di = -1; di <= 1; ++di) {
@@ -914,7 +920,7 @@ __global__ void __launch_bounds__(256) k_restrict(Dims c, int FX, int shift, con
 }
 
 void launch_restrict(const Dims &c, int fineNX, int shift, const double *fine, double *coarse, hipStream_t s) {
-    dim3 blk(64, 4, 1), grd((c.NZ + 63) / 64, (c.NY + 3) / 4, c.NX);
+    dim3 blk(64, 4, 1), grd((c.NY * c.NZ + 255) / 256, 1, c.NX);
     k_restrict<<<grd, blk, 0, s>>>(c, fineNX, shift, fine, coarse);
     VFEM_HIP(hipGetLastError());
 }
@@ -922,10 +928,9 @@ void launch_restrict(const Dims &c, int fineNX, int shift, const double *fine, d
 template <bool ACC>
 __global__ void __launch_bounds__(256) k_prolong(Dims c, int shift, const double *__restrict__ coarse, double *__restrict__ fine) {
     const int FY = 2 * c.ny + 1, FZ = 2 * c.nz + 1;
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    const int j = blockIdx.y * 4 + threadIdx.y;
-    const int i = blockIdx.z;
-    if (k >= FZ || j >= FY) return;
+    const int qq = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x;      // lanes packed over the nodes of an x-plane
+    if (qq >= FY * FZ) return;
+    const int j = qq / FZ, k = qq - j * FZ, i = blockIdx.z;
     const int ig = i - shift;                     // >= 0: shift is 0 or -1
     const int i0 = ig >> 1, j0 = j >> 1, k0 = k >> 1;
     const int oi = ig & 1, oj = j & 1, ok = k & 1;
@@ -948,7 +953,7 @@ __global__ void __launch_bounds__(256) k_prolong(Dims c, int shift, const double
 
 void launch_prolong(const Dims &c, int fineNX, int shift, const double *coarse, double *fine, int accumulate, hipStream_t s) {
     const int FY = 2 * c.ny + 1, FZ = 2 * c.nz + 1;
-    dim3 blk(64, 4, 1), grd((FZ + 63) / 64, (FY + 3) / 4, fineNX);
+    dim3 blk(64, 4, 1), grd((FY * FZ + 255) / 256, 1, fineNX);
     if (accumulate) k_prolong<true><<<grd, blk, 0, s>>>(c, shift, coarse, fine);
     else            k_prolong<false><<<grd, blk, 0, s>>>(c, shift, coarse, fine);
     VFEM_HIP(hipGetLastError());

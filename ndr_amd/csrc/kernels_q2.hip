@@ -774,8 +774,10 @@ template <int PX, int PY, int PZ>
 __global__ void __launch_bounds__(256) k_gs_q2_level0_nodes(DimsQ2 d, Q2Color col, const double *__restrict__ tabc, const double *__restrict__ E,
                                                             double *__restrict__ u, const double *__restrict__ b,
                                                             const uint8_t *__restrict__ mask, int forward) {
-    const int c = blockIdx.x * 64 + threadIdx.x, bq = blockIdx.y * 4 + threadIdx.y, a = blockIdx.z;
-    if (c >= col.cnt[2] || bq >= col.cnt[1] || a >= col.cnt[0]) return;
+    // lanes packed over the launch's nodes of an x-plane, row after row
+    const int fq = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x, a = blockIdx.z;
+    if (fq >= col.cnt[1] * col.cnt[2]) return;
+    const int bq = fq / col.cnt[2], c = fq - bq * col.cnt[2];
     const int i = col.start[0] + a * col.inc[0], j = col.start[1] + bq * col.inc[1], k = col.start[2] + c * col.inc[2];
     constexpr int NG = q2_ngroups(PX, PY, PZ);
     // moduli of the incident elements (slot sx*4 + sy*2 + sz; a mid node has one element along that axis: slot bit 0)
@@ -973,12 +975,24 @@ void launch_gs_sweep_q2_level0_nodes(int nx, int ny, int nz, const double *tab, 
             empty = empty || col.cnt[a] == 0;
         }
         if (empty) continue;
-        const dim3 grd((col.cnt[2] + 63) / 64, (col.cnt[1] + 3) / 4, col.cnt[0]), blk(64, 4, 1);
         const int cls = 4 * (l[0] & 1) + 2 * (l[1] & 1) + (l[2] & 1);
         const double *tc = tab + q2_table_offset(cls);
-        const dim3 grdr((col.cnt[2] + 63) / 64, (col.cnt[1] + VFEM_Q2ROWS_WAVES - 1) / VFEM_Q2ROWS_WAVES, col.cnt[0]), blkr(64, VFEM_Q2ROWS_WAVES, 1);
-#define VFEM_Q2GSN(X, Y, Z) do { if (rows_in_lds) k_gs_q2_level0_rows<X, Y, Z><<<grdr, blkr, 0, s>>>(d, col, tc, E, u, b, mask, forward); \
-                                else k_gs_q2_level0_nodes<X, Y, Z><<<grd, blk, 0, s>>>(d, col, tc, E, u, b, mask, forward); } while (0)
+        // rows kernel: whole waves of 64 nodes per z-row; a row of 2^k + 1 nodes leaves one node over, and a wave for it would
+        // run the full stream with one lane: the left-over columns (up to 16 per row) go to the gather kernel, lanes packed
+        // over the rows (the nodes of a colour are independent: any order)
+        Q2Color colr = col, coll = col;
+        const int over = col.cnt[2] % 64;
+        const bool split = rows_in_lds && col.cnt[2] > 64 && over >= 1 && over <= 16;
+        if (split) {
+            colr.cnt[2] = col.cnt[2] - over;
+            coll.start[2] = col.start[2] + colr.cnt[2] * col.inc[2];
+            coll.cnt[2] = over;
+        }
+        const Q2Color &coln = split ? coll : col;
+        const dim3 grd((coln.cnt[1] * coln.cnt[2] + 255) / 256, 1, coln.cnt[0]), blk(64, 4, 1);
+        const dim3 grdr((colr.cnt[2] + 63) / 64, (colr.cnt[1] + VFEM_Q2ROWS_WAVES - 1) / VFEM_Q2ROWS_WAVES, colr.cnt[0]), blkr(64, VFEM_Q2ROWS_WAVES, 1);
+#define VFEM_Q2GSN(X, Y, Z) do { if (rows_in_lds) k_gs_q2_level0_rows<X, Y, Z><<<grdr, blkr, 0, s>>>(d, colr, tc, E, u, b, mask, forward); \
+                                if (!rows_in_lds || split) k_gs_q2_level0_nodes<X, Y, Z><<<grd, blk, 0, s>>>(d, coln, tc, E, u, b, mask, forward); } while (0)
         switch (cls) {
             case 0: VFEM_Q2GSN(0, 0, 0); break;
             case 1: VFEM_Q2GSN(0, 0, 1); break;
@@ -1073,8 +1087,10 @@ template <int MODE>      // 1: out = K u; 2: out = zeroDirichlet(b - K u); 3: ou
 __global__ void __launch_bounds__(256) k_q2_level1(Q2L1 a, const double *__restrict__ u, const double *__restrict__ b,
                                                    const uint8_t *__restrict__ mask, double *__restrict__ out) {
     const DimsQ2 &d = a.d;
-    const int c = blockIdx.x * 64 + threadIdx.x, bq = blockIdx.y * 4 + threadIdx.y, ai = blockIdx.z;
-    if (c >= a.col.cnt[2] || bq >= a.col.cnt[1] || ai >= a.col.cnt[0]) return;
+    // lanes packed over the launch's nodes of an x-plane, row after row (rows of 2^k + 1 nodes leave a wave per row with one lane)
+    const int fq = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x, ai = blockIdx.z;
+    if (fq >= a.col.cnt[1] * a.col.cnt[2]) return;
+    const int bq = fq / a.col.cnt[2], c = fq - bq * a.col.cnt[2];
     const int i = a.col.start[0] + ai * a.col.inc[0], j = a.col.start[1] + bq * a.col.inc[1], k = a.col.start[2] + c * a.col.inc[2];
     // parity of the launch's nodes per axis (uniform): odd = mid node of one element, even = on an element boundary
     const int px = a.col.start[0] & 1, py = a.col.start[1] & 1, pz = a.col.start[2] & 1;
@@ -1112,9 +1128,11 @@ __global__ void __launch_bounds__(512) k_q2_level1_gs(Q2L1 a, double *__restrict
     extern __shared__ double q2l1_part[];               // [waves][12][64] (nothing for a colour with one incident element)
     double (*part)[12][64] = reinterpret_cast<double (*)[12][64]>(q2l1_part);
     const DimsQ2 &d = a.d;
-    const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y), c = blockIdx.x * 64 + lane, bq = blockIdx.y, ai = blockIdx.z;
-    const bool live = c < a.col.cnt[2];
-    const int i = a.col.start[0] + ai * a.col.inc[0], j = a.col.start[1] + bq * a.col.inc[1], k = a.col.start[2] + (live ? c : 0) * a.col.inc[2];
+    // the block's 64 nodes are consecutive in the (row, z) order of the colour's nodes of an x-plane: whole blocks whatever the row length
+    const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y), fq = blockIdx.x * 64 + lane, ai = blockIdx.z;
+    const bool live = fq < a.col.cnt[1] * a.col.cnt[2];
+    const int bq = live ? fq / a.col.cnt[2] : 0, c = live ? fq - bq * a.col.cnt[2] : 0;
+    const int i = a.col.start[0] + ai * a.col.inc[0], j = a.col.start[1] + bq * a.col.inc[1], k = a.col.start[2] + c * a.col.inc[2];
     const int px = a.col.start[0] & 1, py = a.col.start[1] & 1, pz = a.col.start[2] & 1;
     const int ney = py ? 1 : 2, nez = pz ? 1 : 2;
     const int sx = w / (ney * nez), sy = (w / nez) % ney, sz = w % nez;      // this wave's incident element (uniform)
@@ -1172,7 +1190,7 @@ void launch_gs_sweep_q2_level1(int nx, int ny, int nz, const double *tab, const 
         }
         if (empty) continue;
         const int waves = (l[0] == 1 ? 1 : 2) * (l[1] == 1 ? 1 : 2) * (l[2] == 1 ? 1 : 2);
-        const dim3 grd((a.col.cnt[2] + 63) / 64, a.col.cnt[1], a.col.cnt[0]), blk(64, waves, 1);
+        const dim3 grd((a.col.cnt[1] * a.col.cnt[2] + 63) / 64, 1, a.col.cnt[0]), blk(64, waves, 1);
         k_q2_level1_gs<<<grd, blk, waves > 1 ? (size_t) waves * 12 * 64 * sizeof(double) : 0, s>>>(a, u, b, mask, forward);
     }
     VFEM_HIP(hipGetLastError());
@@ -1188,7 +1206,7 @@ void launch_apply_q2_level1(int nx, int ny, int nz, const double *tab, const dou
             a.col.start[ax] = par[ax]; a.col.inc[ax] = 2;
             a.col.cnt[ax] = (NN[ax] - 1 - par[ax]) / 2 + 1;
         }
-        const dim3 grd((a.col.cnt[2] + 63) / 64, (a.col.cnt[1] + 3) / 4, a.col.cnt[0]), blk(64, 4, 1);
+        const dim3 grd((a.col.cnt[1] * a.col.cnt[2] + 255) / 256, 1, a.col.cnt[0]), blk(64, 4, 1);
         if (mode == 0) k_q2_level1<1><<<grd, blk, 0, s>>>(a, u, b, mask, out);
         else if (mode == 1) k_q2_level1<2><<<grd, blk, 0, s>>>(a, u, b, mask, out);
         else k_q2_level1<3><<<grd, blk, 0, s>>>(a, u, b, mask, out);
