@@ -822,10 +822,9 @@ template <bool RES>
 __global__ void __launch_bounds__(256) k_apply_stencil(Dims d, const double *__restrict__ St, const double *__restrict__ u,
                                                        const double *__restrict__ b, const uint8_t *__restrict__ mask,
                                                        double *__restrict__ out) {
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    const int j = blockIdx.y * 4 + threadIdx.y;
-    const int i = blockIdx.z;
-    if (k >= d.NZ || j >= d.NY) return;
+    const int q = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x;       // lanes packed over the nodes of an x-plane
+    if (q >= d.NY * d.NZ) return;
+    const int j = q / d.NZ, k = q - j * d.NZ, i = blockIdx.z;
     const long long n = nidx(d, i, j, k);
     double S[3], M[9];
     stencil_node<false>(d, St, u, i, j, k, n, S, M);
@@ -841,7 +840,7 @@ __global__ void __launch_bounds__(256) k_apply_stencil(Dims d, const double *__r
 
 void launch_apply_stencil(const Dims &d, const double *S, const double *u, const double *b, const uint8_t *mask,
                           int res, double *out, hipStream_t s) {
-    dim3 blk(64, 4, 1), grd((d.NZ + 63) / 64, (d.NY + 3) / 4, d.NX);
+    dim3 blk(64, 4, 1), grd((d.NY * d.NZ + 255) / 256, 1, d.NX);
     if (res) k_apply_stencil<true><<<grd, blk, 0, s>>>(d, S, u, b, mask, out);
     else     k_apply_stencil<false><<<grd, blk, 0, s>>>(d, S, u, b, mask, out);
     VFEM_HIP(hipGetLastError());
