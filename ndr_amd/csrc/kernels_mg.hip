@@ -873,6 +873,49 @@ __global__ void __launch_bounds__(256) k_gs_color_stencil(Dims d, const double *
     for (int c = 0; c < 3; ++c) u[3 * n + c] = uself[c] + ud[c];
 }
 
+// The same relaxation with ONE WAVE PER NODE, for the small levels (a colour of a 33^3 level has 4.5 k nodes, of a 17^3 level 614):
+// there a launch of the node-per-lane kernel lasts ~10 us whatever its size -- the chain of a node's 243 + 81 loads -- and a
+// sweep is eight such launches.  Here the 243 stencil entries of the node are spread over the lanes (four each, all loads of
+// the node in flight at once), every lane multiplies its entries with the matching neighbour component, a fixed xor tree adds
+// the three row sums, the centre block comes from the lanes that hold it.  Same arithmetic in a different (fixed) order.
+__global__ void __launch_bounds__(256) k_gs_color_stencil_wave(Dims d, const double *__restrict__ St, double *__restrict__ u,
+                                                               const double *__restrict__ b, const uint8_t *__restrict__ mask,
+                                                               int cx, int cy, int cz, int forward) {
+    const int cntx = (d.NX - 1 - cx) / 2 + 1, cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
+    const long long q = (long long) blockIdx.x * 4 + threadIdx.y;              // colour-local node index of this wave
+    if (q >= (long long) cntx * cnty * cntz) return;
+    const int lane = threadIdx.x;
+    const int iq = (int) (q / ((long long) cnty * cntz)), rem = (int) (q - (long long) iq * cnty * cntz), jq = rem / cntz;
+    const int i = 2 * iq + cx, j = 2 * jq + cy, k = 2 * (rem - jq * cntz) + cz;
+    const long long n = nidx(d, i, j, k);
+    long long sbase, scnt;
+    cm_index(d, i, j, k, sbase, scnt);
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, centre = 0.0;
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+        const int e = lane + 64 * sidx;
+        if (e < 243) {
+            const int nb = e / 9, qq = e - 9 * nb, r = qq / 3, c = qq - 3 * r;
+            // neighbours outside the grid have zero entries (k_stencil_build): read the clamped node
+            const int ii = min(max(i + nb / 9 - 1, 0), d.NX - 1), jj = min(max(j + (nb / 3) % 3 - 1, 0), d.NY - 1), kk = min(max(k + nb % 3 - 1, 0), d.NZ - 1);
+            const double a = St[sbase + (long long) e * scnt];
+            const double t = a * u[3 * nidx(d, ii, jj, kk) + c];
+            p0 += r == 0 ? t : 0.0; p1 += r == 1 ? t : 0.0; p2 += r == 2 ? t : 0.0;
+            if (sidx == 1) centre = a;                                           // entries 117..125 (the node's own block): lanes 53..61
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); p2 += __shfl_xor(p2, o); }
+    double M[9];
+#pragma unroll
+    for (int qq = 0; qq < 9; ++qq) M[qq] = __shfl(centre, 53 + qq);
+    if (lane != 0) return;
+    double bms[3] = {b[3 * n] - p0, b[3 * n + 1] - p1, b[3 * n + 2] - p2}, ud[3];
+    gs_solve(bms, M, mask[n], forward != 0, ud);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) u[3 * n + c] += ud[c];
+}
+
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
                              int forward, int xparity, int first, int count, hipStream_t s) {
     for (int ci = first; ci < first + count; ++ci) {
@@ -880,8 +923,10 @@ void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const do
         const int cx = ((lni >> 2) & 1) ^ (xparity & 1), cy = (lni >> 1) & 1, cz = lni & 1;
         if (cx > d.NX - 1) continue;
         const int cntx = (d.NX - 1 - cx) / 2 + 1, cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
-        dim3 blk(64, 4, 1), grd((unsigned) (((long long) cntx * cnty * cntz + 255) / 256), 1, 1);
-        k_gs_color_stencil<<<grd, blk, 0, s>>>(d, S, u, b, mask, cx, cy, cz, forward);
+        const long long cnt = (long long) cntx * cnty * cntz;
+        dim3 blk(64, 4, 1), grd((unsigned) ((cnt + 255) / 256), 1, 1);
+        if (d.nn <= 40000) k_gs_color_stencil_wave<<<dim3((unsigned) ((cnt + 3) / 4)), blk, 0, s>>>(d, S, u, b, mask, cx, cy, cz, forward);
+        else k_gs_color_stencil<<<grd, blk, 0, s>>>(d, S, u, b, mask, cx, cy, cz, forward);
     }
     VFEM_HIP(hipGetLastError());
 }
