@@ -202,7 +202,7 @@ static void mg_apply(vfem_mg *mg, int l, const double *u, const double *b, int r
 
 static void mg_smooth(vfem_mg *mg, int l, double *u, const double *b, int forward, hipStream_t s, int first = 0, int count = 8) {
     MgLevel &L = mg->lv[l];
-    if (L.kind == OP_STENCIL) launch_gs_sweep_stencil(L.d, L.S.p, u, b, L.maskp, forward, L.xparity, first, count, s);
+    if (L.kind == OP_STENCIL) launch_gs_sweep_stencil(L.d, L.S.p, u, b, L.maskp, forward, L.xparity, first, count, s, L.Sn.p);
     else launch_gs_sweep_mf(L.d, L.kind, level_K(mg, l), l == 0 ? mg->fine->dGsTab.p : mg->mf1diag.p, level_E(mg, l), u, b, L.maskp,
                             forward, L.xparity, first, count, s, mg->fine->tune, mg->mf1_sym,
                             (l == 1 && mg->fine->tune.l1_diag) ? L.Mdiag.p : nullptr);
@@ -240,6 +240,10 @@ static void update_operators(vfem_mg *mg, hipStream_t s) {
         MgLevel &lv = mg->lv[l];
         lv.S.alloc((size_t) stencil_storage_doubles(lv.d));
         launch_stencil_from_ke(lv.d, lv.Ke.p + lv.ex_lo * (long long) lv.d.ny * lv.d.nz * 576, lv.S.p, s);
+        if (lv.d.nn <= WAVE_SWEEP_MAX_NODES) {
+            lv.Sn.alloc((size_t) stencil_storage_doubles(lv.d));
+            launch_stencil_node_major(lv.d, lv.S.p, lv.Sn.p, s);
+        } else lv.Sn.release();
     }
     if (mg->slab) { mg->operators_valid = true; mg->operators_version = sim->operator_version; return; }       // the coarse levels live in the replicated hierarchy
     // coarsest level: dense inverse

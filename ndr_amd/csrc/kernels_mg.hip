@@ -878,7 +878,22 @@ __global__ void __launch_bounds__(256) k_gs_color_stencil(Dims d, const double *
 // sweep is eight such launches.  Here the 243 stencil entries of the node are spread over the lanes (four each, all loads of
 // the node in flight at once), every lane multiplies its entries with the matching neighbour component, a fixed xor tree adds
 // the three row sums, the centre block comes from the lanes that hold it.  Same arithmetic in a different (fixed) order.
-__global__ void __launch_bounds__(256) k_gs_color_stencil_wave(Dims d, const double *__restrict__ St, double *__restrict__ u,
+// node-major copy of a level's stencil for the wave-per-node sweep: the 243 entries of the node with padded colour-major number
+// lin (all 64-node tiles of the earlier colours, then the node's place in its own) are contiguous, Sn[243 lin + e]
+__global__ void __launch_bounds__(256) k_stencil_node_major(long long ntiles, const double *__restrict__ St, double *__restrict__ Sn) {
+    const long long t = (long long) blockIdx.x * 256 + threadIdx.x;              // (tile, entry, lane) -> lane fastest: coalesced reads
+    if (t >= ntiles * 243 * 64) return;
+    const long long tile = t / (243 * 64);
+    const int e = (int) ((t / 64) % 243), lane = (int) (t % 64);
+    Sn[(tile * 64 + lane) * 243 + e] = St[t];
+}
+void launch_stencil_node_major(const Dims &d, const double *St, double *Sn, hipStream_t s) {
+    const long long ntiles = stencil_storage_doubles(d) / (243 * 64);
+    k_stencil_node_major<<<dim3((unsigned) ((ntiles * 243 * 64 + 255) / 256)), dim3(256), 0, s>>>(ntiles, St, Sn);
+    VFEM_HIP(hipGetLastError());
+}
+
+__global__ void __launch_bounds__(256) k_gs_color_stencil_wave(Dims d, const double *__restrict__ Sn, double *__restrict__ u,
                                                                const double *__restrict__ b, const uint8_t *__restrict__ mask,
                                                                int cx, int cy, int cz, int forward) {
     const int cntx = (d.NX - 1 - cx) / 2 + 1, cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
@@ -890,6 +905,8 @@ __global__ void __launch_bounds__(256) k_gs_color_stencil_wave(Dims d, const dou
     const long long n = nidx(d, i, j, k);
     long long sbase, scnt;
     cm_index(d, i, j, k, sbase, scnt);
+    // tile-major base = 243 * 64 * tile + lane-in-tile  ->  padded colour-major number of the node
+    const double *row = Sn + ((sbase / (243 * 64)) * 64 + sbase % 64) * 243;
     double p0 = 0.0, p1 = 0.0, p2 = 0.0, centre = 0.0;
 #pragma unroll
     for (int sidx = 0; sidx < 4; ++sidx) {
@@ -898,7 +915,7 @@ __global__ void __launch_bounds__(256) k_gs_color_stencil_wave(Dims d, const dou
             const int nb = e / 9, qq = e - 9 * nb, r = qq / 3, c = qq - 3 * r;
             // neighbours outside the grid have zero entries (k_stencil_build): read the clamped node
             const int ii = min(max(i + nb / 9 - 1, 0), d.NX - 1), jj = min(max(j + (nb / 3) % 3 - 1, 0), d.NY - 1), kk = min(max(k + nb % 3 - 1, 0), d.NZ - 1);
-            const double a = St[sbase + (long long) e * scnt];
+            const double a = row[e];
             const double t = a * u[3 * nidx(d, ii, jj, kk) + c];
             p0 += r == 0 ? t : 0.0; p1 += r == 1 ? t : 0.0; p2 += r == 2 ? t : 0.0;
             if (sidx == 1) centre = a;                                           // entries 117..125 (the node's own block): lanes 53..61
@@ -917,7 +934,7 @@ __global__ void __launch_bounds__(256) k_gs_color_stencil_wave(Dims d, const dou
 }
 
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
-                             int forward, int xparity, int first, int count, hipStream_t s) {
+                             int forward, int xparity, int first, int count, hipStream_t s, const double *Sn) {
     for (int ci = first; ci < first + count; ++ci) {
         const int lni = forward ? ci : 7 - ci;
         const int cx = ((lni >> 2) & 1) ^ (xparity & 1), cy = (lni >> 1) & 1, cz = lni & 1;
@@ -925,7 +942,7 @@ void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const do
         const int cntx = (d.NX - 1 - cx) / 2 + 1, cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
         const long long cnt = (long long) cntx * cnty * cntz;
         dim3 blk(64, 4, 1), grd((unsigned) ((cnt + 255) / 256), 1, 1);
-        if (d.nn <= 40000) k_gs_color_stencil_wave<<<dim3((unsigned) ((cnt + 3) / 4)), blk, 0, s>>>(d, S, u, b, mask, cx, cy, cz, forward);
+        if (Sn) k_gs_color_stencil_wave<<<dim3((unsigned) ((cnt + 3) / 4)), blk, 0, s>>>(d, Sn, u, b, mask, cx, cy, cz, forward);
         else k_gs_color_stencil<<<grd, blk, 0, s>>>(d, S, u, b, mask, cx, cy, cz, forward);
     }
     VFEM_HIP(hipGetLastError());

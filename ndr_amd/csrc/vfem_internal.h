@@ -118,7 +118,10 @@ bool build_gs_coef(const double *K0, double *coef /* 36 doubles; false: K0 lacks
 bool coarsened_matrices_are_mirror_images(const double *cK0_host /* 8 x 576 */);
 void build_mf1_diag_table(const double *cK0_0, double *tab /* 8*12 */);
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
-                             int forward, int xparity, int first, int count, hipStream_t s);
+                             int forward, int xparity, int first, int count, hipStream_t s, const double *S_node_major = nullptr);
+// node-major copy of a level's stencil (levels small enough for the wave-per-node sweep, WAVE_SWEEP_MAX_NODES)
+void launch_stencil_node_major(const Dims &d, const double *St, double *Sn, hipStream_t s);
+constexpr long long WAVE_SWEEP_MAX_NODES = 40000;
 
 // fine local plane index = 2 * (coarse local plane) + shift + {-1,0,1}; fineNX = fine local node planes
 void launch_restrict(const Dims &coarse, int fineNX, int shift, const double *fine, double *coarse_out, hipStream_t s);
@@ -239,6 +242,7 @@ struct MgLevel {
     const uint8_t *maskp = nullptr;
     std::vector<uint8_t> hmask;
     vfem::DevBuf<double> Ke, S;                 // Galerkin element matrices / stencil (levels >= 2)
+    vfem::DevBuf<double> Sn;                    // node-major copy of S on levels of at most WAVE_SWEEP_MAX_NODES nodes (wave-per-node sweep)
     vfem::DevBuf<double> Mdiag;                 // level 1: precomputed diagonal blocks [nn][9] of the virtual operator
     vfem::DevBuf<double> x, b, r;               // work vectors (m_x, m_b of MG.hh:755-756 + residual)
 };
