@@ -436,6 +436,7 @@ int vfem_sim_set_option(vfem_sim *sim, int key, int value) {
         case VFEM_OPT_DMA_STRIP:     if (value < 0 || value > 2) throw Error("strip mode must be 0..2"); t.dma_strip = value; break;
         case VFEM_OPT_GS_PAIR:       t.gs_pair = value != 0; break;
         case VFEM_OPT_GS_RESIDENT:   t.gs_resident = (value != 0 && sim->gs_resident_ok) ? 1 : 0; break;
+        case VFEM_OPT_L1_SPLIT:      if (value != 1 && value != 2 && value != 4 && value != 8) throw Error("level-1 slot split 1, 2, 4 or 8"); t.l1_split = value; break;
         case VFEM_OPT_L1_DIAG:       t.l1_diag = value != 0; ++sim->operator_version; break;   // hierarchies (re)build the blocks
         default: throw Error("unknown simulator option " + std::to_string(key));
     }

@@ -590,15 +590,14 @@ void launch_mf1_diag(const Dims &d, const double *Dtab, const double *E, double 
 }
 
 // relaxation of one level-1 node (i, j, k) with the mirror-symmetric child matrices: the work of one lane
-__device__ __forceinline__ void gs_node_mf1_sym(const Dims &d, const double *__restrict__ K0c, const double *__restrict__ Dtab,
-                                                const double *__restrict__ Mdiag, const double *__restrict__ E, double *__restrict__ u,
-                                                const double *__restrict__ b, const uint8_t *__restrict__ mask, int i, int j, int k,
-                                                int forward) {
-    if (k >= d.NZ) return;
+// S, M: the sums over the element slots [slot0, slot1) of the node (the whole node: 0, 8)
+__device__ __forceinline__ void mf1_sym_partial(const Dims &d, const double *__restrict__ K0c, const double *__restrict__ Dtab,
+                                                const double *__restrict__ Mdiag, const double *__restrict__ E, const double *__restrict__ u,
+                                                int i, int j, int k, int slot0, int slot1, double S[3], double M[9]) {
     const long long nyf = 2LL * d.ny, nzf = 2LL * d.nz;
     const long long sx = (long long) d.NY * d.NZ, sy = d.NZ;
-    double S[3] = {0.0, 0.0, 0.0}, M[9];
-    if (Mdiag) {                                   // precomputed diagonal block, requested ahead of the slot loop
+    S[0] = S[1] = S[2] = 0.0;
+    if (Mdiag && slot0 == 0) {                     // precomputed diagonal block, requested ahead of the slot loop
         const long long nq = 9 * nidx(d, i, j, k);
 #pragma unroll
         for (int q = 0; q < 9; ++q) M[q] = Mdiag[nq + q];
@@ -609,7 +608,7 @@ __device__ __forceinline__ void gs_node_mf1_sym(const Dims &d, const double *__r
     // the element slot is a run-time loop: fully unrolled the kernel is ~60 KB of straight-line code, about the size of
     // the instruction cache two CUs share; the child index f stays compile-time (it permutes registers and fixes the signs)
 #pragma unroll 1
-    for (int slot = 0; slot < 8; ++slot) {
+    for (int slot = slot0; slot < slot1; ++slot) {
         const int li = 7 - slot;
         const int di = (slot >> 2) & 1, dj = (slot >> 1) & 1, dk = slot & 1;
         const int ex = i - 1 + di, ey = j - 1 + dj, ez = k - 1 + dk;
@@ -655,6 +654,9 @@ __device__ __forceinline__ void gs_node_mf1_sym(const Dims &d, const double *__r
         });
         if (!Mdiag) mf1_diag_slot(Dtab, li, Ef, M);
     }
+}
+__device__ __forceinline__ void mf1_relax(const Dims &d, double *__restrict__ u, const double *__restrict__ b, const uint8_t *__restrict__ mask,
+                                          int i, int j, int k, int forward, const double S[3], const double M[9]) {
     const long long n = nidx(d, i, j, k);
     double bms[3], ud[3];
 #pragma unroll
@@ -662,6 +664,16 @@ __device__ __forceinline__ void gs_node_mf1_sym(const Dims &d, const double *__r
     gs_solve(bms, M, mask[n], forward != 0, ud);
 #pragma unroll
     for (int c = 0; c < 3; ++c) u[3 * n + c] += ud[c];
+}
+// relaxation of one level-1 node (i, j, k) with the mirror-symmetric child matrices: the work of one lane
+__device__ __forceinline__ void gs_node_mf1_sym(const Dims &d, const double *__restrict__ K0c, const double *__restrict__ Dtab,
+                                                const double *__restrict__ Mdiag, const double *__restrict__ E, double *__restrict__ u,
+                                                const double *__restrict__ b, const uint8_t *__restrict__ mask, int i, int j, int k,
+                                                int forward) {
+    if (k >= d.NZ) return;
+    double S[3], M[9];
+    mf1_sym_partial(d, K0c, Dtab, Mdiag, E, u, i, j, k, 0, 8, S, M);
+    mf1_relax(d, u, b, mask, i, j, k, forward, S, M);
 }
 
 __global__ void __launch_bounds__(256, 4) k_gs_color_mf1_sym(Dims d, const double *__restrict__ K0c, const double *__restrict__ Dtab,
@@ -677,6 +689,44 @@ __global__ void __launch_bounds__(256, 4) k_gs_color_mf1_sym(Dims d, const doubl
     const int jq = q / cntz;
     const int k = 2 * (q - jq * cntz) + cz, j = 2 * jq + cy, i = 2 * blockIdx.z + cx;
     gs_node_mf1_sym(d, K0c, Dtab, Mdiag, E, u, b, mask, i, j, k, forward);
+}
+
+// The same sweep with the eight element slots of a node shared by TWO waves (slots 0-3 / 4-7; partial sums meet in LDS, added in
+// slot order).  A launch whose waves just exceed the chip's resident-wave slots pays for a second, almost empty round with a full
+// wave duration (a colour of the 129^3 level: 4291 waves for 4096 slots, 128 us per launch against 94 us by the per-node rate
+// of the 257^3 level); with half the work per wave the rounds are half as long.  Used while a colour has fewer than three
+// rounds of waves.
+template <int SPLIT>      // waves per node group: 2, 4 or 8 (8 / SPLIT element slots per wave)
+__global__ void __launch_bounds__(SPLIT == 8 ? 512 : 256) k_gs_color_mf1_sym_split(Dims d, const double *__restrict__ K0c, const double *__restrict__ Dtab,
+                                                                   const double *__restrict__ Mdiag, const double *__restrict__ E,
+                                                                   double *__restrict__ u, const double *__restrict__ b,
+                                                                   const uint8_t *__restrict__ mask, int cx, int cy, int cz, int forward) {
+    constexpr int GROUPS = SPLIT == 8 ? 1 : 256 / (64 * SPLIT);
+    __shared__ double part[GROUPS][SPLIT - 1][12][64];
+    const int lane = threadIdx.x, part_id = __builtin_amdgcn_readfirstlane(threadIdx.y), grp = threadIdx.z;       // (part_id: uniform over the wave)
+    const int cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
+    const int q = blockIdx.x * (64 * GROUPS) + grp * 64 + lane;
+    const bool live = q < cnty * cntz;
+    const int qq = live ? q : cnty * cntz - 1;
+    const int jq = qq / cntz;
+    const int k = 2 * (qq - jq * cntz) + cz, j = 2 * jq + cy, i = 2 * blockIdx.z + cx;
+    double S[3], M[9];
+    mf1_sym_partial(d, K0c, Dtab, Mdiag, E, u, i, j, k, (8 / SPLIT) * part_id, (8 / SPLIT) * (part_id + 1), S, M);
+    if (part_id > 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) part[grp][part_id - 1][c][lane] = S[c];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) part[grp][part_id - 1][3 + c][lane] = M[c];
+    }
+    __syncthreads();
+    if (part_id > 0 || !live) return;
+    for (int o = 0; o < SPLIT - 1; ++o) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) S[c] += part[grp][o][c][lane];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) M[c] += part[grp][o][3 + c][lane];
+    }
+    mf1_relax(d, u, b, mask, i, j, k, forward, S, M);
 }
 
 // diagonal blocks of cK0[0] for k_gs_color_mf1_sym: 8 groups of 12 doubles (9 used)
@@ -727,6 +777,12 @@ void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const doubl
         if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab && res && d.nz >= 2) k_gs_rows_mf0<true><<<grd, blk, 0, s>>>(d, gs_tab + GS_TABLE_DOUBLES, E, u, b, mask, cx, cy, cz, forward);
         else if (kind == OP_MF0 && g_gs_variant == 0 && gs_tab && d.nz >= 2) k_gs_rows_mf0<false><<<grd, blk, 0, s>>>(d, gs_tab, E, u, b, mask, cx, cy, cz, forward);
         else if (kind == OP_MF0) k_gs_color_mf<0><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);
+        else if (g_mf1_sym && g_gs_variant == 0 && gs_tab && tune.l1_split == 2)
+            k_gs_color_mf1_sym_split<2><<<dim3((cnty * cntz + 127) / 128, 1, cntx), dim3(64, 2, 2), 0, s>>>(d, K, gs_tab, mdiag, E, u, b, mask, cx, cy, cz, forward);
+        else if (g_mf1_sym && g_gs_variant == 0 && gs_tab && tune.l1_split == 4)
+            k_gs_color_mf1_sym_split<4><<<dim3((cnty * cntz + 63) / 64, 1, cntx), dim3(64, 4, 1), 0, s>>>(d, K, gs_tab, mdiag, E, u, b, mask, cx, cy, cz, forward);
+        else if (g_mf1_sym && g_gs_variant == 0 && gs_tab && tune.l1_split == 8)
+            k_gs_color_mf1_sym_split<8><<<dim3((cnty * cntz + 63) / 64, 1, cntx), dim3(64, 8, 1), 0, s>>>(d, K, gs_tab, mdiag, E, u, b, mask, cx, cy, cz, forward);
         else if (g_mf1_sym && g_gs_variant == 0 && gs_tab)
             k_gs_color_mf1_sym<<<dim3((cnty * cntz + 255) / 256, 1, cntx), blk, 0, s>>>(d, K, gs_tab, mdiag, E, u, b, mask, cx, cy, cz, forward);
         else                k_gs_color_mf<1><<<grd, blk, 0, s>>>(d, K, E, u, b, mask, cx, cy, cz, forward);

@@ -84,6 +84,7 @@ struct Tuning {
     int gs_variant = 0;     // 0: row-streaming / symmetric sweeps, 1: plain gather sweeps
     int gs_pair = 1;        // level 0: both z colours of a row in one launch
     int gs_resident = 0;    // level 0: K0 kept in 72 SGPRs (36 distinct values; set when build_gs_coef reproduces K0 bit for bit)
+    int l1_split = 4;       // level 1: waves sharing the eight element slots of a node (1: one lane does all eight; 2, 4, 8)
     int l1_diag = 0;        // level 1: diagonal blocks precomputed once per operator update instead of inside every sweep (measured
                             // 3 % SLOWER at 512^3, profiles/r02_gs_experiments.json: the sweep is not bound by its arithmetic)
 };
