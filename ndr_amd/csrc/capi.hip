@@ -202,7 +202,7 @@ static void mg_apply(vfem_mg *mg, int l, const double *u, const double *b, int r
 
 static void mg_smooth(vfem_mg *mg, int l, double *u, const double *b, int forward, hipStream_t s, int first = 0, int count = 8) {
     MgLevel &L = mg->lv[l];
-    if (L.kind == OP_STENCIL) launch_gs_sweep_stencil(L.d, L.S.p, u, b, L.maskp, forward, L.xparity, first, count, s, L.Sn.p);
+    if (L.kind == OP_STENCIL) launch_gs_sweep_stencil(L.d, L.S.p, u, b, L.maskp, forward, L.xparity, first, count, s, L.Sn.p, mg->fine->tune.stencil_split);
     else launch_gs_sweep_mf(L.d, L.kind, level_K(mg, l), l == 0 ? mg->fine->dGsTab.p : mg->mf1diag.p, level_E(mg, l), u, b, L.maskp,
                             forward, L.xparity, first, count, s, mg->fine->tune, mg->mf1_sym,
                             (l == 1 && mg->fine->tune.l1_diag) ? L.Mdiag.p : nullptr);
@@ -437,6 +437,7 @@ int vfem_sim_set_option(vfem_sim *sim, int key, int value) {
         case VFEM_OPT_GS_PAIR:       t.gs_pair = value != 0; break;
         case VFEM_OPT_GS_RESIDENT:   t.gs_resident = (value != 0 && sim->gs_resident_ok) ? 1 : 0; break;
         case VFEM_OPT_L1_SPLIT:      if (value != 1 && value != 2 && value != 4 && value != 8) throw Error("level-1 slot split 1, 2, 4 or 8"); t.l1_split = value; break;
+        case VFEM_OPT_STENCIL_SPLIT: t.stencil_split = value != 0; break;
         case VFEM_OPT_L1_DIAG:       t.l1_diag = value != 0; ++sim->operator_version; break;   // hierarchies (re)build the blocks
         default: throw Error("unknown simulator option " + std::to_string(key));
     }

@@ -929,6 +929,71 @@ __global__ void __launch_bounds__(256) k_gs_color_stencil(Dims d, const double *
     for (int c = 0; c < 3; ++c) u[3 * n + c] = uself[c] + ud[c];
 }
 
+// The node-per-lane relaxation with the 27 neighbour blocks shared by THREE waves (one x-plane of neighbours each; partial
+// row sums through LDS, the wave of the centre plane holds the diagonal block and finishes): a third of the dependent loads per
+// lane and three times the waves -- the mid-size levels (65^3: 537 waves per colour) are latency-bound, the large one
+// (129^3) gets more loads in flight against its stencil traffic.
+template <int W>
+__device__ __forceinline__ void stencil_plane(const Dims &d, const double *__restrict__ St, const double *__restrict__ u, int i, int j, int k,
+                                              long long sbase, long long scnt, double S[3], double M[9], double uself[3]) {
+    static_for<9>([&](auto tc) {
+        constexpr int nb = 9 * W + decltype(tc)::value, di = W - 1, dj = (nb / 3) % 3 - 1, dk = nb % 3 - 1;
+        int ii = i + di, jj = j + dj, kk = k + dk;
+        if (di < 0) ii = ii < 0 ? 0 : ii;
+        if (di > 0) ii = ii > d.NX - 1 ? d.NX - 1 : ii;
+        if (dj < 0) jj = jj < 0 ? 0 : jj;
+        if (dj > 0) jj = jj > d.NY - 1 ? d.NY - 1 : jj;
+        if (dk < 0) kk = kk < 0 ? 0 : kk;
+        if (dk > 0) kk = kk > d.NZ - 1 ? d.NZ - 1 : kk;
+        const long long m = nidx(d, ii, jj, kk);
+        const double u0 = u[3 * m], u1 = u[3 * m + 1], u2 = u[3 * m + 2];
+        const double *a = St + sbase + (long long) nb * 9 * scnt;
+        double A[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) A[q] = a[(long long) q * scnt];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) S[r] += A[3 * r] * u0 + A[3 * r + 1] * u1 + A[3 * r + 2] * u2;
+        if (nb == 13) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) M[q] = A[q];
+            uself[0] = u0; uself[1] = u1; uself[2] = u2;
+        }
+    });
+}
+__global__ void __launch_bounds__(192) k_gs_color_stencil_split(Dims d, const double *__restrict__ St, double *__restrict__ u,
+                                                                const double *__restrict__ b, const uint8_t *__restrict__ mask,
+                                                                int cx, int cy, int cz, int forward) {
+    __shared__ double part[2][3][64];
+    const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int cntx = (d.NX - 1 - cx) / 2 + 1, cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
+    const long long q0 = (long long) blockIdx.x * 64 + lane, total = (long long) cntx * cnty * cntz;
+    const bool live = q0 < total;
+    const long long q = live ? q0 : total - 1;
+    const int iq = (int) (q / ((long long) cnty * cntz)), rem = (int) (q - (long long) iq * cnty * cntz), jq = rem / cntz;
+    const int i = 2 * iq + cx, j = 2 * jq + cy, k = 2 * (rem - jq * cntz) + cz;
+    const long long n = nidx(d, i, j, k);
+    long long sbase, scnt;
+    cm_index(d, i, j, k, sbase, scnt);
+    double S[3] = {0.0, 0.0, 0.0}, M[9], uself[3] = {0.0, 0.0, 0.0};
+    if (w == 0) stencil_plane<0>(d, St, u, i, j, k, sbase, scnt, S, M, uself);
+    else if (w == 1) stencil_plane<1>(d, St, u, i, j, k, sbase, scnt, S, M, uself);
+    else stencil_plane<2>(d, St, u, i, j, k, sbase, scnt, S, M, uself);
+    if (w != 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) part[w >> 1][c][lane] = S[c];
+    }
+    __syncthreads();
+    if (w != 1 || !live) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) S[c] = (part[0][c][lane] + S[c]) + part[1][c][lane];       // x-planes in ascending order
+    double bms[3], ud[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bms[c] = b[3 * n + c] - S[c];
+    gs_solve(bms, M, mask[n], forward != 0, ud);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) u[3 * n + c] = uself[c] + ud[c];
+}
+
 // The same relaxation with ONE WAVE PER NODE, for the small levels (a colour of a 33^3 level has 4.5 k nodes, of a 17^3 level 614):
 // there a launch of the node-per-lane kernel lasts ~10 us whatever its size -- the chain of a node's 243 + 81 loads -- and a
 // sweep is eight such launches.  Here the 243 stencil entries of the node are spread over the lanes (four each, all loads of
@@ -990,7 +1055,7 @@ __global__ void __launch_bounds__(256) k_gs_color_stencil_wave(Dims d, const dou
 }
 
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
-                             int forward, int xparity, int first, int count, hipStream_t s, const double *Sn) {
+                             int forward, int xparity, int first, int count, hipStream_t s, const double *Sn, int stencil_split) {
     for (int ci = first; ci < first + count; ++ci) {
         const int lni = forward ? ci : 7 - ci;
         const int cx = ((lni >> 2) & 1) ^ (xparity & 1), cy = (lni >> 1) & 1, cz = lni & 1;
@@ -999,6 +1064,7 @@ void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const do
         const long long cnt = (long long) cntx * cnty * cntz;
         dim3 blk(64, 4, 1), grd((unsigned) ((cnt + 255) / 256), 1, 1);
         if (Sn) k_gs_color_stencil_wave<<<dim3((unsigned) ((cnt + 3) / 4)), blk, 0, s>>>(d, Sn, u, b, mask, cx, cy, cz, forward);
+        else if (stencil_split) k_gs_color_stencil_split<<<dim3((unsigned) ((cnt + 63) / 64)), dim3(64, 3, 1), 0, s>>>(d, S, u, b, mask, cx, cy, cz, forward);
         else k_gs_color_stencil<<<grd, blk, 0, s>>>(d, S, u, b, mask, cx, cy, cz, forward);
     }
     VFEM_HIP(hipGetLastError());

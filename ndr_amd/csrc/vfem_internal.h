@@ -85,6 +85,7 @@ struct Tuning {
     int gs_pair = 1;        // level 0: both z colours of a row in one launch
     int gs_resident = 0;    // level 0: K0 kept in 72 SGPRs (36 distinct values; set when build_gs_coef reproduces K0 bit for bit)
     int l1_split = 4;       // level 1: waves sharing the eight element slots of a node (1: one lane does all eight; 2, 4, 8)
+    int stencil_split = 1;  // stored-stencil levels above the wave-per-node threshold: 27 neighbour blocks shared by three waves (1) or one lane (0)
     int l1_diag = 0;        // level 1: diagonal blocks precomputed once per operator update instead of inside every sweep (measured
                             // 3 % SLOWER at 512^3, profiles/r02_gs_experiments.json: the sweep is not bound by its arithmetic)
 };
@@ -119,7 +120,8 @@ bool build_gs_coef(const double *K0, double *coef /* 36 doubles; false: K0 lacks
 bool coarsened_matrices_are_mirror_images(const double *cK0_host /* 8 x 576 */);
 void build_mf1_diag_table(const double *cK0_0, double *tab /* 8*12 */);
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
-                             int forward, int xparity, int first, int count, hipStream_t s, const double *S_node_major = nullptr);
+                             int forward, int xparity, int first, int count, hipStream_t s, const double *S_node_major = nullptr,
+                             int stencil_split = 1);
 // node-major copy of a level's stencil (levels small enough for the wave-per-node sweep, WAVE_SWEEP_MAX_NODES)
 void launch_stencil_node_major(const Dims &d, const double *St, double *Sn, hipStream_t s);
 constexpr long long WAVE_SWEEP_MAX_NODES = 40000;
