@@ -142,6 +142,35 @@ def test_mg_operators(ne, levels):
     assert relerr(tmg.coarsestSolve_device(bL).cpu().numpy(), ref) < 1e-8
 
 
+def test_sweep_kernel_choices_agree():
+    """the choices between sweep kernels that share the arithmetic (include/vfem.h VFEM_OPT_*): level-1 element slots shared by
+    1 / 2 / 4 / 8 waves, stored-stencil neighbour blocks shared by three waves or not -- against each other and, through the
+    oracle comparison of test_mg_operators, against the reference rules; grid with a stencil level above and below the
+    wave-per-node threshold"""
+    import torch
+    from ndr_amd import _lib
+    lib = _lib.load()
+    ne, dom = (160, 144, 176), ([0, 0, 0], [2, 1, 1])     # level 2: 41 x 37 x 45 = 68 k nodes (above the threshold), level 3: 9 k
+    t = make_hip(ne, dom, BC_CANTILEVER, None, v0=0.5)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    t.setElementDensities(torch.rand(t.numElements(), dtype=torch.float64, device="cuda", generator=g))
+    mg = t.multigridSolver(4)
+    mg.updateElementStiffnessMatrices()
+    fields = {l: (torch.randn((mg._nn(l), 3), dtype=torch.float64, device="cuda", generator=g),
+                  torch.randn((mg._nn(l), 3), dtype=torch.float64, device="cuda", generator=g)) for l in (1, 2)}
+    ref = {}
+    for key, values, level in ((15, (1, 2, 4, 8), 1), (18, (0, 1), 2)):
+        for v in values:
+            _lib.check(lib.vfem_sim_set_option(t._h, key, v))
+            for fwd in (True, False):
+                got = mg.smoothing_device(level, fields[level][0], fields[level][1], fwd)
+                r = ref.setdefault((key, fwd), got)
+                assert float((got - r).abs().max()) < 1e-12 * float(r.abs().max()), (key, v, fwd)
+        _lib.check(lib.vfem_sim_set_option(t._h, key, {15: 4, 18: 1}[key]))
+    with pytest.raises(RuntimeError):
+        _lib.check(lib.vfem_sim_set_option(t._h, 15, 3))
+
+
 def test_transfer_adjointness():
     o, t, omg, tmg = _mg_pair((16, 8, 8), ([0, 0, 0], [2, 1, 1]), BC_CANTILEVER, 2)
     rng = np.random.default_rng(3)
