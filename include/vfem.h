@@ -62,7 +62,7 @@ enum {
                                     the neighbour rows staged through LDS by coalesced loads (default) */
     VFEM_OPT_TRANSFER_AXIS = 17, /* vfem_gsim: restriction / interpolation of 3-D levels above 100 k nodes axis by axis (1, default) or in one pass (0) */
     VFEM_OPT_Q2_L1_VIRTUAL = 14  /* vfem_gsim: level 1 of a degree-2 hierarchy evaluated as sum_f E_f cK0[f] on the fly (1), from stored 81 x 81
-                                    element matrices (0), or chosen by their size (2, default: on the fly above 32 GB); read by the next
+                                    element matrices (0), or chosen by their size (2, default: on the fly above 1.5 GB); read by the next
                                     vfem_gmg_update_operators */
 };
 
@@ -171,6 +171,11 @@ int vfem_mg_zero_dirichlet(vfem_mg *mg, int level, double *u, void *stream);
 int vfem_mg_restrict(vfem_mg *mg, int fine_level, const double *fine, double *coarse, void *stream);
 int vfem_mg_interpolate(vfem_mg *mg, int fine_level, const double *coarse, double *fine, int accumulate, void *stream);
 int vfem_mg_coarsest_solve(vfem_mg *mg, const double *b, double *x, void *stream);
+/* The factorisation behind the exact coarsest solve (TPS::solve with CholmodFactorizer, TPS.hh:834-865, SparseMatrices.hh:1875-1965),
+ * as this library does it: A (n x n doubles, row-major, symmetric positive definite, both triangles) is replaced in place by
+ * its inverse (both triangles).  Own blocked Cholesky / triangular inverse / product kernels on `stream`, fixed summation
+ * order: the same matrix gives the same inverse bit for bit in every run.  Fails ("not positive definite") on a pivot <= 0. */
+int vfem_dense_spd_inverse(int64_t n, double *A, void *stream);
 
 /* MG::solve (MG.hh:447-472): numSteps V-cycles (first one a full-multigrid cycle if fmg) on K x = f
  * starting from x (in/out). */

@@ -70,6 +70,7 @@ SIGNATURES = {
     "vfem_mg_restrict": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "vfem_mg_interpolate": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "vfem_mg_coarsest_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vfem_dense_spd_inverse": (c_int, [c_int64, c_void_p, c_void_p]),
     "vfem_mg_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vfem_mg_pcg": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_int, c_int,
                             RESIDUAL_CB, c_void_p, POINTER(c_int), POINTER(c_double), c_void_p]),

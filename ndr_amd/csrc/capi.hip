@@ -8,7 +8,6 @@
 #include "vfem_internal.h"
 
 #include <rocblas/rocblas.h>
-#include <rocsolver/rocsolver.h>
 
 #include <chrono>
 #include <cmath>
@@ -261,26 +260,7 @@ static void update_operators(vfem_mg *mg, hipStream_t s) {
     mg->Ainv.alloc((size_t) n * n);
     mg->Ainv.zero(s);
     launch_dense_from_stencil(cl.d, Sc, cl.maskp, mg->Ainv.p, s);
-    if (!mg->rocblas) {
-        rocblas_handle hnd;
-        if (rocblas_create_handle(&hnd) != rocblas_status_success) throw Error("rocblas_create_handle failed");
-        // the dense coarsest inverse must not depend on the order in which atomic partial sums happen to land (rocBLAS allows
-        // atomics by default): the same densities must give the same preconditioner, bit for bit, in every run and on every rank
-        rocblas_set_atomics_mode(hnd, rocblas_atomics_not_allowed);
-        mg->rocblas = hnd;
-        mg->info.alloc(1);
-    }
-    rocblas_handle hnd = (rocblas_handle) mg->rocblas;
-    rocblas_set_stream(hnd, s);
-    vfem::DenseFactorisationLock dense_lock;      // released after the stream has drained (end of this function)
-    if (rocsolver_dpotrf(hnd, rocblas_fill_lower, (rocblas_int) n, mg->Ainv.p, (rocblas_int) n, mg->info.p) != rocblas_status_success)
-        throw Error("rocsolver_dpotrf failed");
-    int info = 0;
-    VFEM_HIP(hipMemcpyAsync(&info, mg->info.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    VFEM_HIP(hipStreamSynchronize(s));
-    if (info != 0) throw Error("coarsest-level stiffness matrix is not positive definite (potrf info = " + std::to_string(info) + ")");
-    if (rocsolver_dpotri(hnd, rocblas_fill_lower, (rocblas_int) n, mg->Ainv.p, (rocblas_int) n, mg->info.p) != rocblas_status_success)
-        throw Error("rocsolver_dpotri failed");
+    dense_spd_inverse(n, mg->Ainv.p, mg->dense, s);      // own kernels, fixed summation order (dense_spd.hip)
     launch_dense_finish_inverse(n, cl.maskp, mg->Ainv.p, s);
     VFEM_HIP(hipStreamSynchronize(s));   // tmpS lifetime
     mg->operators_valid = true;
@@ -696,7 +676,6 @@ int vfem_mg_create_slab(vfem_mg **out, vfem_sim *fine, int n_levels, const vfem_
 }
 int vfem_mg_destroy(vfem_mg *mg) {
     VFEM_TRY
-    if (mg && mg->rocblas) rocblas_destroy_handle((rocblas_handle) mg->rocblas);
     delete mg;
     VFEM_CATCH
 }
@@ -799,6 +778,14 @@ int vfem_mg_interpolate(vfem_mg *mg, int fine_level, const double *coarse, doubl
     VFEM_TRY
     check_level(mg, fine_level + 1);
     launch_prolong(mg->lv[(size_t) fine_level + 1].d, mg->lv[(size_t) fine_level].d.NX, mg->lv[(size_t) fine_level + 1].xshift, coarse, fine, accumulate, S(stream));
+    VFEM_CATCH
+}
+int vfem_dense_spd_inverse(int64_t n, double *A, void *stream) {
+    VFEM_TRY
+    if (n < 1 || n > 40000) throw Error("dense inverse: n must be in [1, 40000]");
+    DenseWork w;
+    dense_spd_inverse(n, A, w, S(stream));
+    VFEM_HIP(hipStreamSynchronize(S(stream)));      // the workspace is released on return
     VFEM_CATCH
 }
 int vfem_mg_coarsest_solve(vfem_mg *mg, const double *b, double *x, void *stream) {

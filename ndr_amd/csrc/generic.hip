@@ -12,8 +12,6 @@
 #include "vfem_internal.h"
 #include "q2_modes.h"
 
-#include <rocblas/rocblas.h>
-#include <rocsolver/rocsolver.h>
 
 #include <algorithm>
 #include <cmath>
@@ -690,8 +688,7 @@ struct vfem_gmg {
     DevBuf<double> tr1, tr2;           // intermediates of the axis-by-axis transfers
     DevBuf<double> c2tab;              // degree-2 hexahedra: c2K0[g][f] = I_g^T cK0[f] I_g as [entry][64] (level 2 straight from the moduli)
     DevBuf<double> l1tab;              // degree-2 hexahedra: cK0 regrouped for k_q2_level1, [ln][m][f][r][c]
-    DevBuf<int> info;
-    void *rocblas = nullptr;
+    vfem::DenseWork dense;             // workspace of the coarsest-level inverse (dense_spd.hip)
 };
 
 static double lagrange1d(int p, int a, double x) {            // LagrangePolynomial.hh:9,42-56
@@ -1050,26 +1047,7 @@ static void gmg_update(vfem_gmg *mg, hipStream_t s) {
     mg->Ainv.alloc((size_t) n * n);
     VFEM_HIP(hipStreamSynchronize(s));
     VFEM_HIP(hipMemcpy(mg->Ainv.p, A.data(), A.size() * sizeof(double), hipMemcpyHostToDevice));       // (synchronous: the source is pageable host memory)
-    if (!mg->rocblas) {
-        rocblas_handle hnd;
-        if (rocblas_create_handle(&hnd) != rocblas_status_success) throw Error("rocblas_create_handle failed");
-        // the dense coarsest inverse must not depend on the order in which atomic partial sums happen to land (rocBLAS allows
-        // atomics by default): the same densities must give the same preconditioner, bit for bit, in every run and on every rank
-        rocblas_set_atomics_mode(hnd, rocblas_atomics_not_allowed);
-        mg->rocblas = hnd;
-        mg->info.alloc(1);
-    }
-    rocblas_handle hnd = (rocblas_handle) mg->rocblas;
-    rocblas_set_stream(hnd, s);
-    vfem::DenseFactorisationLock dense_lock;      // released after the stream has drained (end of this function)
-    if (rocsolver_dpotrf(hnd, rocblas_fill_lower, (rocblas_int) n, mg->Ainv.p, (rocblas_int) n, mg->info.p) != rocblas_status_success)
-        throw Error("rocsolver_dpotrf failed");
-    int info = 0;
-    VFEM_HIP(hipMemcpyAsync(&info, mg->info.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    VFEM_HIP(hipStreamSynchronize(s));
-    if (info != 0) throw Error("coarsest-level stiffness matrix is not positive definite (potrf info = " + std::to_string(info) + ")");
-    if (rocsolver_dpotri(hnd, rocblas_fill_lower, (rocblas_int) n, mg->Ainv.p, (rocblas_int) n, mg->info.p) != rocblas_status_success)
-        throw Error("rocsolver_dpotri failed");
+    dense_spd_inverse(n, mg->Ainv.p, mg->dense, s);      // own kernels, fixed summation order (dense_spd.hip)
     kg_dense_finish<<<dim3((unsigned) ((n * n + 255) / 256)), dim3(256), 0, s>>>(n, N, cl.mask.p, mg->Ainv.p);
     VFEM_HIP(hipGetLastError());
     VFEM_HIP(hipStreamSynchronize(s));
@@ -1421,7 +1399,6 @@ int vfem_gmg_create_slab(vfem_gmg **out, vfem_gsim *fine, int n_levels, const vf
 }
 int vfem_gmg_destroy(vfem_gmg *mg) {
     G_TRY
-    if (mg && mg->rocblas) rocblas_destroy_handle((rocblas_handle) mg->rocblas);
     delete mg;
     G_CATCH
 }

@@ -2,33 +2,10 @@
 // wavefront (64-lane) reductions, compliance sensitivity.
 #include "vfem_internal.h"
 
-#include <fcntl.h>
-#include <sys/file.h>
-#include <unistd.h>
-
 #include <cstdlib>
 #include <string>
 
 namespace vfem {
-
-// Processes that share a device (ranks rehearsed on one GPU, several jobs on one card) must not run the dense factorisation
-// at the same moment: measured on this stack (tools/q2_dense_probe.py, five processes updating in step) rocsolver_dpotrf /
-// dpotri then return inverses that differ from run to run -- up to six distinct ones in 40 updates, residual histories of
-// the solves off by 3e-3 -- and now and then "not positive definite" for a matrix that factorises alone.  The factorisation
-// is therefore taken under an advisory file lock per device; a process alone on its GPU never waits.
-DenseFactorisationLock::DenseFactorisationLock() {
-    int dev = 0;
-    char bus[64] = "unknown";
-    if (hipGetDevice(&dev) == hipSuccess) (void) hipDeviceGetPCIBusId(bus, (int) sizeof(bus), dev);
-    for (char *c = bus; *c; ++c) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
-    const char *tmp = getenv("TMPDIR");
-    const std::string path = std::string(tmp && *tmp ? tmp : "/tmp") + "/vfem_dense_" + bus + ".lock";
-    fd = open(path.c_str(), O_CREAT | O_RDWR, 0666);
-    if (fd >= 0 && flock(fd, LOCK_EX) != 0) { close(fd); fd = -1; }       // no lock available: proceed unlocked
-}
-DenseFactorisationLock::~DenseFactorisationLock() {
-    if (fd >= 0) { flock(fd, LOCK_UN); close(fd); }
-}
 
 static inline unsigned grid_for(long long n, int block, int cap = 4096) {
     long long g = (n + block - 1) / block;

@@ -168,14 +168,11 @@ void launch_apply_q2_pencil(int nx, int ny, int nz, const double *mode_table, co
 void launch_apply_q2_march(int nx, int ny, int nz, const double *mode_table, const double *E, const double *u, double *out, hipStream_t s);
 void launch_gs_sweep_q2_level0(int nx, int ny, int nz, const double *K0, const double *E, double *u, const double *b,
                                const uint8_t *mask, int forward, hipStream_t s, int first = 0, int count = 27);
-// held around rocsolver_dpotrf / dpotri (kernels_vec.hip): serialises the dense factorisations of processes sharing a device
-struct DenseFactorisationLock {
-    int fd = -1;
-    DenseFactorisationLock();
-    ~DenseFactorisationLock();
-    DenseFactorisationLock(const DenseFactorisationLock &) = delete;
-    DenseFactorisationLock &operator=(const DenseFactorisationLock &) = delete;
-};
+// Dense SPD inverse of the coarsest level (dense_spd.hip): A (n x n row-major, full symmetric) is replaced by its inverse (full
+// symmetric).  The build's own blocked Cholesky / triangular inverse / product on one stream with a fixed summation order:
+// bitwise reproducible whatever else shares the device.  Throws when a pivot is not positive.  The workspace grows, never shrinks.
+struct DenseWork { DevBuf<double> L, X, Tm, D; DevBuf<int> info; };
+void dense_spd_inverse(long long n, double *A, DenseWork &w, hipStream_t s);
 void launch_gs_sweep_q2_level1(int nx, int ny, int nz, const double *cK0, const double *Ef, int fx0, double *u, const double *b,
                                const uint8_t *mask, int forward, hipStream_t s, int first = 0, int count = 27);
 void launch_apply_q2_level1(int nx, int ny, int nz, const double *cK0, const double *Ef, int fx0, const double *u, const double *b,
@@ -267,8 +264,7 @@ struct vfem_mg {
     bool operators_valid = false;
     long long operators_version = 0;            // fine->operator_version the coarse operators were built for
     bool mf1_sym = false;                       // cK0[f] are mirror images of cK0[0]: level-1 sweeps read cK0[0] only
-    void *rocblas = nullptr;                    // rocblas_handle for the coarsest factorisation
-    vfem::DevBuf<int> info;
+    vfem::DenseWork dense;                      // workspace of the coarsest-level inverse
 };
 
 struct vfem_mlp {
