@@ -58,6 +58,9 @@ enum {
     VFEM_OPT_GS_RESIDENT  = 13,  /* level-0 Gauss-Seidel: K0 held in SGPRs (1, when K0 has the 36-value structure) or coefficient table (0) */
     VFEM_OPT_L1_SPLIT     = 15,  /* level-1 Gauss-Seidel (degree 1): waves sharing the eight element slots of a node, 1 / 2 / 4 / 8 */
     VFEM_OPT_STENCIL_SPLIT = 18, /* stored-stencil levels: the 27 neighbour blocks of a node shared by three waves (1, default) or one lane (0) */
+    VFEM_OPT_GS_MARCH     = 19,  /* level-0 Gauss-Seidel: plane-resident x-marching half sweeps (1, default) or the row-streaming kernels (0); the two
+                                    agree to rounding (different summation order) */
+    VFEM_OPT_GS_MARCH_CHUNKS = 20, /* x-chunks of the marching sweep (0 = default) */
     VFEM_OPT_Q2_GS_IMPL   = 16,  /* vfem_gsim: finest-level degree-2 sweep 0 element by element, 1 neighbour node by neighbour node, 2 the same with
                                     the neighbour rows staged through LDS by coalesced loads (default) */
     VFEM_OPT_TRANSFER_AXIS = 17, /* vfem_gsim: restriction / interpolation of 3-D levels above 100 k nodes axis by axis (1, default) or in one pass (0) */
@@ -167,6 +170,10 @@ int vfem_mg_import_level_ke(vfem_mg *mg, int level, const double *ke, void *stre
 int vfem_mg_apply_k(vfem_mg *mg, int level, const double *u, double *out, void *stream);
 int vfem_mg_residual(vfem_mg *mg, int level, const double *u, const double *b, double *r, void *stream);
 int vfem_mg_smooth(vfem_mg *mg, int level, double *u, const double *b, int forward, void *stream);
+/* `sweeps` consecutive calls of smoothingMulticoloredGS in one direction, as vcycle makes them (MG.hh:525-528, 546-549).  On the
+ * finest level the sweeps are out-of-place marching half sweeps (kernels_gs_march.hip) alternating between u and a scratch
+ * vector: an even count ends in u without a copy. */
+int vfem_mg_smooth_sweeps(vfem_mg *mg, int level, double *u, const double *b, int forward, int sweeps, void *stream);
 int vfem_mg_zero_dirichlet(vfem_mg *mg, int level, double *u, void *stream);
 int vfem_mg_restrict(vfem_mg *mg, int fine_level, const double *fine, double *coarse, void *stream);
 int vfem_mg_interpolate(vfem_mg *mg, int fine_level, const double *coarse, double *fine, int accumulate, void *stream);

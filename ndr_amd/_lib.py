@@ -66,6 +66,7 @@ SIGNATURES = {
     "vfem_mg_apply_k": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "vfem_mg_residual": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vfem_mg_smooth": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "vfem_mg_smooth_sweeps": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "vfem_mg_zero_dirichlet": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "vfem_mg_restrict": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "vfem_mg_interpolate": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),

@@ -207,6 +207,56 @@ static void mg_smooth(vfem_mg *mg, int l, double *u, const double *b, int forwar
                             (l == 1 && mg->fine->tune.l1_diag) ? L.Mdiag.p : nullptr);
 }
 
+// n consecutive sweeps of level l in one direction.  Level 0 runs them as marching half sweeps (kernels_gs_march.hip) when
+// it can: those are out of place, so the planes of either parity alternate between u and the level's scratch vector; an even
+// number of sweeps ends in u, an odd one is followed by a copy of the planes left in the scratch vector.
+static void mg_smooth_n(vfem_mg *mg, int l, double *u, const double *b, int forward, int n, hipStream_t s) {
+    MgLevel &L = mg->lv[l];
+    const vfem_sim *sim = mg->fine;
+    const Tuning &t = sim->tune;
+    if (!(l == 0 && L.kind == OP_MF0 && t.gs_march && t.gs_variant == 0 && t.gs_resident && sim->dGsTab.p && n > 0)) {
+        for (int i = 0; i < n; ++i) mg_smooth(mg, l, u, b, forward, s);
+        return;
+    }
+    L.tmp.reserve((size_t) L.d.nn * 3);
+    double *cur[2] = {u, u};                         // where the planes of local parity 0 / 1 currently live
+    const double *coef = sim->dGsTab.p + GS_TABLE_DOUBLES;
+    for (int i = 0; i < n; ++i)
+        for (int half = 0; half < 2; ++half) {
+            const int cx = forward ? half : 1 - half;                    // colour groups 0-3 / 4-7 of MG.hh:292-310, reversed for a backward sweep
+            const int cxl = cx ^ (L.xparity & 1);
+            if (cxl > L.d.NX - 1) continue;
+            double *dst = cur[cxl] == u ? L.tmp.p : u;
+            if (!launch_gs_march_mf0(L.d, coef, level_E(mg, 0), sim->E.p, sim->E.p + sim->n_store(), cur[cxl], cur[1 - cxl], dst, b, L.maskp,
+                                     cxl, forward, t.gs_march_chunks, s)) {
+                // buffers the kernel cannot take: finish in place with the row kernels
+                for (int par = 0; par < 2; ++par)
+                    if (cur[par] != u) { launch_copy_planes(L.d, par, cur[par], u, s); cur[par] = u; }
+                mg_smooth(mg, l, u, b, forward, s, 4 * half, 4);
+                continue;
+            }
+            cur[cxl] = dst;
+        }
+    for (int par = 0; par < 2; ++par)
+        if (cur[par] != u) launch_copy_planes(L.d, par, cur[par], u, s);
+}
+
+// one colour group (half sweep `half` of the sweep order) of level 0 by the marching kernel, result back in u; false: not available
+static bool mg_smooth_half(vfem_mg *mg, int l, double *u, const double *b, int forward, int half, hipStream_t s) {
+    MgLevel &L = mg->lv[l];
+    const vfem_sim *sim = mg->fine;
+    const Tuning &t = sim->tune;
+    if (!(l == 0 && L.kind == OP_MF0 && t.gs_march && t.gs_variant == 0 && t.gs_resident && sim->dGsTab.p)) return false;
+    const int cx = forward ? half : 1 - half;
+    const int cxl = cx ^ (L.xparity & 1);
+    if (cxl > L.d.NX - 1) return true;
+    L.tmp.reserve((size_t) L.d.nn * 3);
+    if (!launch_gs_march_mf0(L.d, sim->dGsTab.p + GS_TABLE_DOUBLES, level_E(mg, 0), sim->E.p, sim->E.p + sim->n_store(), u, u, L.tmp.p, b, L.maskp,
+                             cxl, forward, t.gs_march_chunks, s)) return false;
+    launch_copy_planes(L.d, cxl, L.tmp.p, u, s);
+    return true;
+}
+
 static void coarsest_solve(vfem_mg *mg, const double *b, double *x, hipStream_t s) {
     const long long n = 3 * mg->lv[mg->L].d.nn;
     launch_gemv_sym(n, mg->Ainv.p, b, x, s);
@@ -273,13 +323,13 @@ static void vcycle(vfem_mg *mg, int l, int nsmooth, bool residual_system, hipStr
     if (l == mg->L) { coarsest_solve(mg, L.b.p, L.x.p, s); return; }
     MgLevel &C = mg->lv[l + 1];
     launch_enforce_dirichlet(L.d.nn, L.maskp, l == 0 ? mg->fine->dvals.p : nullptr, L.x.p, residual_system ? 1 : 0, s);
-    for (int i = 0; i < nsmooth; ++i) mg_smooth(mg, l, L.x.p, L.b.p, 1, s);
+    mg_smooth_n(mg, l, L.x.p, L.b.p, 1, nsmooth, s);
     mg_apply(mg, l, L.x.p, L.b.p, 1, L.r.p, s);                       // computeResidual (Dirichlet zeroed)
     launch_restrict(C.d, L.d.NX, C.xshift, L.r.p, C.b.p, s);
     C.x.zero(s);
     vcycle(mg, l + 1, nsmooth, true, s);
     launch_prolong(C.d, L.d.NX, C.xshift, C.x.p, L.x.p, 1, s);
-    for (int i = 0; i < nsmooth; ++i) mg_smooth(mg, l, L.x.p, L.b.p, mg->symmetric_gs ? 0 : 1, s);
+    mg_smooth_n(mg, l, L.x.p, L.b.p, mg->symmetric_gs ? 0 : 1, nsmooth, s);
 }
 
 // fullMultigrid, MG.hh:486-508
@@ -418,6 +468,8 @@ int vfem_sim_set_option(vfem_sim *sim, int key, int value) {
         case VFEM_OPT_GS_RESIDENT:   t.gs_resident = (value != 0 && sim->gs_resident_ok) ? 1 : 0; break;
         case VFEM_OPT_L1_SPLIT:      if (value != 1 && value != 2 && value != 4 && value != 8) throw Error("level-1 slot split 1, 2, 4 or 8"); t.l1_split = value; break;
         case VFEM_OPT_STENCIL_SPLIT: t.stencil_split = value != 0; break;
+        case VFEM_OPT_GS_MARCH:      t.gs_march = value != 0; break;
+        case VFEM_OPT_GS_MARCH_CHUNKS: if (value < 0) throw Error("negative chunk count"); t.gs_march_chunks = value; break;
         case VFEM_OPT_L1_DIAG:       t.l1_diag = value != 0; ++sim->operator_version; break;   // hierarchies (re)build the blocks
         default: throw Error("unknown simulator option " + std::to_string(key));
     }
@@ -759,7 +811,15 @@ int vfem_mg_smooth(vfem_mg *mg, int level, double *u, const double *b, int forwa
     VFEM_TRY
     check_level(mg, level);
     if (level >= 1) update_operators(mg, S(stream));          // no-op when the operators match the current moduli
-    mg_smooth(mg, level, u, b, forward, S(stream));
+    mg_smooth_n(mg, level, u, b, forward, 1, S(stream));
+    VFEM_CATCH
+}
+int vfem_mg_smooth_sweeps(vfem_mg *mg, int level, double *u, const double *b, int forward, int sweeps, void *stream) {
+    VFEM_TRY
+    check_level(mg, level);
+    if (sweeps < 0) throw Error("negative sweep count");
+    if (level >= 1) update_operators(mg, S(stream));
+    mg_smooth_n(mg, level, u, b, forward, sweeps, S(stream));
     VFEM_CATCH
 }
 int vfem_mg_zero_dirichlet(vfem_mg *mg, int level, double *u, void *stream) {
@@ -800,6 +860,7 @@ int vfem_mg_smooth_colors(vfem_mg *mg, int level, double *u, const double *b, in
     check_level(mg, level);
     if (first < 0 || count < 0 || first + count > 8) throw Error("colour range out of [0, 8)");
     if (level >= 1) update_operators(mg, S(stream));          // no-op when the operators match the current moduli
+    if (first % 4 == 0 && count == 4 && mg_smooth_half(mg, level, u, b, forward, first / 4, S(stream))) return 0;
     mg_smooth(mg, level, u, b, forward, S(stream), first, count);
     VFEM_CATCH
 }

@@ -12,6 +12,7 @@
 // node-centred gather (no atomics, deterministic summation order).
 #include "vfem_internal.h"
 #include "device_utils.h"
+#include "gs_coef.h"
 
 #include <algorithm>
 #include <cmath>
@@ -175,16 +176,6 @@ __global__ void __launch_bounds__(256) k_gs_color_mf(Dims d, const double *__res
 // the node loop (the table version spends one 24-double scalar load per 18 multiply-adds).  build_gs_coef() fills the table
 // from K0 and checks that EVERY entry of K0 is reproduced bit for bit; otherwise the table kernels are used.
 // ------------------------------------------------------------------------------------------
-struct KSel { int idx; bool neg; };
-__host__ __device__ constexpr int kbit(int n, int d) { return (n >> (2 - d)) & 1; }
-__host__ __device__ constexpr KSel ksel(int n, int a, int m, int b) {
-    if (a == b) return KSel{a * 8 + (kbit(n, 0) == kbit(m, 0) ? 4 : 0) + (kbit(n, 1) == kbit(m, 1) ? 2 : 0) + (kbit(n, 2) == kbit(m, 2) ? 1 : 0), false};
-    const int lo = a < b ? a : b, hi = a < b ? b : a, t = 3 - a - b;
-    const bool t1 = kbit(n, lo) == kbit(m, hi);          // tau1 = s(n_lo) s(m_hi) = +1 iff the bits agree
-    const bool t2 = kbit(n, hi) == kbit(m, lo);
-    const int idx = 24 + (lo + hi - 1) * 4 + (kbit(n, t) == kbit(m, t) ? 2 : 0) + (t1 == t2 ? 1 : 0);
-    return KSel{idx, !(a < b ? t1 : t2)};
-}
 bool build_gs_coef(const double *K0, double *coef /* 36 */) {
     bool have[36] = {false};
     for (int q = 0; q < 36; ++q) coef[q] = 0.0;
@@ -245,7 +236,6 @@ void build_gs_table(const double *K0, double *tab /* 72*12 */) {
 // one z-segment (64 colour nodes from colour index l0) of the colour row (x, y): the work of one wave
 // RES: `tab` holds the 36 resident coefficients (build_gs_coef) instead of the 72 x 12 table (build_gs_table); the arithmetic
 // (order of the multiply-adds, operands) is the same in both forms, so the results agree bit for bit
-struct GsCoef { d8_t c[4]; d4_t t; };
 template <bool RES>
 __device__ __forceinline__ void gs_row_segment_mf0(const Dims &d, const double *__restrict__ tab, const GsCoef &ck, const double *__restrict__ E,
                                                    double *__restrict__ u, const double *__restrict__ b,
@@ -461,16 +451,6 @@ __device__ __forceinline__ void gs_row_segment_mf0(const Dims &d, const double *
     gs_solve(bms, M, mk, forward != 0, ud);
 #pragma unroll
     for (int c = 0; c < 3; ++c) u[3 * n + c] = uself[c] + ud[c];      // the node's own value came through the staged row
-}
-
-// the 36 resident coefficients into SGPRs (one wave-uniform load per wave)
-template <bool RES>
-__device__ __forceinline__ void gs_load_coef(const double *__restrict__ tab, GsCoef &ck) {
-    if constexpr (RES) {
-        asm volatile("s_load_dwordx16 %0, %5, 0x0\n\ts_load_dwordx16 %1, %5, 0x40\n\ts_load_dwordx16 %2, %5, 0x80\n\t"
-                     "s_load_dwordx16 %3, %5, 0xc0\n\ts_load_dwordx8 %4, %5, 0x100\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(ck.c[0]), "=&s"(ck.c[1]), "=&s"(ck.c[2]), "=&s"(ck.c[3]), "=&s"(ck.t) : "s"(tab));
-    }
 }
 
 template <bool RES>

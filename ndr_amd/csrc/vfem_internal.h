@@ -86,6 +86,8 @@ struct Tuning {
     int gs_resident = 0;    // level 0: K0 kept in 72 SGPRs (36 distinct values; set when build_gs_coef reproduces K0 bit for bit)
     int l1_split = 4;       // level 1: waves sharing the eight element slots of a node (1: one lane does all eight; 2, 4, 8)
     int stencil_split = 1;  // stored-stencil levels above the wave-per-node threshold: 27 neighbour blocks shared by three waves (1) or one lane (0)
+    int gs_march = 1;       // level 0: plane-resident x-marching half sweeps (kernels_gs_march.hip) where whole colour groups are swept; 0: row kernels
+    int gs_march_chunks = 0;   // x-chunks of the marching sweep (0 = default)
     int l1_diag = 0;        // level 1: diagonal blocks precomputed once per operator update instead of inside every sweep (measured
                             // 3 % SLOWER at 512^3, profiles/r02_gs_experiments.json: the sweep is not bound by its arithmetic)
 };
@@ -112,6 +114,12 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
 void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const double *gs_tab, const double *E, double *u,
                         const double *b, const uint8_t *mask, int forward, int xparity, int first, int count, hipStream_t s,
                         const Tuning &tune, bool mf1_sym, const double *mf1_diag = nullptr);
+// level 0: one half sweep (the four colours of local x parity cxl) marching along x with the planes in LDS; out of place:
+// relaxed planes read from uR, the others from uO, results to dst != uR.  false: cannot run on these buffers
+bool launch_gs_march_mf0(const Dims &d, const double *coef36, const double *E, const double *E_alloc_begin, const double *E_alloc_end,
+                         const double *uR, const double *uO, double *dst, const double *b, const uint8_t *mask,
+                         int cxl, int forward, int chunks, hipStream_t s);
+void launch_copy_planes(const Dims &d, int par, const double *src, double *dst, hipStream_t s);
 // level 1: diagonal 3x3 blocks of the virtual Galerkin operator, [nn][9] (once per operator update)
 void launch_mf1_diag(const Dims &d, const double *Dtab, const double *E, double *Mdiag, hipStream_t s);
 void build_gs_table(const double *K0, double *tab /* 72*12 doubles */);
@@ -245,6 +253,7 @@ struct MgLevel {
     vfem::DevBuf<double> Sn;                    // node-major copy of S on levels of at most WAVE_SWEEP_MAX_NODES nodes (wave-per-node sweep)
     vfem::DevBuf<double> Mdiag;                 // level 1: precomputed diagonal blocks [nn][9] of the virtual operator
     vfem::DevBuf<double> x, b, r;               // work vectors (m_x, m_b of MG.hh:755-756 + residual)
+    vfem::DevBuf<double> tmp;                   // level 0: second copy of the field for the out-of-place marching half sweeps
 };
 
 struct vfem_mg {
