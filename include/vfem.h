@@ -58,8 +58,8 @@ enum {
     VFEM_OPT_GS_RESIDENT  = 13,  /* level-0 Gauss-Seidel: K0 held in SGPRs (1, when K0 has the 36-value structure) or coefficient table (0) */
     VFEM_OPT_L1_SPLIT     = 15,  /* level-1 Gauss-Seidel (degree 1): waves sharing the eight element slots of a node, 1 / 2 / 4 / 8 */
     VFEM_OPT_STENCIL_SPLIT = 18, /* stored-stencil levels: the 27 neighbour blocks of a node shared by three waves (1, default) or one lane (0) */
-    VFEM_OPT_GS_MARCH     = 19,  /* level-0 Gauss-Seidel: plane-resident x-marching half sweeps (1, default) or the row-streaming kernels (0); the two
-                                    agree to rounding (different summation order) */
+    VFEM_OPT_GS_MARCH     = 19,  /* level-0 Gauss-Seidel: plane-resident x-marching half sweeps on grids of at least 12 M nodes (1, default), always (2),
+                                    or the row-streaming kernels (0); the two agree to rounding (different summation order) */
     VFEM_OPT_GS_MARCH_CHUNKS = 20, /* x-chunks of the marching sweep (0 = default) */
     VFEM_OPT_Q2_GS_IMPL   = 16,  /* vfem_gsim: finest-level degree-2 sweep 0 element by element, 1 neighbour node by neighbour node, 2 the same with
                                     the neighbour rows staged through LDS by coalesced loads (default) */

@@ -6,6 +6,7 @@
 //   vcycle / fullMultigrid / solve / applyPreconditionerInv   VoxelFEM/MultigridSolver.hh:447-553
 //   preconditionedConjugateGradient                           VoxelFEM/MultigridSolver.hh:679-732
 #include "vfem_internal.h"
+#include "gs_coef.h"
 
 #include <rocblas/rocblas.h>
 
@@ -138,11 +139,12 @@ void vfem_sim::update_k0() {
         if (!used[q] && std::fabs(Dfull[q]) > 1e-13 * maxabs) fast_ok = false;
     dK0.alloc(576);
     VFEM_HIP(hipMemcpy(dK0.p, K0, sizeof(K0), hipMemcpyHostToDevice));
-    double tab[GS_TABLE_DOUBLES + 36];
+    double tab[GS_TABLE_DOUBLES + 36 + 48];
     vfem::build_gs_table(K0, tab);
     gs_resident_ok = vfem::build_gs_coef(K0, tab + GS_TABLE_DOUBLES);
+    vfem::build_gs_coef_parts(tab + GS_TABLE_DOUBLES, tab + GS_TABLE_DOUBLES + 36, tab + GS_TABLE_DOUBLES + 60);
     tune.gs_resident = gs_resident_ok ? 1 : 0;
-    dGsTab.alloc(GS_TABLE_DOUBLES + 36);
+    dGsTab.alloc(GS_TABLE_DOUBLES + 36 + 48);
     VFEM_HIP(hipMemcpy(dGsTab.p, tab, sizeof(tab), hipMemcpyHostToDevice));
 }
 
@@ -207,6 +209,22 @@ static void mg_smooth(vfem_mg *mg, int l, double *u, const double *b, int forwar
                             (l == 1 && mg->fine->tune.l1_diag) ? L.Mdiag.p : nullptr);
 }
 
+// gs_march: 0 row kernels, 1 marching kernel on grids where it wins (measured per sweep, marching / rows: 512^3 7.7 / 9.6 ms, 256^3
+// 1.30 / 1.35, 128^3 0.25 / 0.23: its 12 x 58 tiles fit 2^k + 1 nodes badly on small grids), 2 marching kernel always
+static bool gs_march_wanted(const MgLevel &L, const Tuning &t) {
+    return t.gs_march == 2 || (t.gs_march == 1 && L.d.nn >= 12000000);
+}
+
+// level 0: solve data of the marching sweeps, recomputed when the moduli (or the material / Dirichlet mask: both bump the version) changed
+static void gs_solve_data(vfem_mg *mg, hipStream_t s) {
+    MgLevel &L = mg->lv[0];
+    const vfem_sim *sim = mg->fine;
+    if (L.gs_sd.p && L.gs_sd_version == sim->operator_version) return;
+    L.gs_sd.reserve((size_t) L.d.nn * 6);
+    launch_gs_solve_data(L.d, sim->dK0.p, level_E(mg, 0), L.maskp, L.gs_sd.p, s);
+    L.gs_sd_version = sim->operator_version;
+}
+
 // n consecutive sweeps of level l in one direction.  Level 0 runs them as marching half sweeps (kernels_gs_march.hip) when
 // it can: those are out of place, so the planes of either parity alternate between u and the level's scratch vector; an even
 // number of sweeps ends in u, an odd one is followed by a copy of the planes left in the scratch vector.
@@ -214,11 +232,12 @@ static void mg_smooth_n(vfem_mg *mg, int l, double *u, const double *b, int forw
     MgLevel &L = mg->lv[l];
     const vfem_sim *sim = mg->fine;
     const Tuning &t = sim->tune;
-    if (!(l == 0 && L.kind == OP_MF0 && t.gs_march && t.gs_variant == 0 && t.gs_resident && sim->dGsTab.p && n > 0)) {
+    if (!(l == 0 && L.kind == OP_MF0 && gs_march_wanted(L, t) && t.gs_variant == 0 && t.gs_resident && sim->dGsTab.p && n > 0)) {
         for (int i = 0; i < n; ++i) mg_smooth(mg, l, u, b, forward, s);
         return;
     }
     L.tmp.reserve((size_t) L.d.nn * 3);
+    gs_solve_data(mg, s);
     double *cur[2] = {u, u};                         // where the planes of local parity 0 / 1 currently live
     const double *coef = sim->dGsTab.p + GS_TABLE_DOUBLES;
     for (int i = 0; i < n; ++i)
@@ -227,7 +246,7 @@ static void mg_smooth_n(vfem_mg *mg, int l, double *u, const double *b, int forw
             const int cxl = cx ^ (L.xparity & 1);
             if (cxl > L.d.NX - 1) continue;
             double *dst = cur[cxl] == u ? L.tmp.p : u;
-            if (!launch_gs_march_mf0(L.d, coef, level_E(mg, 0), sim->E.p, sim->E.p + sim->n_store(), cur[cxl], cur[1 - cxl], dst, b, L.maskp,
+            if (!launch_gs_march_mf0(L.d, coef, level_E(mg, 0), sim->E.p, sim->E.p + sim->n_store(), cur[cxl], cur[1 - cxl], dst, b, L.gs_sd.p,
                                      cxl, forward, t.gs_march_chunks, s)) {
                 // buffers the kernel cannot take: finish in place with the row kernels
                 for (int par = 0; par < 2; ++par)
@@ -246,12 +265,13 @@ static bool mg_smooth_half(vfem_mg *mg, int l, double *u, const double *b, int f
     MgLevel &L = mg->lv[l];
     const vfem_sim *sim = mg->fine;
     const Tuning &t = sim->tune;
-    if (!(l == 0 && L.kind == OP_MF0 && t.gs_march && t.gs_variant == 0 && t.gs_resident && sim->dGsTab.p)) return false;
+    if (!(l == 0 && L.kind == OP_MF0 && gs_march_wanted(L, t) && t.gs_variant == 0 && t.gs_resident && sim->dGsTab.p)) return false;
     const int cx = forward ? half : 1 - half;
     const int cxl = cx ^ (L.xparity & 1);
     if (cxl > L.d.NX - 1) return true;
     L.tmp.reserve((size_t) L.d.nn * 3);
-    if (!launch_gs_march_mf0(L.d, sim->dGsTab.p + GS_TABLE_DOUBLES, level_E(mg, 0), sim->E.p, sim->E.p + sim->n_store(), u, u, L.tmp.p, b, L.maskp,
+    gs_solve_data(mg, s);
+    if (!launch_gs_march_mf0(L.d, sim->dGsTab.p + GS_TABLE_DOUBLES, level_E(mg, 0), sim->E.p, sim->E.p + sim->n_store(), u, u, L.tmp.p, b, L.gs_sd.p,
                              cxl, forward, t.gs_march_chunks, s)) return false;
     launch_copy_planes(L.d, cxl, L.tmp.p, u, s);
     return true;
@@ -371,6 +391,9 @@ int vfem_debug_set(int key, int value) {
 }
 #endif
 
+/* diagnostic, not part of include/vfem.h: per-phase s_memtime stamps of one workgroup of the marching Gauss-Seidel kernel */
+int vfem_debug_gsm_stamps(long long *device_buffer) { vfem::g_gsm_stamps = device_buffer; return 0; }
+
 int vfem_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -468,7 +491,7 @@ int vfem_sim_set_option(vfem_sim *sim, int key, int value) {
         case VFEM_OPT_GS_RESIDENT:   t.gs_resident = (value != 0 && sim->gs_resident_ok) ? 1 : 0; break;
         case VFEM_OPT_L1_SPLIT:      if (value != 1 && value != 2 && value != 4 && value != 8) throw Error("level-1 slot split 1, 2, 4 or 8"); t.l1_split = value; break;
         case VFEM_OPT_STENCIL_SPLIT: t.stencil_split = value != 0; break;
-        case VFEM_OPT_GS_MARCH:      t.gs_march = value != 0; break;
+        case VFEM_OPT_GS_MARCH:      if (value < 0 || value > 2) throw Error("marching sweep mode 0..2"); t.gs_march = value; break;
         case VFEM_OPT_GS_MARCH_CHUNKS: if (value < 0) throw Error("negative chunk count"); t.gs_march_chunks = value; break;
         case VFEM_OPT_L1_DIAG:       t.l1_diag = value != 0; ++sim->operator_version; break;   // hierarchies (re)build the blocks
         default: throw Error("unknown simulator option " + std::to_string(key));
@@ -488,6 +511,7 @@ int vfem_sim_set_dirichlet(vfem_sim *sim, const uint8_t *mask_host, const double
             for (int c = 0; c < 3; ++c)
                 if (((sim->hmask[n] >> c) & 1) && sim->hvals[3 * n + c] != 0.0) sim->nonzero_dirichlet = true;
     } else sim->hvals.assign((size_t) sim->d.nn * 3, 0.0);
+    ++sim->operator_version;                    // (the level-0 solve data of the marching sweeps carries the mask)
     VFEM_HIP(hipMemcpy(sim->dmask.p, sim->hmask.data(), (size_t) sim->d.nn, hipMemcpyHostToDevice));
     VFEM_HIP(hipMemcpy(sim->dvals.p, sim->hvals.data(), (size_t) sim->d.nn * 3 * sizeof(double), hipMemcpyHostToDevice));
     VFEM_CATCH

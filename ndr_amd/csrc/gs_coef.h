@@ -37,4 +37,44 @@ __device__ __forceinline__ double gs_coef_at(const GsCoef &ck) {
     return k.neg ? -v : v;
 }
 
+
+// The marching sweep (kernels_gs_march.hip) uses the coefficients in two parts, each of which needs 22 of the 36 magnitudes: the far
+// planes pair a node with neighbours whose x bit DIFFERS, the node's own plane with neighbours whose x bit AGREES.  Holding all 72
+// SGPRs across the kernel left too few for everything else (the compiler parked coefficients in VGPR lanes and fetched them back
+// with ~110 v_readlane per colour), so each part loads its own compact table of 24 doubles just before its multiply-adds.
+//   compact index: same component a: 4 a + (y-agree ? 2 : 0) + (z-agree ? 1 : 0);  pairs (x,y), (x,z): 12 + 4 pair + (idx & 3);
+//   pair (y,z): 20 + (t1 == t2)   [its third axis is x, whose agreement is what selects the part]
+__host__ __device__ constexpr int gs_part_index(int idx) {
+    if (idx < 24) return (idx / 8) * 4 + (idx % 8 & 3);
+    const int p = (idx - 24) / 4;
+    return p < 2 ? 12 + 4 * p + (idx & 3) : 20 + (idx & 1);
+}
+// part 0: x bits differ, part 1: x bits agree
+__host__ __device__ constexpr bool gs_in_part(int idx, int part) {
+    if (idx < 24) return ((idx % 8 >> 2) & 1) == part;
+    const int p = (idx - 24) / 4;
+    return p < 2 ? true : (((idx >> 1) & 1) == part);
+}
+inline void build_gs_coef_parts(const double *coef36, double *far24, double *mid24) {
+    for (int q = 0; q < 24; ++q) far24[q] = mid24[q] = 0.0;
+    for (int idx = 0; idx < 36; ++idx) {
+        if (gs_in_part(idx, 0)) far24[gs_part_index(idx)] = coef36[idx];
+        if (gs_in_part(idx, 1)) mid24[gs_part_index(idx)] = coef36[idx];
+    }
+}
+struct GsCoef24 { d8_t c[3]; };
+// requested and awaited inside one asm statement (device_utils.h: sload12); the wait also covers the LDS reads in flight
+__device__ __forceinline__ void gs_load_coef24(const double *__restrict__ tab, GsCoef24 &ck) {
+    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx16 %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(ck.c[0]), "=&s"(ck.c[1]), "=&s"(ck.c[2]) : "s"(tab) : "memory");
+}
+template <int PART, int N, int A, int M, int B>
+__device__ __forceinline__ double gs_coef24_at(const GsCoef24 &ck) {
+    constexpr KSel k = ksel(N, A, M, B);
+    static_assert(gs_in_part(k.idx, PART), "coefficient does not belong to this part");
+    constexpr int i = gs_part_index(k.idx);
+    const double v = ck.c[i / 8][i % 8];
+    return k.neg ? -v : v;
+}
+
 }  // namespace vfem

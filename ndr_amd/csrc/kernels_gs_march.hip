@@ -52,17 +52,18 @@ static_assert(2 * (U_INSTR + E_INSTR) <= 63, "one step of DMA must fit the 6-bit
 
 struct GsMarchArgs {
     Dims d;
-    const double *coef;            // 36 resident coefficients (build_gs_coef)
+    const double *coef;            // 36 resident coefficients (build_gs_coef) followed by the two 24-entry part tables (build_gs_coef_parts)
     const double *E;               // moduli of the level's elements, [nx][ny][nz]
     const char *e_first, *e_last;  // first / last admissible 16-byte piece of the moduli allocation
     const double *uR, *uO;         // current values of the planes of the relaxed parity / of the other parity
     const char *uR_first, *uR_last, *uO_first, *uO_last;
     double *dst;                   // receives the relaxed planes (other planes untouched)
     const double *b;
-    const uint8_t *mask;
+    const double *sd;              // solve data per node (k_gs_solve_data): inverse diagonal (mask folded in), strict lower part of the diagonal block
     int cxl;                       // local x parity of the relaxed planes
     int forward;                   // component order of the 3x3 solve (MG.hh:254-264)
     int steps_per_chunk;           // relaxed planes per block
+    long long *stamps;             // diagnostic (normally null): s_memtime stamps of one block, [wave][step < 8][16]
 };
 
 typedef double d2a_t __attribute__((ext_vector_type(2), aligned(16)));
@@ -74,24 +75,34 @@ __device__ __forceinline__ void gsm_glds16(const void *g, void *l) {
 __device__ __forceinline__ double flip(double v, unsigned long long sgn) {
     return __longlong_as_double(__double_as_longlong(v) ^ (long long) sgn);
 }
-// nine consecutive doubles from LDS; `odd`: the (wave-uniform) parity of idx, so that the 16-byte reads are aligned
-__device__ __forceinline__ void read9(const double *s, int idx, bool odd, double v[9]) {
-    if (odd) {
-        v[0] = s[idx];
-        const d2a_t a = *reinterpret_cast<const d2a_t *>(s + idx + 1), b = *reinterpret_cast<const d2a_t *>(s + idx + 3);
-        const d2a_t c = *reinterpret_cast<const d2a_t *>(s + idx + 5), e = *reinterpret_cast<const d2a_t *>(s + idx + 7);
-        v[1] = a[0]; v[2] = a[1]; v[3] = b[0]; v[4] = b[1]; v[5] = c[0]; v[6] = c[1]; v[7] = e[0]; v[8] = e[1];
-    } else {
-        const d2a_t a = *reinterpret_cast<const d2a_t *>(s + idx), b = *reinterpret_cast<const d2a_t *>(s + idx + 2);
-        const d2a_t c = *reinterpret_cast<const d2a_t *>(s + idx + 4), e = *reinterpret_cast<const d2a_t *>(s + idx + 6);
-        v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1]; v[4] = c[0]; v[5] = c[1]; v[6] = e[0]; v[7] = e[1];
-        v[8] = s[idx + 8];
+// The nine doubles of a node window start at an index whose parity depends on the row and the plane (the alignment shift of the
+// staged image).  Ten doubles from the 16-byte-aligned index at or below it are read instead, always as five 16-byte reads in the
+// same registers whatever the parity; the consumer then indexes w[off + j] with off = the parity, selected by a wave-uniform
+// branch around the multiply-adds.  (Reading by parity -- 8 + 4 x 16 bytes or 4 x 16 + 8 -- left the two paths with different
+// register layouts, which the compiler reconciled with moves behind a wait for the data: every row's latency was exposed.)
+__device__ __forceinline__ void read10(const double *s, int idx_aligned, double w[10]) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const d2a_t a = *reinterpret_cast<const d2a_t *>(s + idx_aligned + 2 * q);
+        w[2 * q] = a[0]; w[2 * q + 1] = a[1];
     }
 }
 
-template <int P>      // parity of the first in-plane colour: 0 forward colour order, 1 reverse
+__device__ __forceinline__ long long gsm_now() {
+    long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");      // 100 MHz wall clock (s_memtime does not advance at the shader clock here)
+    return t;
+}
+
+// The parity of a window's first double (the consumer's offset into its ten doubles, see read10) is
+//     (k + (P+1) + base parity of the buffer + (plane & ppar) + ALT ((P+1) + staged row)) & 1,     ALT = NZ & 1, ppar = (3 NY NZ) & 1:
+// tile origins have the parity of P, so nothing in it depends on the tile, and the planes of a launch have fixed parities.  It is
+// therefore QF + k + ALT (ro + dy) for the far planes and QM + k + ALT (ro + dy) for the relaxed plane with launch-uniform QF, QM,
+// which are template parameters: every register index in the multiply-adds is a compile-time constant.
+template <int ALT, int QF, int QM>
 __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs A) {
     using namespace gsm;
+    const int P = A.forward ? 0 : 1;              // parity of the first in-plane colour: 0 forward colour order, 1 reverse
     extern __shared__ __align__(16) unsigned char smem[];
     double *sU = reinterpret_cast<double *>(smem);
     double *sE = sU + NU * U_SLOT_D;
@@ -115,8 +126,8 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
     const int yl = yb - 1, zl = zb - 3;                                 // node row / column of staged index 0
     const int k0u = zl < -1 ? -1 : zl;                                  // first node column held by a staged node row
     const int cshift = k0u - zl;
-    const int ek0u = zl < 0 ? 0 : zl;                                   // first element column held by a staged element row
-    const int ecshift = ek0u - zl;
+    const int ek0u = k0u;                                               // first element column held by a staged element row
+    const int ecshift = cshift;
 
     const long long plane = (long long) d.NY * d.NZ, elayer = (long long) d.ny * d.nz;
     const int ppar = (int) ((3 * plane) & 1), epar = (int) (elayer & 1);
@@ -126,6 +137,9 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
         int jj = yl + ry; jj = jj < 0 ? 0 : (jj > d.NY - 1 ? d.NY - 1 : jj);
         return ((jj & d.NZ) ^ k0u) & 1;                                 // (3 (jj NZ + k0u)) & 1
     };
+
+    // a tile whose staged element rows / columns reach beyond the grid: the compute waves zero those moduli in LDS after they land
+    const bool fix_yz = yl < 0 || yl + EY - 1 > d.ny - 1 || zl < 0 || zl + EZ - 1 > d.nz - 1;
 
     // =========================== DMA wave ===========================
     if (wave == CW) {
@@ -145,8 +159,8 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
             int r = Pc / PE, c = Pc - r * PE;
             if (r > EY - 1) { r = EY - 1; c = PE - 1; }
             int jj = yl + r; jj = jj < 0 ? 0 : (jj > d.ny - 1 ? d.ny - 1 : jj);
-            const long long rs = (long long) jj * d.nz + ek0u;
-            ego[t] = (unsigned) ((rs + 2LL * c) * 2 + (rs & 1));
+            const long long rs = (long long) jj * d.nz + ek0u;       // >= -1
+            ego[t] = (unsigned) ((rs + 1 + 2LL * c) * 2 + (rs & 1));   // biased by +1 double
         }
         auto issueU = [&](int j) {
             const int i = plane_of(j);
@@ -166,7 +180,7 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
         auto issueE = [&](int j) {
             int il = x0 - 1 + j; il = il < 0 ? 0 : (il > d.nx - 1 ? d.nx - 1 : il);
             const int par0 = bparE + (il & epar);
-            const double *pb = A.E + (long long) il * elayer;
+            const double *pb = A.E + (long long) il * elayer - 1;     // (the bias of ego)
             unsigned char *slot = reinterpret_cast<unsigned char *>(sE + (j % NE) * E_SLOT_D);
 #pragma unroll
             for (int t = 0; t < E_INSTR; ++t) {
@@ -180,150 +194,289 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                               // B0: the planes of step m have landed; step m-1 is finished
             if (m + 1 < nsteps) { issueU(2 * m + 3); issueU(2 * m + 4); issueE(2 * m + 2); issueE(2 * m + 3); }
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_s_barrier();
+            if (fix_yz || x0 + 2 * m - 1 < 0 || x0 + 2 * m > d.nx - 1) __builtin_amdgcn_s_barrier();   // (the compute waves zero moduli outside the grid)
+            __builtin_amdgcn_s_barrier();                               // B1
         }
         return;
     }
 
     // =========================== compute waves ===========================
-    GsCoef ck;
-    gs_load_coef<true>(A.coef, ck);
-    const int h = lane >> 5, cl = lane & 31;                            // half (0: low-x element slots, 1: high-x, mirrored), column index
+    const int h = lane >> 5, cl = lane & 31;                            // half (0: low side, 1: high side, computed on mirrored data), column index
     const unsigned long long sgn = h ? 0x8000000000000000ull : 0ull;
+    const int z0s = zb < 0 ? 0 : zb;                                    // owned columns inside the grid: [z0s, z1s]
+    const int z1s = zb + 2 * C - 1 > d.NZ - 1 ? d.NZ - 1 : zb + 2 * C - 1;
+    const int nd_store = 3 * (z1s - z0s + 1);
+    const bool stamping = A.stamps && blockIdx.x == 0 && blockIdx.y == 1 && blockIdx.z == 1;
+    auto stamp = [&](int m, int slot) {
+        if (stamping && m < 8) {
+            const long long t = gsm_now();
+            if (lane == 0) A.stamps[(wave * 8 + m) * 16 + slot] = t;
+        }
+    };
+    // right-hand side and solve data (inverse diagonal with the Dirichlet mask folded in, strict lower part of the node's
+    // diagonal block; k_gs_solve_data) of the node this lane relaxes in colour k of plane xx, requested one colour ahead of
+    // their use (bd[k & 1])
+    double bd[2][9];
+    auto request = [&](auto kc, int xx) {
+        constexpr int k = decltype(kc)::value, ro = k >> 1;
+        constexpr int nrows = R + 1 - ro, ncols = C + 3 - k;
+        const int y = yl + 1 + ro + 2 * wave, z = zl + 1 + k + 2 * cl;
+        const bool mine = h == 0 && wave < nrows && cl < ncols && y >= 0 && y < d.NY && z >= 0 && z < d.NZ;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) bd[k & 1][q] = 0.0;
+        if (mine) {
+            const long long n = ((long long) xx * d.NY + y) * d.NZ + z;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) bd[k & 1][q] = A.b[3 * n + q];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) bd[k & 1][3 + q] = A.sd[6 * n + q];
+        }
+    };
+    request(std::integral_constant<int, 0>{}, x0);
 
     for (int m = 0; m < nsteps; ++m) {
         const int x = x0 + 2 * m;
+        stamp(m, 0);
         __builtin_amdgcn_s_barrier();                                   // B0
+        stamp(m, 1);
         const int midoff = ((2 * m + 1) % NU) * U_SLOT_D;
         const int faroff = ((2 * m + 2 * h) % NU) * U_SLOT_D;           // per lane: plane x-1 (h = 0) or x+1 (h = 1)
         const int shM = bparR + (x & ppar);                             // + row parity = alignment shift of the staged rows
         const int shF = bparO + (plane_of(2 * m) & ppar);               // (planes x-1 and x+1 have the same parity)
-        const int il = x - 1 + h;                                       // element layer of this half
-        const bool layer_ok = il >= 0 && il < d.nx;
-        const int ilc = il < 0 ? 0 : (il > d.nx - 1 ? d.nx - 1 : il);
-        const int eoff = ((2 * m + h) % NE) * E_SLOT_D;
-        const int esh0 = bparE + (ilc & epar);
-
-        static_for<4>([&](auto kc) {
-            constexpr int k = decltype(kc)::value, ro = k >> 1;
-            constexpr int nrows = R + 1 - ro, ncols = C + 3 - k;
-            if (wave < nrows) {
-                const int ry = 1 + ro + 2 * wave;                       // staged row of the node
-                const int y = yl + ry;
-                const int ce = cl < ncols ? cl : ncols - 1;             // lanes beyond the colour's columns shadow the last one
-                const int czn = 1 + k + 2 * ce;                         // staged column
-                const int z = zl + czn;
-                const bool node_ok = cl < ncols && y >= 0 && y < d.NY && z >= 0 && z < d.NZ;
-                const bool mine = node_ok && h == 0;
-                // right-hand side and mask (consumed at the end of the phase)
-                const long long n = ((long long) x * d.NY + (y < 0 ? 0 : (y > d.NY - 1 ? d.NY - 1 : y))) * d.NZ + (z < 0 ? 0 : (z > d.NZ - 1 ? d.NZ - 1 : z));
-                double bv[3] = {0.0, 0.0, 0.0};
-                uint8_t mk = 0;
-                if (mine) {
-                    bv[0] = A.b[3 * n]; bv[1] = A.b[3 * n + 1]; bv[2] = A.b[3 * n + 2];
-                    mk = A.mask[n];
-                }
-                // the four moduli of this half: elements (y - 1 + dj, z - 1 + dk) of layer il
-                double e4[4];
-#pragma unroll
-                for (int sl = 0; sl < 4; ++sl) {
-                    const int dj = sl >> 1, dk = sl & 1;
-                    const int ey = y - 1 + dj, ez = z - 1 + dk;
-                    const bool ok = node_ok && layer_ok && ey >= 0 && ey < d.ny && ez >= 0 && ez < d.nz;
-                    const int eyc = ey < 0 ? 0 : (ey > d.ny - 1 ? d.ny - 1 : ey);
-                    int ec = czn - 1 + dk - ecshift; ec = ec < 0 ? 0 : ec;
-                    const int esh = (esh0 + (((eyc & d.nz) ^ ek0u) & 1)) & 1;
-                    const double v = sE[eoff + (ry - 1 + dj) * EROW_D + ec + esh];
-                    e4[sl] = ok ? v : 0.0;
-                }
-                int ni = czn - 1 - cshift;                              // staged node index of the window's first node (z - 1)
-                if (ni < 0) ni &= 1;                                    // (outside the grid: any window of the right alignment)
-                const int nipar = (k + cshift) & 1;                     // parity of ni, wave-uniform
-
-                double T[4][3];
-#pragma unroll
-                for (int sl = 0; sl < 4; ++sl) { T[sl][0] = 0.0; T[sl][1] = 0.0; T[sl][2] = 0.0; }
-                double uself[3] = {0.0, 0.0, 0.0};
-                static_for<6>([&](auto rc6) {
-                    constexpr int t = decltype(rc6)::value / 3, dy = decltype(rc6)::value % 3 - 1;      // t = 0: far plane, 1: the node's plane
-                    const int rr = ry + dy;
-                    const int sh = ((t ? shM : shF) + row_par(rr)) & 1;
-                    const int idx = (t ? midoff : faroff) + rr * ROW_D + 3 * ni + sh;
-                    double v[9];
-                    read9(sU, idx, ((nipar + sh) & 1) != 0, v);
-                    if (t == 1 && dy == 0) { uself[0] = v[3]; uself[1] = v[4]; uself[2] = v[5]; }
-                    v[0] = flip(v[0], sgn); v[3] = flip(v[3], sgn); v[6] = flip(v[6], sgn);
-                    // elements of this half touching the row: dj - 1 + my == dy
-                    static_for<4>([&](auto ec) {
-                        constexpr int dj = decltype(ec)::value >> 1, my = decltype(ec)::value & 1;
-                        if constexpr (dj - 1 + my == dy) {
-                            static_for<4>([&](auto zc) {
-                                constexpr int dk = decltype(zc)::value >> 1, mz = decltype(zc)::value & 1;
-                                constexpr int n3 = dk + mz;
-                                constexpr int ln = 4 + 2 * (1 - dj) + (1 - dk), lm = 4 * t + 2 * my + mz;
-                                static_for<9>([&](auto qc) {
-                                    constexpr int r = decltype(qc)::value / 3, c = decltype(qc)::value % 3;
-                                    T[2 * dj + dk][r] = fma(gs_coef_at<ln, r, lm, c>(ck), v[3 * n3 + c], T[2 * dj + dk][r]);
-                                });
-                            });
-                        }
-                    });
-                });
-                // partial sums of this half (in the mirrored frame for h = 1), then back to the node's frame
-                double Sp[3] = {0.0, 0.0, 0.0}, Mp[9];
-#pragma unroll
-                for (int q = 0; q < 9; ++q) Mp[q] = 0.0;
-                static_for<4>([&](auto sc) {
-                    constexpr int sl = decltype(sc)::value, dj = sl >> 1, dk = sl & 1, ln = 4 + 2 * (1 - dj) + (1 - dk);
-                    static_for<3>([&](auto rc) {
-                        constexpr int r = decltype(rc)::value;
-                        Sp[r] = fma(e4[sl], T[sl][r], Sp[r]);
-                        static_for<3>([&](auto cc) {
-                            constexpr int c = decltype(cc)::value;
-                            Mp[3 * r + c] = fma(e4[sl], gs_coef_at<ln, r, ln, c>(ck), Mp[3 * r + c]);
-                        });
-                    });
-                });
-                Sp[0] = flip(Sp[0], sgn);
-                Mp[1] = flip(Mp[1], sgn); Mp[2] = flip(Mp[2], sgn); Mp[3] = flip(Mp[3], sgn); Mp[6] = flip(Mp[6], sgn);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) Sp[q] += __shfl_down(Sp[q], 32, 64);
-#pragma unroll
-                for (int q = 0; q < 9; ++q) Mp[q] += __shfl_down(Mp[q], 32, 64);
-                if (mine) {
-                    double bms[3], ud[3];
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) bms[q] = bv[q] - Sp[q];
-                    gs_solve(bms, Mp, mk, A.forward != 0, ud);
-                    const int iself = midoff + ry * ROW_D + 3 * (czn - cshift) + ((shM + row_par(ry)) & 1);
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) sU[iself + q] = uself[q] + ud[q];
-                }
+        // element layers x-1 (ring slot of stream index 2m) and x (2m + 1)
+        const bool lay_ok[2] = {x - 1 >= 0, x <= d.nx - 1};
+        const int eoffs[2] = {((2 * m) % NE) * E_SLOT_D, ((2 * m + 1) % NE) * E_SLOT_D};
+        const int eshl[2] = {bparE + ((x - 1 < 0 ? 0 : x - 1) & epar), bparE + ((x > d.nx - 1 ? d.nx - 1 : x) & epar)};
+        auto erow_shift = [&](int layer, int r) {                       // alignment shift of staged element row r of a layer
+            int jj = yl + r; jj = jj < 0 ? 0 : (jj > d.ny - 1 ? d.ny - 1 : jj);
+            return (eshl[layer] + (((jj & d.nz) ^ ek0u) & 1)) & 1;
+        };
+        if (fix_yz || !lay_ok[0] || !lay_ok[1]) {
+            // moduli of elements outside the grid are zero: written over whatever the (clamped) DMA brought, once per layer
+            for (int q = threadIdx.y * 64 + lane; q < 2 * EY * (EZ + 1); q += CW * 64) {
+                const int layer = q / (EY * (EZ + 1)), q2 = q - layer * (EY * (EZ + 1));
+                const int r = q2 / (EZ + 1), ci = q2 - r * (EZ + 1);
+                const int ey = yl + r, ez = ek0u + ci;
+                if (!lay_ok[layer] || ey < 0 || ey > d.ny - 1 || ez < 0 || ez > d.nz - 1) sE[eoffs[layer] + r * EROW_D + ci + erow_shift(layer, r)] = 0.0;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-        });
-
-        // the finished plane: owned rows [yb, yb + 2R) x columns [zb, zb + 2C), dense 8-byte stores row by row
-        {
-            const int z0 = zb < 0 ? 0 : zb;
-            int z1 = zb + 2 * C - 1; z1 = z1 > d.NZ - 1 ? d.NZ - 1 : z1;
-            const int nd = 3 * (z1 - z0 + 1);
-            for (int row = wave; row < 2 * R; row += CW) {
-                const int y = yb + row;
-                if (y < 0 || y > d.NY - 1) continue;
-                const int ry = 1 + row;
-                const double *src = sU + midoff + ry * ROW_D + 3 * (z0 - k0u) + ((shM + row_par(ry)) & 1);
-                double *dp = A.dst + 3 * (((long long) x * d.NY + y) * d.NZ + z0);
-                for (int i = lane; i < nd; i += 64) dp[i] = src[i];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+
+        auto phase = [&](auto kc) {
+            constexpr int k = decltype(kc)::value, ro = k >> 1;
+            constexpr int nrows = R + 1 - ro, ncols = C + 3 - k;
+            if (wave >= nrows) return;
+            const int ry = 1 + ro + 2 * wave;                           // staged row of the node
+            const int y = yl + ry;
+            const int ce = cl < ncols ? cl : ncols - 1;                 // lanes beyond the colour's columns shadow the last one
+            const int czn = 1 + k + 2 * ce;                             // staged column
+            const int z = zl + czn;
+            const bool mine = h == 0 && cl < ncols && y >= 0 && y < d.NY && z >= 0 && z < d.NZ;
+            int ni = czn - 1 - cshift;                                  // staged node index of the window's first node (z - 1)
+            ni = max(ni, ni & 1);                                       // (outside the grid: any window of the right alignment)
+            // Rows read: the far plane's rows y-1, y, y+1; the node's own plane: row y and the row on this half's side.
+            // A row outside the grid (only ever multiplied by zero moduli) is replaced by its mirror image on the other side,
+            // which has the same parity
+            const int rlo = y - 1 >= 0 ? ry - 1 : ry + 1, rhi = y + 1 <= d.NY - 1 ? ry + 1 : ry - 1;
+            const int rside = h ? rhi : rlo;
+            constexpr int OFC = (QF + k + ALT * ro) & 1, OFS = (QF + k + ALT * (ro + 1)) & 1;      // window offsets: far row y, far rows y -+ 1
+            constexpr int OMC = (QM + k + ALT * ro) & 1, OMS = (QM + k + ALT * (ro + 1)) & 1;      // own plane: row y, side row
+            double wf[3][10], wm[2][10];
+            {
+                const int shc = (shF + row_par(ry)) & 1, shs = (shF + row_par(rlo)) & 1;
+                read10(sU, faroff + rlo * ROW_D + 3 * ni + shs - OFS, wf[0]);
+                read10(sU, faroff + ry * ROW_D + 3 * ni + shc - OFC, wf[1]);
+                read10(sU, faroff + rhi * ROW_D + 3 * ni + shs - OFS, wf[2]);
+                const int mhc = (shM + row_par(ry)) & 1, mhs = (shM + row_par(rlo)) & 1;
+                read10(sU, midoff + rside * ROW_D + 3 * ni + mhs - OMS, wm[0]);
+                read10(sU, midoff + ry * ROW_D + 3 * ni + mhc - OMC, wm[1]);
+            }
+            // moduli of the elements (layer, y - 1 + dj, z - 1 + dk); zero outside the grid (fixed up in LDS above)
+            const int ecol = max(czn - 1 - ecshift, 0);
+            // layer of this half for the four far slots; both layers for the element row dj = h of the node's own plane
+            // (per-lane layer: the ring offset and the alignment shift are selected, not the data)
+            const int eo_mine = h ? eoffs[1] : eoffs[0], eo_other = h ? eoffs[0] : eoffs[1];
+            double ea[2][2], eb[2];
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+                const int r = ry - 1 + dj;
+                const int s0 = erow_shift(0, r), s1 = erow_shift(1, r);
+                const int rowoff = r * EROW_D + ecol;
+                const int sm = h ? s1 : s0;
+#pragma unroll
+                for (int dk = 0; dk < 2; ++dk) ea[dj][dk] = sE[eo_mine + rowoff + dk + sm];
+            }
+            {
+                const int r = ry - 1 + h;
+                int jj = yl + r; jj = jj < 0 ? 0 : (jj > d.ny - 1 ? d.ny - 1 : jj);
+                const int so = ((h ? eshl[0] : eshl[1]) + (((jj & d.nz) ^ ek0u) & 1)) & 1;
+#pragma unroll
+                for (int dk = 0; dk < 2; ++dk) eb[dk] = sE[eo_other + r * EROW_D + ecol + dk + so];
+            }
+            double ep[2], em[2];
+#pragma unroll
+            for (int dk = 0; dk < 2; ++dk) {
+                const double own = h ? ea[1][dk] : ea[0][dk];           // this half's layer of element row y - 1 + h
+                // layers x-1, x:  h = 0: (own, other);  h = 1: (other, own)  ->  sum is symmetric, the difference changes sign with h
+                ep[dk] = own + eb[dk];
+                em[dk] = flip(own - eb[dk], sgn);
+            }
+            // the node's own value (used by the lanes h = 0, where nothing is mirrored)
+            const double uself[3] = {wm[1][OMC + 3], wm[1][OMC + 4], wm[1][OMC + 5]};
+
+            // ---- far plane: the four element slots on this half's side in x (x-mirrored for h = 1) ----
+            GsCoef24 ckF;
+            gs_load_coef24(A.coef + 36, ckF);                           // (waits for the LDS reads above as well)
+            double T[4][3];                                             // (the first term of every accumulator is a plain product)
+            static_for<3>([&](auto dc) {
+                constexpr int dy = decltype(dc)::value - 1, off = dy == 0 ? OFC : OFS;
+                const double *w = wf[dy + 1];
+                const double v[9] = {flip(w[off], sgn), w[off + 1], w[off + 2], flip(w[off + 3], sgn), w[off + 4], w[off + 5],
+                                     flip(w[off + 6], sgn), w[off + 7], w[off + 8]};
+                static_for<4>([&](auto ec) {
+                    constexpr int dj = decltype(ec)::value >> 1, my = decltype(ec)::value & 1;
+                    if constexpr (dj - 1 + my == dy) {
+                        static_for<4>([&](auto zc) {
+                            constexpr int dk = decltype(zc)::value >> 1, mz = decltype(zc)::value & 1;
+                            constexpr int n3 = dk + mz;
+                            constexpr int ln = 4 + 2 * (1 - dj) + (1 - dk), lm = 2 * my + mz;
+                            static_for<9>([&](auto qc) {
+                                constexpr int r = decltype(qc)::value / 3, c = decltype(qc)::value % 3;
+                                if constexpr (my == 0 && mz == 0 && c == 0) T[2 * dj + dk][r] = gs_coef24_at<0, ln, r, lm, c>(ckF) * v[3 * n3 + c];
+                                else T[2 * dj + dk][r] = fma(gs_coef24_at<0, ln, r, lm, c>(ckF), v[3 * n3 + c], T[2 * dj + dk][r]);
+                            });
+                        });
+                    }
+                });
+            });
+            // ---- the node's own plane: the element row on this half's side in y (y-mirrored for h = 1), both layers at once.
+            // K0[(n ^ 4, a), (m ^ 4, b)] = s_a s_b K0[(n, a), (m, b)] with s_x = -1: the entries with exactly one x index change
+            // sign between the two layers ("odd", weighted by E(x-1) - E(x)), the others do not ("even", E(x-1) + E(x)) ----
+            GsCoef24 ckM;
+            gs_load_coef24(A.coef + 60, ckM);
+            double Te[2][3], To[2][3];
+            static_for<2>([&](auto mc) {
+                constexpr int my = decltype(mc)::value, off = my ? OMC : OMS;
+                const double *w = wm[my];
+                const double v[9] = {w[off], flip(w[off + 1], sgn), w[off + 2], w[off + 3], flip(w[off + 4], sgn), w[off + 5],
+                                     w[off + 6], flip(w[off + 7], sgn), w[off + 8]};
+                static_for<4>([&](auto zc) {
+                    constexpr int dk = decltype(zc)::value >> 1, mz = decltype(zc)::value & 1;
+                    constexpr int n3 = dk + mz;
+                    constexpr int ln = 4 + 2 + (1 - dk), lm = 4 + 2 * my + mz;
+                    static_for<9>([&](auto qc) {
+                        constexpr int r = decltype(qc)::value / 3, c = decltype(qc)::value % 3;
+                        constexpr bool even = (r == 0) == (c == 0);
+                        constexpr bool first = my == 0 && mz == 0 && c == (even ? (r == 0 ? 0 : 1) : (r == 0 ? 1 : 0));      // first entry of its class in the row
+                        if constexpr (even) {
+                            if constexpr (first) Te[dk][r] = gs_coef24_at<1, ln, r, lm, c>(ckM) * v[3 * n3 + c];
+                            else Te[dk][r] = fma(gs_coef24_at<1, ln, r, lm, c>(ckM), v[3 * n3 + c], Te[dk][r]);
+                        } else {
+                            if constexpr (first) To[dk][r] = gs_coef24_at<1, ln, r, lm, c>(ckM) * v[3 * n3 + c];
+                            else To[dk][r] = fma(gs_coef24_at<1, ln, r, lm, c>(ckM), v[3 * n3 + c], To[dk][r]);
+                        }
+                    });
+                });
+            });
+            // partial sums of this half in its mirrored frames, then back to the node's frame
+            double Sf[3] = {0.0, 0.0, 0.0}, Sm[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) Sf[r] = fma(ea[sl >> 1][sl & 1], T[sl][r], Sf[r]);
+#pragma unroll
+            for (int dk = 0; dk < 2; ++dk)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { Sm[r] = fma(ep[dk], Te[dk][r], Sm[r]); Sm[r] = fma(em[dk], To[dk][r], Sm[r]); }
+            double Sp[3] = {flip(Sf[0], sgn) + Sm[0], Sf[1] + flip(Sm[1], sgn), Sf[2] + Sm[2]};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) Sp[q] += __shfl_down(Sp[q], 32, 64);
+            if (mine) {
+                // component-sequential solve of MG.hh:254-264 with the stored inverse diagonal (0 for a fixed component)
+                const double *B = bd[k & 1], *D = bd[k & 1] + 3;        // D: i00 i11 i22 m10 m20 m21
+                const double b0 = B[0] - Sp[0], b1 = B[1] - Sp[1], b2 = B[2] - Sp[2];
+                double ud0, ud1, ud2;
+                if (A.forward) {
+                    ud0 = b0 * D[0];
+                    ud1 = (b1 - D[3] * ud0) * D[1];
+                    ud2 = (b2 - (D[4] * ud0 + D[5] * ud1)) * D[2];
+                } else {
+                    ud2 = b2 * D[2];
+                    ud1 = (b1 - D[5] * ud2) * D[1];
+                    ud0 = (b0 - (D[3] * ud1 + D[4] * ud2)) * D[0];
+                }
+                const int iself = midoff + ry * ROW_D + 3 * (czn - cshift) + ((shM + row_par(ry)) & 1);
+                sU[iself] = uself[0] + ud0; sU[iself + 1] = uself[1] + ud1; sU[iself + 2] = uself[2] + ud2;
+            }
+        };
+        // a finished row of this wave (owned rows only), dense 8-byte stores
+        auto store_row = [&](int ry) {
+            const int y = yl + ry;
+            if (ry < 1 || ry > 2 * R || y < 0 || y > d.NY - 1) return;
+            const double *src = sU + midoff + ry * ROW_D + 3 * (z0s - k0u) + ((shM + row_par(ry)) & 1);
+            double *dp = A.dst + 3 * (((long long) x * d.NY + y) * d.NZ + z0s);
+            for (int i = lane; i < nd_store; i += 64) dp[i] = src[i];
+        };
+
+        // rows of parity P: colours (P,P) then (P,Q); the second reads the first's updates of its own row only, so the two are
+        // ordered inside the wave (its LDS accesses execute in order) and need no workgroup barrier
+        request(std::integral_constant<int, 1>{}, x);
+        phase(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_wave_barrier();
+        stamp(m, 2);
+        request(std::integral_constant<int, 2>{}, x);
+        phase(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_wave_barrier();
+        stamp(m, 3);
+        store_row(1 + 2 * wave);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(m, 4);
+        __builtin_amdgcn_s_barrier();                                   // B1: the rows of parity P are final
+        stamp(m, 5);
+        request(std::integral_constant<int, 3>{}, x);
+        phase(std::integral_constant<int, 2>{});
+        __builtin_amdgcn_wave_barrier();
+        stamp(m, 6);
+        if (m + 1 < nsteps) request(std::integral_constant<int, 0>{}, x + 2);
+        phase(std::integral_constant<int, 3>{});
+        __builtin_amdgcn_wave_barrier();
+        if (wave < R) store_row(2 + 2 * wave);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(m, 7);
     }
 }
+
+// Solve data of the level-0 sweeps, once per operator update: per node the inverse diagonal of its 3x3 diagonal block
+// M = sum_e E_e K0[n-block] (MG.hh:199-220) with the Dirichlet mask folded in (0 for a fixed component, MG.hh:258-262) and the
+// strict lower part of M (it is symmetric): sd[n] = { 1/M00, 1/M11, 1/M22, M10, M20, M21 }
+__global__ void __launch_bounds__(256) k_gs_solve_data(Dims d, const double *__restrict__ K0, const double *__restrict__ E,
+                                                       const uint8_t *__restrict__ mask, double *__restrict__ sd) {
+    const long long n = (long long) blockIdx.x * 256 + threadIdx.x;
+    if (n >= d.nn) return;
+    const int k = (int) (n % d.NZ), j = (int) ((n / d.NZ) % d.NY), i = (int) (n / ((long long) d.NZ * d.NY));
+    double M[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};           // 00 11 22 10 20 21
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+        const int ex = i - 1 + ((sl >> 2) & 1), ey = j - 1 + ((sl >> 1) & 1), ez = k - 1 + (sl & 1);
+        if (ex < 0 || ex >= d.nx || ey < 0 || ey >= d.ny || ez < 0 || ez >= d.nz) continue;
+        const double Ee = E[((long long) ex * d.ny + ey) * d.nz + ez];
+        const double *blk = K0 + (3 * (7 - sl)) * 24 + 3 * (7 - sl);
+        M[0] = fma(Ee, blk[0], M[0]); M[1] = fma(Ee, blk[24 + 1], M[1]); M[2] = fma(Ee, blk[48 + 2], M[2]);
+        M[3] = fma(Ee, blk[24], M[3]); M[4] = fma(Ee, blk[48], M[4]); M[5] = fma(Ee, blk[48 + 1], M[5]);
+    }
+    const uint8_t mk = mask[n];
+    sd[6 * n + 0] = (mk & 1) ? 0.0 : 1.0 / M[0];
+    sd[6 * n + 1] = (mk & 2) ? 0.0 : 1.0 / M[1];
+    sd[6 * n + 2] = (mk & 4) ? 0.0 : 1.0 / M[2];
+    sd[6 * n + 3] = M[3]; sd[6 * n + 4] = M[4]; sd[6 * n + 5] = M[5];
+}
+void launch_gs_solve_data(const Dims &d, const double *K0, const double *E, const uint8_t *mask, double *sd, hipStream_t s) {
+    k_gs_solve_data<<<dim3((unsigned) ((d.nn + 255) / 256)), 256, 0, s>>>(d, K0, E, mask, sd);
+    VFEM_HIP(hipGetLastError());
+}
+
+long long *g_gsm_stamps = nullptr;       // diagnostic: device buffer of 7 x 8 x 8 stamps (vfem_debug_gsm_stamps), null in production
 
 // planes of local parity `par` copied from src to dst (the odd sweep left them in the scratch vector)
 __global__ void __launch_bounds__(256) k_copy_planes(Dims d, int par, const double *__restrict__ src, double *__restrict__ dst) {
@@ -344,7 +497,7 @@ void launch_copy_planes(const Dims &d, int par, const double *src, double *dst, 
 // and components 0,1,2; otherwise the reverse of both.  Reads the relaxed planes from uR and the others from uO, writes the
 // relaxed planes to dst (must differ from uR).  Returns false when the kernel cannot run on these buffers.
 bool launch_gs_march_mf0(const Dims &d, const double *coef36, const double *E, const double *E_alloc_begin, const double *E_alloc_end,
-                         const double *uR, const double *uO, double *dst, const double *b, const uint8_t *mask,
+                         const double *uR, const double *uO, double *dst, const double *b, const double *solve_data,
                          int cxl, int forward, int chunks, hipStream_t s) {
     using namespace gsm;
     if (dst == uR) return false;
@@ -361,28 +514,48 @@ bool launch_gs_march_mf0(const Dims &d, const double *coef36, const double *E, c
     a.uR = uR; a.uO = uO;
     a.uR_first = first_piece(uR); a.uR_last = last_piece(uR + 3 * d.nn);
     a.uO_first = first_piece(uO); a.uO_last = last_piece(uO + 3 * d.nn);
-    a.dst = dst; a.b = b; a.mask = mask;
+    a.dst = dst; a.b = b; a.sd = solve_data;
     a.cxl = cxl; a.forward = forward;
+    a.stamps = g_gsm_stamps;
     const int M = (d.NX - 1 - cxl) / 2 + 1;
     const int P = forward ? 0 : 1;
     const int nty = (d.NY + P + 2 * R - 1) / (2 * R), ntz = (d.NZ + P + 2 * C - 1) / (2 * C);
     if (chunks <= 0) {
-        // enough blocks for a few rounds of the 256 CUs, chunks of at least 8 steps
+        // many more blocks than CUs (one block per CU is resident: short blocks even out the tail), chunks of at least 8 steps;
+        // measured at 512^3 (387 tiles): 4 chunks 8.7 ms per sweep, 9: 7.9, 13-26: 7.7-7.8 (tools/gs_march_probe.py)
         chunks = 1;
-        while ((long long) chunks * nty * ntz < 1536 && M / (chunks + 1) >= 8) ++chunks;
+        while ((long long) chunks * nty * ntz < 5000 && M / (chunks + 1) >= 8) ++chunks;
     }
     if (chunks > M) chunks = M;
     a.steps_per_chunk = (M + chunks - 1) / chunks;
     const unsigned gx = (unsigned) ((M + a.steps_per_chunk - 1) / a.steps_per_chunk);
     const dim3 grd(gx, (unsigned) ntz, (unsigned) nty), blk(64, CW + 1, 1);
-    static bool attr[2] = {false, false};
-    if (P == 0) {
-        if (!attr[0]) { VFEM_HIP(hipFuncSetAttribute((const void *) k_gs_march_mf0<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES)); attr[0] = true; }
-        k_gs_march_mf0<0><<<grd, blk, LDS_BYTES, s>>>(a);
-    } else {
-        if (!attr[1]) { VFEM_HIP(hipFuncSetAttribute((const void *) k_gs_march_mf0<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES)); attr[1] = true; }
-        k_gs_march_mf0<1><<<grd, blk, LDS_BYTES, s>>>(a);
+    // launch-uniform window parities (see the kernel's comment)
+    const long long plane = (long long) d.NY * d.NZ;
+    const int ppar = (int) ((3 * plane) & 1), ALT = d.NZ & 1;
+    const int bparR = (int) ((reinterpret_cast<uintptr_t>(uR) >> 3) & 1), bparO = (int) ((reinterpret_cast<uintptr_t>(uO) >> 3) & 1);
+    const int QF = ((P + 1) + bparO + ((cxl + 1) & ppar) + ALT * P) & 1, QM = ((P + 1) + bparR + (cxl & ppar) + ALT * P) & 1;
+    static bool attr[8] = {false, false, false, false, false, false, false, false};
+#define VFEM_GSM_LAUNCH(A_, F_, M_)                                                                                               \
+    do {                                                                                                                          \
+        constexpr int v_ = A_ * 4 + F_ * 2 + M_;                                                                                  \
+        if (!attr[v_]) {                                                                                                          \
+            VFEM_HIP(hipFuncSetAttribute((const void *) k_gs_march_mf0<A_, F_, M_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES)); \
+            attr[v_] = true;                                                                                                      \
+        }                                                                                                                         \
+        k_gs_march_mf0<A_, F_, M_><<<grd, blk, LDS_BYTES, s>>>(a);                                                              \
+    } while (0)
+    switch (ALT * 4 + QF * 2 + QM) {
+        case 0: VFEM_GSM_LAUNCH(0, 0, 0); break;
+        case 1: VFEM_GSM_LAUNCH(0, 0, 1); break;
+        case 2: VFEM_GSM_LAUNCH(0, 1, 0); break;
+        case 3: VFEM_GSM_LAUNCH(0, 1, 1); break;
+        case 4: VFEM_GSM_LAUNCH(1, 0, 0); break;
+        case 5: VFEM_GSM_LAUNCH(1, 0, 1); break;
+        case 6: VFEM_GSM_LAUNCH(1, 1, 0); break;
+        default: VFEM_GSM_LAUNCH(1, 1, 1); break;
     }
+#undef VFEM_GSM_LAUNCH
     VFEM_HIP(hipGetLastError());
     return true;
 }

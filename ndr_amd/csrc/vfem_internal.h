@@ -117,9 +117,12 @@ void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const doubl
 // level 0: one half sweep (the four colours of local x parity cxl) marching along x with the planes in LDS; out of place:
 // relaxed planes read from uR, the others from uO, results to dst != uR.  false: cannot run on these buffers
 bool launch_gs_march_mf0(const Dims &d, const double *coef36, const double *E, const double *E_alloc_begin, const double *E_alloc_end,
-                         const double *uR, const double *uO, double *dst, const double *b, const uint8_t *mask,
+                         const double *uR, const double *uO, double *dst, const double *b, const double *solve_data,
                          int cxl, int forward, int chunks, hipStream_t s);
+// per node { 1/M00, 1/M11, 1/M22 (0 where the component is fixed), M10, M20, M21 } of the level-0 diagonal blocks M = sum_e E_e K0[n-block]
+void launch_gs_solve_data(const Dims &d, const double *K0, const double *E, const uint8_t *mask, double *sd, hipStream_t s);
 void launch_copy_planes(const Dims &d, int par, const double *src, double *dst, hipStream_t s);
+extern long long *g_gsm_stamps;         // diagnostic stamps of the marching kernel (tools/gs_march_stamps.py), null in production
 // level 1: diagonal 3x3 blocks of the virtual Galerkin operator, [nn][9] (once per operator update)
 void launch_mf1_diag(const Dims &d, const double *Dtab, const double *E, double *Mdiag, hipStream_t s);
 void build_gs_table(const double *K0, double *tab /* 72*12 doubles */);
@@ -254,6 +257,8 @@ struct MgLevel {
     vfem::DevBuf<double> Mdiag;                 // level 1: precomputed diagonal blocks [nn][9] of the virtual operator
     vfem::DevBuf<double> x, b, r;               // work vectors (m_x, m_b of MG.hh:755-756 + residual)
     vfem::DevBuf<double> tmp;                   // level 0: second copy of the field for the out-of-place marching half sweeps
+    vfem::DevBuf<double> gs_sd;                 // level 0: solve data of the marching sweeps [nn][6] (launch_gs_solve_data)
+    long long gs_sd_version = 0;                // fine->operator_version gs_sd was computed for
 };
 
 struct vfem_mg {

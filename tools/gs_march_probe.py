@@ -25,7 +25,7 @@ def setup(ne, seed=88):
 
 
 def sweeps(tps, mg, u, b, march, seq):
-    _lib.check(lib.vfem_sim_set_option(tps._h, GS_MARCH, march))
+    _lib.check(lib.vfem_sim_set_option(tps._h, GS_MARCH, 2 * march))
     uu = u.clone()
     for fwd in seq:
         _lib.check(lib.vfem_mg_smooth(mg._h, 0, _ptr(uu), _ptr(b), fwd, _stream()))
@@ -57,8 +57,8 @@ def check():
 def timing(ns):
     for n in ns:
         tps, mg, u, b = setup((n, n, n))
-        for march, chunks in [(0, 0), (1, 0), (1, 2), (1, 3), (1, 4), (1, 5), (1, 7), (1, 8), (1, 9), (1, 12), (1, 16)]:
-            _lib.check(lib.vfem_sim_set_option(tps._h, GS_MARCH, march))
+        for march, chunks in [(0, 0), (1, 0), (1, 9), (1, 11), (1, 13), (1, 16), (1, 20), (1, 26), (1, 32)]:
+            _lib.check(lib.vfem_sim_set_option(tps._h, GS_MARCH, 2 * march))
             _lib.check(lib.vfem_sim_set_option(tps._h, GS_MARCH_CHUNKS, chunks))
             uu = u.clone()
             _lib.check(lib.vfem_mg_smooth_sweeps(mg._h, 0, _ptr(uu), _ptr(b), 1, 2, _stream()))
