@@ -192,28 +192,31 @@ def mlp_rate(side=(512, 256, 256), es=1024, nn_=512, nl=4, sigma=4.0, reps=3):
     bs = [rng.standard_normal(nn_).astype(np.float32) * 0.1 for _ in range(nl - 1)] + [np.array([0.4], np.float32)]
     m = MLP(3, 1, nn_, nl, es, sigma)
     m.load_arrays(B, Ws, bs)
-    m.forward_grid(side)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        m.forward_grid(side)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
     nv = int(np.prod(side))
     flop = 2.0 * (3 * es + 2 * es * nn_ + (nl - 2) * nn_ * nn_ + nn_) * nv
-    res = {"grid": "%dx%dx%d" % tuple(side), "network": "%d->%d x%d->1" % (2 * es, nn_, nl - 1), "operands": "f16, f32 accumulate",
+
+    def timed(precision):
+        m.precision = precision
+        m.forward_grid(side)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m.forward_grid(side)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    # the forward pass at the reference's precision (networks.MLP is fp32): fused kernel, split fp16 operands, 3 MFMA products per
+    # product (kernels_mlp_x3.hip).  "tflops" counts the network's 3.15 MFLOP per voxel once; the matrix pipe executes three times
+    # that, which is what the fraction of the dense f16 peak is taken on; the fp32 MFMA peak (157 TF) is quoted for scale
+    dt = timed("fp32")
+    res = {"grid": "%dx%dx%d" % tuple(side), "network": "%d->%d x%d->1" % (2 * es, nn_, nl - 1),
+           "operands": "split f16 (hi + lo 2^-11), f32 accumulate: reference (fp32) precision",
            "seconds": dt, "voxels_per_s": nv / dt, "tflops": flop / dt / 1e12,
-           "mfma_frac_of_2.5PF": flop / dt / 2.5e15}
-    # the reference-precision mode (fp32 features, library SGEMMs): the parity path, reported beside the fused kernel
-    m.precision = "fp32"
-    m.forward_grid(side)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    m.forward_grid(side)
-    torch.cuda.synchronize()
-    d32 = time.perf_counter() - t0
-    res["fp32_mode"] = {"seconds": d32, "voxels_per_s": nv / d32, "tflops": flop / d32 / 1e12, "operands": "f32 (rocBLAS SGEMM)"}
-    m.precision = "fp16"
+           "mfma_frac_of_2.5PF": 3.0 * flop / dt / 2.5e15, "times_the_157TF_fp32_mfma_peak": flop / dt / 157.3e12}
+    # the fast option: plain fp16 operands (4e-4 on the logits, 1e-5 on the config-4 compliance)
+    d16 = timed("fp16")
+    res["fp16_option"] = {"seconds": d16, "voxels_per_s": nv / d16, "tflops": flop / d16 / 1e12, "mfma_frac_of_2.5PF": flop / d16 / 2.5e15,
+                          "operands": "f16, f32 accumulate"}
     # parameter gradients of the whole grid (recomputed forward with saved activations + data path + weight-gradient GEMMs)
     g = torch.randn(nv, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
     m.backward_grid(side, g)

@@ -1042,6 +1042,12 @@ int vfem_mlp_load_weights(vfem_mlp *m, const float *B, const float *W1, const fl
     up(m->Whf, Wh, (size_t) nh * m->nn * m->nn);
     m->W1.alloc((size_t) m->nn * 2 * m->es);
     launch_f32_to_f16((long long) m->nn * 2 * m->es, m->W1f.p, m->W1.p, nullptr);
+    m->W1h.alloc((size_t) m->nn * 2 * m->es);
+    m->W1l.alloc((size_t) m->nn * 2 * m->es);
+    launch_split_f32((long long) m->nn * 2 * m->es, m->W1f.p, m->W1h.p, m->W1l.p, nullptr);
+    m->Whh.alloc((size_t) nh * m->nn * m->nn);
+    m->Whl.alloc((size_t) nh * m->nn * m->nn);
+    if (nh) launch_split_f32((long long) nh * m->nn * m->nn, m->Whf.p, m->Whh.p, m->Whl.p, nullptr);
     m->Wh.alloc((size_t) nh * m->nn * m->nn);
     m->WhT.alloc((size_t) nh * m->nn * m->nn);
     if (nh) {
@@ -1108,49 +1114,13 @@ int vfem_mlp_forward_grid_range(vfem_mlp *m, const int64_t n[3], const double lo
     VFEM_CATCH
 }
 }  // extern "C"
-// Reference-precision forward (the reference evaluates networks.MLP in fp32 end to end): Fourier features in fp32 with accurate
-// sin / cos, the Linear layers as library SGEMMs (fp32 MFMA in rocBLAS), bias + ReLU and the output layer as small kernels.
-// Voxels are processed in chunks; nothing is fused, every activation passes through HBM -- this is the parity mode (the
-// fused fp16-operand kernel is 10-20 x faster and changes the compliance of the config-4 closure by 1e-5).
+// Reference-precision forward (the reference evaluates networks.MLP in fp32 end to end, networks.py:178-185): the fused kernel with
+// split fp16 operands (kernels_mlp_x3.hip) -- three MFMA products per product, fp32 accumulation, accurate fp32 sin / cos of the
+// argument formed as the reference forms it.  Nothing wider than the output scalar per voxel reaches HBM.
 static void mlp_forward_f32_impl(vfem_mlp *m, vfem::MlpArgs base, float *o32, double *o64, hipStream_t s) {
     if (!m->loaded) throw Error("vfem_mlp_load_weights has not been called");
-    const long long V = base.nvox;
-    const int nn = m->nn, K1 = 2 * m->es, nh = m->n_layers - 2;
-    const long long Vc = std::min<long long>(V, 1LL << 14);
-    m->f32_feat.alloc((size_t) Vc * K1);
-    m->f32_h[0].alloc((size_t) Vc * nn);
-    m->f32_h[1].alloc((size_t) Vc * nn);
-    if (!m->rocblas) {
-        rocblas_handle hnd;
-        if (rocblas_create_handle(&hnd) != rocblas_status_success) throw Error("rocblas_create_handle failed");
-        m->rocblas = hnd;
-    }
-    rocblas_handle hnd = (rocblas_handle) m->rocblas;
-    rocblas_set_stream(hnd, s);
-    rocblas_set_pointer_mode(hnd, rocblas_pointer_mode_host);
-    const float one = 1.f, zero = 0.f;
-    // row-major H[rows][n] = X[rows][k] W^T, W row-major [n][k]  <=>  column-major H^T (n x rows) = W^T(op T) ... (k x n)^T (k x rows)
-    auto linear = [&](const float *W, const float *X, float *H, long long rows, int n, int k) {
-        if (rocblas_sgemm(hnd, rocblas_operation_transpose, rocblas_operation_none, n, (rocblas_int) rows, k, &one, W, k, X, k, &zero, H, n)
-            != rocblas_status_success) throw Error("rocblas_sgemm failed");
-    };
-    for (long long c0 = 0; c0 < V; c0 += Vc) {
-        const long long rows = std::min(Vc, V - c0);
-        vfem::MlpArgs a = base;
-        a.v_offset = base.v_offset + c0;
-        if (base.coords) { a.coords = base.coords + 3 * c0; a.v_offset = 0; }
-        a.nvox = rows;
-        launch_mlp_features_f32(a, rows, m->f32_feat.p, s);
-        linear(m->W1f.p, m->f32_feat.p, m->f32_h[0].p, rows, nn, K1);
-        launch_bias_relu_f32(rows, nn, m->f32_h[0].p, m->bias.p, s);
-        int cur = 0;
-        for (int l = 0; l < nh; ++l) {
-            linear(m->Whf.p + (size_t) l * nn * nn, m->f32_h[cur].p, m->f32_h[1 - cur].p, rows, nn, nn);
-            launch_bias_relu_f32(rows, nn, m->f32_h[1 - cur].p, m->bias.p + (size_t) (l + 1) * nn, s);
-            cur = 1 - cur;
-        }
-        launch_mlp_out_f32(rows, nn, m->f32_h[cur].p, m->wout.p, m->bout, m->sigmoid, o32 ? o32 + c0 : nullptr, o64 ? o64 + c0 : nullptr, s);
-    }
+    base.out32 = o32; base.out64 = o64;
+    launch_mlp_forward_x3(base, m->W1h.p, m->W1l.p, m->Whh.p, m->Whl.p, s);
 }
 extern "C" {
 int vfem_mlp_forward_f32(vfem_mlp *m, const float *coords, int64_t nvox, float *o32, double *o64, void *stream) {

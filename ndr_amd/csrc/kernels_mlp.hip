@@ -423,59 +423,6 @@ __global__ void __launch_bounds__(256) k_mlp_features(MlpArgs a, long long rows,
     }
     *reinterpret_cast<h8_t *>(out + v * 2 * a.es + 8 * c) = o;
 }
-// ---- reference-precision (fp32) forward: small kernels around library SGEMMs ----
-// gamma(x) = [sin(arg), cos(arg)], arg = (2 pi x) . B_j evaluated in fp32 as networks.MLP.forward does (networks.py:178-180),
-// fp32 [rows][2 es]
-__global__ void __launch_bounds__(256) k_mlp_features_f32(MlpArgs a, long long rows, float *__restrict__ out) {
-    const long long q = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= rows * a.es) return;
-    const long long v = q / a.es;
-    const int j = (int) (q - v * a.es);
-    float x[3];
-    voxel_coord(a, v, x);
-    const float twopi = 6.283185307179586f;
-    const float c0 = twopi * x[0], c1 = twopi * x[1], c2 = twopi * x[2];
-    const float arg = fmaf(c2, a.B[3 * j + 2], fmaf(c1, a.B[3 * j + 1], c0 * a.B[3 * j]));
-    out[v * 2 * a.es + j] = sinf(arg);
-    out[v * 2 * a.es + a.es + j] = cosf(arg);
-}
-__global__ void __launch_bounds__(256) k_bias_relu_f32(long long rows, int nn, float *__restrict__ H, const float *__restrict__ bias) {
-    const long long q = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= rows * nn) return;
-    const float v = H[q] + bias[q % nn];
-    H[q] = v > 0.f ? v : 0.f;
-}
-// out[v] = act(w . h_v + b): one wave per voxel
-__global__ void __launch_bounds__(256) k_mlp_out_f32(long long rows, int nn, const float *__restrict__ H, const float *__restrict__ w,
-                                                     float bout, int sigmoid, float *__restrict__ o32, double *__restrict__ o64) {
-    const long long v = (long long) blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (v >= rows) return;
-    float acc = 0.f;
-    for (int k = lane; k < nn; k += 64) acc = fmaf(H[v * nn + k], w[k], acc);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if (lane == 0) {
-        float r = acc + bout;
-        if (sigmoid) r = 1.f / (1.f + expf(-r));
-        if (o32) o32[v] = r;
-        if (o64) o64[v] = (double) r;
-    }
-}
-void launch_mlp_features_f32(const MlpArgs &a, long long rows, float *out, hipStream_t s) {
-    const long long total = rows * a.es;
-    k_mlp_features_f32<<<dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, s>>>(a, rows, out);
-    VFEM_HIP(hipGetLastError());
-}
-void launch_bias_relu_f32(long long rows, int nn, float *H, const float *bias, hipStream_t s) {
-    k_bias_relu_f32<<<dim3((unsigned) ((rows * nn + 255) / 256)), dim3(256), 0, s>>>(rows, nn, H, bias);
-    VFEM_HIP(hipGetLastError());
-}
-void launch_mlp_out_f32(long long rows, int nn, const float *H, const float *w, float bout, int sigmoid, float *o32, double *o64, hipStream_t s) {
-    k_mlp_out_f32<<<dim3((unsigned) ((rows + 3) / 4)), dim3(256), 0, s>>>(rows, nn, H, w, bout, sigmoid, o32, o64);
-    VFEM_HIP(hipGetLastError());
-}
-
 void launch_mlp_features(const MlpArgs &a, long long rows, void *out, hipStream_t s) {
     const long long total = rows * (2 * a.es / 8);
     k_mlp_features<<<dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, s>>>(a, rows, (_Float16 *) out);

@@ -1,0 +1,253 @@
+// Fourier-feature MLP forward at the reference's precision (networks.MLP.forward is fp32 end to end, networks.py:178-185), fused,
+// on the f16 matrix pipe with SPLIT operands.
+//
+// Every operand x (a weight, a Fourier feature, a hidden activation) is carried as two halves
+//     hi = fp16(x),   lo = fp16((x - hi) * 2^11)        (x = hi + lo 2^-11 to 2^-22 relative: 22 significant bits)
+// and a product of two operands is three MFMA products with fp32 accumulation,
+//     w x  ~=  wh xh  +  2^-11 (wh xl + wl xh)          (the dropped wl xl term is 2^-22 relative),
+// the first into one accumulator, the two cross terms into a second one that is folded in at 2^-11 in the epilogue.  Scaling
+// only the low halves keeps them in fp16's normal range whatever the magnitude of x; no per-tensor scale is needed.  An f16
+// product is exact in fp32 (11 x 11 bits), so the result differs from an fp32 FMA chain only by the dropped term and by the
+// summation order.  v_mfma_f32_32x32x2_f32 (exact fp32, 1/16 of the f16 rate) would spend 16 x the matrix cycles, this
+// spends 3 x; the rocBLAS SGEMM chain of rounds 1-2 ran at 33 Mvoxel/s and passed every activation through HBM.
+//
+// Tiling as the fp16 kernel (kernels_mlp.hip), with half the voxels per block so that both halves of the activation image fit
+// in LDS: 512 threads own 64 voxels; activations [voxel][k] fp16 x 2 (hi, lo) with a 16-byte row pad; every layer transposed,
+// D[n][v] = sum_k W[n][k] X[v][k] with v_mfma_f32_32x32x16_f16, a wave owns 2 of the 16 row tiles x both voxel tiles
+// (4 + 4 accumulators).  Fourier features: arg = (2 pi x) . B_j in fp32 exactly as the reference forms it, accurate sinf / cosf,
+// generated per 64-wide K chunk into LDS, double-buffered against the previous chunk's MFMAs.
+#include "vfem_internal.h"
+
+#include <hip/hip_fp16.h>
+
+#include "mlp_args.h"
+
+namespace vfem {
+
+namespace x3 {
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef float f16_t __attribute__((ext_vector_type(16)));
+constexpr int TM = 64;                    // voxels per block
+constexpr int MAXN = 512;                 // hidden width limit
+constexpr int HS = MAXN + 8;              // halves per activation row (16-byte pad: conflict-free ds_read_b128)
+constexpr int KC = 64;                    // feature chunk
+constexpr int FS = KC + 8;                // halves per feature row
+constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
+
+__device__ __forceinline__ void split(float x, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16) x;
+    lo = (_Float16) ((x - (float) hi) * LO_SCALE);
+}
+__device__ __forceinline__ void voxel_xyz(const MlpArgs &a, long long v, float x[3]) {
+    if (a.coords) { x[0] = a.coords[3 * v]; x[1] = a.coords[3 * v + 1]; x[2] = a.coords[3 * v + 2]; return; }
+    v += a.v_offset;
+    const long long k = v % a.gn[2], j = (v / a.gn[2]) % a.gn[1], i = v / ((long long) a.gn[2] * a.gn[1]);
+    x[0] = a.glo[0] + a.gstep[0] * (float) i;
+    x[1] = a.glo[1] + a.gstep[1] * (float) j;
+    x[2] = a.glo[2] + a.gstep[2] * (float) k;
+}
+}  // namespace x3
+
+struct MlpX3Weights { const _Float16 *W1h, *W1l, *Whh, *Whl; };
+
+// weights: hi / lo halves of an fp32 array
+__global__ void __launch_bounds__(256) k_split_f32(long long n, const float *__restrict__ in, _Float16 *__restrict__ hi, _Float16 *__restrict__ lo) {
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) x3::split(in[i], hi[i], lo[i]);
+}
+void launch_split_f32(long long n, const float *in, void *hi, void *lo, hipStream_t s) {
+    long long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    k_split_f32<<<dim3((unsigned) (g < 1 ? 1 : g)), 256, 0, s>>>(n, in, (_Float16 *) hi, (_Float16 *) lo);
+    VFEM_HIP(hipGetLastError());
+}
+
+__global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights w) {
+    using namespace x3;
+    extern __shared__ __align__(16) unsigned char smem[];
+    _Float16 *Hh = reinterpret_cast<_Float16 *>(smem);                       // [64][HS] high halves of the activations
+    _Float16 *Hl = Hh + TM * HS;                                             // low halves
+    _Float16 *F = Hh;                                                        // layer 1: 2 buffers x (hi, lo) x [64][FS], aliases the activation images
+    float *xc = reinterpret_cast<float *>(smem + (size_t) 2 * TM * HS * 2);  // [64][3] coordinates, pre-multiplied by 2 pi
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long long v0 = (long long) blockIdx.x * TM;
+    const int ntiles = a.nn / 32;
+    const bool on[2] = {wave < ntiles, wave + 8 < ntiles};
+
+    if (tid < TM) {
+        float x[3] = {0.f, 0.f, 0.f};
+        if (v0 + tid < a.nvox) voxel_xyz(a, v0 + tid, x);
+        const float twopi = 6.283185307179586f;                              // (2. * math.pi * coords) in fp32, networks.py:179
+        xc[3 * tid] = twopi * x[0]; xc[3 * tid + 1] = twopi * x[1]; xc[3 * tid + 2] = twopi * x[2];
+    }
+    __syncthreads();
+
+    f16_t acch[2][2], accx[2][2];         // [row tile of this wave][voxel tile]: hi x hi products / cross products (scaled by 2^11)
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { acch[t][c][q] = 0.f; accx[t][c][q] = 0.f; }
+    };
+    zero_acc();
+
+    // one k-step (16 of K) of this wave's tiles: A = weight fragments (registers), B = activation fragments (LDS images xh / xl)
+    auto kstep = [&](const h8_t (&ah)[2], const h8_t (&al)[2], const _Float16 *xh, const _Float16 *xl, int stride, int klocal) {
+        h8_t bh[2], bl[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            bh[c] = *reinterpret_cast<const h8_t *>(xh + (c * 32 + r) * stride + klocal + 8 * h);
+            bl[c] = *reinterpret_cast<const h8_t *>(xl + (c * 32 + r) * stride + klocal + 8 * h);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (!on[t]) continue;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                acch[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[c], acch[t][c], 0, 0, 0);
+                accx[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[c], accx[t][c], 0, 0, 0);
+                accx[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[c], accx[t][c], 0, 0, 0);
+            }
+        }
+    };
+    // weight fragments of k-step ks of a layer (row-major [N][K] halves): 8 consecutive k of one output row = one 16-byte load
+    auto load_a = [&](const _Float16 *Wh_, const _Float16 *Wl_, int ldw, int ks, h8_t (&ah)[2], h8_t (&al)[2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const long long row = (long long) ((on[t] ? wave + 8 * t : 0) * 32 + r) * ldw + ks * 16 + 8 * h;
+            ah[t] = *reinterpret_cast<const h8_t *>(Wh_ + row);
+            al[t] = *reinterpret_cast<const h8_t *>(Wl_ + row);
+        }
+    };
+
+    // ---- layer 1: K = 2 es, features generated chunk by chunk ------------------------------------------------------------
+    const int K1 = 2 * a.es, nchunks = K1 / KC;
+    // 64 voxels x 64 features per chunk: thread -> voxel tid & 63, features 8 (tid >> 6) .. + 7 (all sines or all cosines: es % 32 == 0)
+    auto make_features = [&](int chunk, int buf) {
+        _Float16 *Fh = F + (2 * buf) * (TM * FS), *Fl = Fh + TM * FS;
+        const int v = tid & 63, fq = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const float c0 = xc[3 * v], c1 = xc[3 * v + 1], c2 = xc[3 * v + 2];
+        const int f0 = chunk * KC + fq * 8;
+        const bool is_cos = f0 >= a.es;
+        const float *Bp = a.B + 3 * (is_cos ? f0 - a.es : f0);
+        h8_t oh, ol;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float arg = fmaf(c2, Bp[3 * j + 2], fmaf(c1, Bp[3 * j + 1], c0 * Bp[3 * j]));
+            const float f = is_cos ? cosf(arg) : sinf(arg);
+            _Float16 fh, fl;
+            split(f, fh, fl);
+            oh[j] = fh; ol[j] = fl;
+        }
+        *reinterpret_cast<h8_t *>(Fh + v * FS + fq * 8) = oh;
+        *reinterpret_cast<h8_t *>(Fl + v * FS + fq * 8) = ol;
+    };
+    make_features(0, 0);
+    __syncthreads();
+    {
+        h8_t ah[2][2], al[2][2];           // [parity of the k-step][row tile]: fragments of the next k-step load while this one multiplies
+        load_a(w.W1h, w.W1l, K1, 0, ah[0], al[0]);
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int cur = ch & 1;
+            const _Float16 *Fh = F + (2 * cur) * (TM * FS), *Fl = Fh + TM * FS;
+            // waves 0-3 generate the next chunk before their MFMAs, waves 4-7 after: the two waves of a SIMD use the vector and
+            // the matrix pipe at different times
+            if (wave < 4 && ch + 1 < nchunks) make_features(ch + 1, 1 - cur);
+#pragma unroll
+            for (int q = 0; q < KC / 16; ++q) {
+                const int ks = ch * (KC / 16) + q;
+                if (ks + 1 < K1 / 16) load_a(w.W1h, w.W1l, K1, ks + 1, ah[(q + 1) & 1], al[(q + 1) & 1]);
+                kstep(ah[q & 1], al[q & 1], Fh, Fl, FS, q * 16);
+            }
+            if (wave >= 4 && ch + 1 < nchunks) make_features(ch + 1, 1 - cur);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue of a layer: bias + ReLU, split into the two activation images --------------------------------------------
+    auto store_layer = [&](const float *bias) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (!on[t]) continue;
+            const int tile = wave + 8 * t;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = tile * 32 + 8 * g + 4 * h;     // rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+                    h4_t oh, ol;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float vv = fmaf(accx[t][c][4 * g + q], LO_INV, acch[t][c][4 * g + q]) + bias[n + q];
+                        const float y = vv > 0.f ? vv : 0.f;
+                        _Float16 yh, yl;
+                        split(y, yh, yl);
+                        oh[q] = yh; ol[q] = yl;
+                    }
+                    *reinterpret_cast<h4_t *>(Hh + (c * 32 + r) * HS + n) = oh;
+                    *reinterpret_cast<h4_t *>(Hl + (c * 32 + r) * HS + n) = ol;
+                }
+        }
+        zero_acc();
+    };
+    store_layer(a.bias);          // all waves passed the last barrier of the chunk loop: the feature buffers are dead
+    __syncthreads();
+
+    // ---- hidden layers ------------------------------------------------------------------------------------------------------
+    for (int l = 0; l < a.n_hidden; ++l) {
+        const _Float16 *Wlh = w.Whh + (long long) l * a.nn * a.nn, *Wll = w.Whl + (long long) l * a.nn * a.nn;
+        h8_t ah[2][2], al[2][2];
+        load_a(Wlh, Wll, a.nn, 0, ah[0], al[0]);
+        const int nks = a.nn / 16;
+        for (int ks = 0; ks < nks; ks += 2) {
+            if (ks + 1 < nks) load_a(Wlh, Wll, a.nn, ks + 1, ah[1], al[1]);
+            kstep(ah[0], al[0], Hh, Hl, HS, ks * 16);
+            if (ks + 1 < nks) {
+                if (ks + 2 < nks) load_a(Wlh, Wll, a.nn, ks + 2, ah[0], al[0]);
+                kstep(ah[1], al[1], Hh, Hl, HS, (ks + 1) * 16);
+            }
+        }
+        __syncthreads();          // every wave finished reading the images
+        store_layer(a.bias + (l + 1) * a.nn);
+        __syncthreads();
+    }
+
+    // ---- output layer: one scalar per voxel, 8 threads per voxel -----------------------------------------------------------
+    {
+        const int v = tid >> 3, part = tid & 7;
+        const int kper = a.nn / 8;
+        float s = 0.f;
+        for (int k = part * kper; k < (part + 1) * kper; ++k)
+            s = fmaf(fmaf((float) Hl[v * HS + k], LO_INV, (float) Hh[v * HS + k]), a.wout[k], s);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (part == 0 && v0 + v < a.nvox) {
+            float o = s + a.bout;
+            if (a.sigmoid) o = 1.f / (1.f + expf(-o));
+            if (a.out32) a.out32[v0 + v] = o;
+            if (a.out64) a.out64[v0 + v] = (double) o;
+        }
+    }
+}
+
+void launch_mlp_forward_x3(const MlpArgs &a, const void *W1h, const void *W1l, const void *Whh, const void *Whl, hipStream_t s) {
+    using namespace x3;
+    if (a.nn % 32 || a.nn > MAXN || a.es % 32) throw Error("fused MLP kernel: hidden width must be a multiple of 32 up to 512, embedding size a multiple of 32");
+    const size_t lds = (size_t) 2 * TM * HS * 2 + TM * 3 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_forward_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        attr_set = true;
+    }
+    MlpX3Weights w{(const _Float16 *) W1h, (const _Float16 *) W1l, (const _Float16 *) Whh, (const _Float16 *) Whl};
+    const long long blocks = (a.nvox + TM - 1) / TM;
+    k_mlp_forward_x3<<<dim3((unsigned) blocks), dim3(512), lds, s>>>(a, w);
+    VFEM_HIP(hipGetLastError());
+}
+
+}  // namespace vfem

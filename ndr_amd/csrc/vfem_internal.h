@@ -202,9 +202,9 @@ void launch_f32_to_f16(long long n, const float *in, void *out, hipStream_t s);
 struct MlpBwdArgs;
 void launch_mlp_backward(const MlpBwdArgs &a, long long rows, hipStream_t s);
 void launch_mlp_features(const MlpArgs &a, long long rows, void *out, hipStream_t s);
-void launch_mlp_features_f32(const MlpArgs &a, long long rows, float *out, hipStream_t s);
-void launch_bias_relu_f32(long long rows, int nn, float *H, const float *bias, hipStream_t s);
-void launch_mlp_out_f32(long long rows, int nn, const float *H, const float *w, float bout, int sigmoid, float *o32, double *o64, hipStream_t s);
+// reference-precision fused forward (kernels_mlp_x3.hip): split fp16 operands (hi + lo 2^-11), three MFMA products per product
+void launch_mlp_forward_x3(const MlpArgs &a, const void *W1h, const void *W1l, const void *Whh, const void *Whl, hipStream_t s);
+void launch_split_f32(long long n, const float *in, void *hi, void *lo, hipStream_t s);
 void launch_colsum_f16(long long rows, int ncols, const void *X, const float *w, float *partial, hipStream_t s);
 void launch_reduce_partials(int nb, long long n, const float *partial, float alpha, float beta, float *out, hipStream_t s);
 void launch_sum_f32(long long n, const float *x, float alpha, float beta, float *out, float *scratch, hipStream_t s);
@@ -284,8 +284,9 @@ struct vfem_mg {
 struct vfem_mlp {
     int es = 0, nn = 0, n_layers = 0, sigmoid = 0;
     vfem::DevBuf<float> B, bias, wout;
-    vfem::DevBuf<float> W1f, Whf, f32_feat, f32_h[2];   // fp32 copies of the weights + workspace of the reference-precision forward
+    vfem::DevBuf<float> W1f, Whf;               // fp32 copies of the weights
     vfem::DevBuf<uint16_t> W1, Wh;               // fp16 bit patterns
+    vfem::DevBuf<uint16_t> W1h, W1l, Whh, Whl;   // split operands of the reference-precision forward (hi = fp16(w), lo = fp16((w - hi) 2^11))
     float bout = 0.f;
     bool loaded = false;
     // training workspace (vfem_mlp_backward*): transposed hidden weights, per-chunk activations / gradients / features

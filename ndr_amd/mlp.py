@@ -29,9 +29,11 @@ class MLP:
         _lib.require_gpu()
         self._lib = _lib.load()
         self.embedding_size, self.n_neurons, self.n_layers, self.scale = embedding_size, n_neurons, n_layers, scale
-        # "fp16": the fused kernel (fp16 MFMA operands, fp32 accumulation).  "fp32": the reference's arithmetic (fp32 features,
-        # library SGEMMs) -- the parity mode, several times slower; the backward pass is the fp16-operand one in both modes
-        self.precision = "fp16"
+        # "fp32" (default): the reference's precision -- the fused kernel with split fp16 operands (hi + lo 2^-11, three MFMA
+        # products per product, fp32 accumulation; kernels_mlp_x3.hip), outputs within fp32 rounding of networks.MLP.forward.
+        # "fp16": plain fp16 operands, three times the throughput, ~4e-4 on the logits.  The backward pass uses fp16 operands in
+        # both modes.
+        self.precision = "fp32"
         h = ctypes.c_void_p()
         _lib.check(self._lib.vfem_mlp_create(ctypes.byref(h), int(embedding_size), int(n_neurons), int(n_layers),
                                              int(name == "Sigmoid")))

@@ -53,6 +53,7 @@ def test_hip_mlp_full_size_specialisation_matches_reference():
     for sig, key in ((False, "out"), (True, "out_sig")):
         m = MLP(3, 1, nn_, nl, es, sigma, output_act=torch.nn.Sigmoid() if sig else None)
         m.load_arrays(B, Ws, bs)
+        m.precision = "fp16"                     # the plain fp16-operand kernel (the default is the reference-precision one, below)
         got = m.forward(torch.from_numpy(z["coords"]).cuda()).cpu().numpy().reshape(z[key].shape)
         grid = m.forward_grid(side).cpu().numpy().reshape(z[key].shape)
         report[key] = (float(np.abs(got - z[key]).max()), float(np.abs(grid - z[key]).max()))
@@ -110,6 +111,7 @@ def test_hip_mlp_matches_reference(path):
     z, es, nn_, nl, sig, Ws, bs = _load(path)
     m = MLP(3, 1, nn_, nl, es, float(z["sigma"][0]), output_act=torch.nn.Sigmoid() if sig else None)
     m.load_arrays(z["B"], Ws, bs)
+    m.precision = "fp16"
     got = m.forward(torch.from_numpy(z["coords"]).cuda()).cpu().numpy().reshape(z["out"].shape)
     err = np.abs(got - z["out"]).max()
     assert err < TOL_F16, err
@@ -121,13 +123,14 @@ def test_hip_mlp_matches_reference(path):
     assert np.abs(rho64.cpu().numpy().reshape(z["out"].shape) - grid).max() < 1e-7
 
 
-TOL_F32 = 5e-5      # fp32 end to end as the reference: only summation order and sin / cos rounding differ
+TOL_F32 = 5e-5      # reference precision: summation order, sin / cos rounding and the dropped lo x lo products (2^-22) differ
 
 
 @pytest.mark.gpu
 def test_hip_mlp_fp32_mode_matches_reference_to_fp32_rounding():
-    """precision = "fp32" (fp32 features, library SGEMMs, the reference's arithmetic): every fixture, the full-size network,
-    explicit coordinates, the whole grid, a voxel range crossing the 16384-voxel work chunk, and the float64 copy"""
+    """precision = "fp32" (the default: fused kernel with split fp16 operands, fp32 features formed as the reference forms them):
+    every fixture, the full-size network, explicit coordinates, the whole grid, a voxel range that starts and ends inside
+    64-voxel blocks, and the float64 copy"""
     import torch
     from ndr_amd.mlp import MLP
     from helpers import record_deltas
@@ -152,7 +155,7 @@ def test_hip_mlp_fp32_mode_matches_reference_to_fp32_rounding():
         worst = max(worst, float(np.abs(got - z[key]).max()))
     record_deltas("mlp_fp32_mode", {"max_abs_error_vs_reference": worst})
     assert worst < TOL_F32, worst
-    # chunking: a range that starts inside one 16384-voxel chunk and ends in the next equals the slice of the whole grid
+    # a voxel range equals the slice of the whole grid
     side = (40, 32, 24)
     whole = m.forward_grid(side).reshape(-1)
     part = m.forward_grid_range(side, 9000, 17000)
