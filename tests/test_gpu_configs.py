@@ -65,3 +65,98 @@ def test_config3_cantilever_256_cubed_solution_properties():
     assert abs(a - b) < 1e-12 * float(v.norm() * Kw.norm()), (a, b)
     record_deltas("config3_256x256x256", {"relative_residual_gather_kernel": relres, "iterations": mg.last_iterations,
                                           "compliance_f_dot_u": fu, "u_dot_Ku": uKu, "symmetry_defect": abs(a - b) / max(abs(a), 1e-300)})
+
+
+def test_config4_bridge_512x256x256_with_mlp_density_solution_properties():
+    """BASELINE config 4 at its own grid: bridge supports and face load (bcs/3d/bridge.bc) on [0,4]x[0,2]x[0,1], 512x256x256
+    voxels, densities = the run.md network (1024 Fourier features, 512 neurons, 4 layers, sigma 4) evaluated on that grid by
+    the fused kernel, through the constrained sigmoid (train_xdg.py:282-304).  Too large for the oracle, so: the MLP field on a
+    strided sample of voxels against an fp32 torch evaluation of networks.MLP.forward; the PCG solution through the residual
+    recomputed with the independent gather kernel, f.u = u.Ku, and symmetry of K on this grid."""
+    import math
+    from helpers import BC_BRIDGE, MATERIAL, record_deltas, seeded_mlp_weights
+    from ndr_amd import fem
+    from ndr_amd.mlp import TrainableMLP
+    grid, dom, v0 = (512, 256, 256), [[0, 0, 0], [4, 2, 1]], 0.4
+    net = TrainableMLP(3, 1, 512, 4, 1024, 4.0)
+    B, Ws, bs = seeded_mlp_weights(1024, 512, 4, 4.0, 7)
+    with torch.no_grad():
+        net.B.copy_(torch.from_numpy(B))
+        for m, w, b in zip(net._linears(), Ws, bs):
+            m.weight.copy_(torch.from_numpy(w))
+            m.bias.copy_(torch.from_numpy(b))
+        net._linears()[-1].weight.mul_(4.0)
+    net.set_grid(grid)
+    with torch.no_grad():
+        logits = net.forward_grid()
+        # strided sample (every 4099th voxel, a prime: all planes, rows and columns get hit) in torch fp32
+        idx = torch.arange(0, logits.numel(), 4099, device="cuda")
+        k = idx % grid[2]; j = (idx // grid[2]) % grid[1]; i = idx // (grid[1] * grid[2])
+        axes = [torch.linspace(0.0, 1.0, steps=n, device="cuda") for n in grid]          # utils.get_mgrid
+        x = torch.stack([axes[0][i], axes[1][j], axes[2][k]], dim=-1)
+        arg = (2.0 * math.pi * x) @ net.B.T
+        ref = net.net(torch.cat([torch.sin(arg), torch.cos(arg)], dim=-1)).reshape(-1)
+        d_logit = float((logits[idx] - ref).abs().max())
+        density = fem.satisfy_volume_constraint(logits.view(grid), torch.tensor(v0, device="cuda"), mode="constrained_sigmoid")
+    assert d_logit < 5e-5, d_logit
+    assert abs(float(density.mean()) - v0) < 1e-5 and float(logits.std()) > 0.3
+    del net, logits
+    t = fem.initializeTensorProductSimulator([1, 1, 1], dom, list(grid), v0, 1, 1e-4, 3, MATERIAL, BC_BRIDGE)
+    t.setElementDensities(density.flatten().double())
+    mg = t.multigridSolver(5)
+    f = t.buildLoadVector_device()
+    u = mg.preconditionedConjugateGradient_device(torch.zeros_like(f), f, 100, 1e-4, None, 1, 2, True)
+    mask = torch.as_tensor(t.dirichletMask, device="cuda")
+    r = f - t.applyK_device(u, 1)                       # plain gather kernel: shares no code with the solver's apply
+    r[mask] = 0.0
+    relres = float(r.norm() / f.norm())
+    assert relres <= 1e-4 and abs(relres - mg.last_relative_residual) < 1e-6 * relres + 1e-12, (relres, mg.last_relative_residual)
+    Ku = t.applyK_device(u, 0)
+    fu, uKu = float((f * u).sum()), float((u * Ku).sum())
+    assert abs(fu - uKu) < 2e-4 * abs(fu), (fu, uKu)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    v = torch.randn(u.shape, dtype=torch.float64, device="cuda", generator=g)
+    w = torch.randn(u.shape, dtype=torch.float64, device="cuda", generator=g)
+    a, b = float((v * t.applyK_device(w, 0)).sum()), float((w * t.applyK_device(v, 0)).sum())
+    assert abs(a - b) < 1e-12 * float(v.norm() * w.norm()) * float(Ku.norm() / u.norm()), (a, b)
+    record_deltas("config4_512x256x256", {"mlp_max_abs_logit_error_on_sample": d_logit, "sample_size": int(idx.numel()),
+                                          "relative_residual_gather_kernel": relres, "iterations": mg.last_iterations,
+                                          "compliance_f_dot_u": fu, "u_dot_Ku": uKu, "symmetry_defect": abs(a - b) / max(abs(a), 1e-300)})
+
+
+def test_config5_degree2_cantilever_256_cubed_solution_properties():
+    """BASELINE config 5's element (27-node hexahedra) on the largest grid one GPU holds comfortably, 256^3 elements = 135 M
+    nodes (the 512^3 grid of the config is sized for the eight GPUs of a node): the MG-PCG solution through the
+    residual recomputed with the dense-matrix gather apply (VFEM_OPT_Q2_IMPL = 1: shares no code with the marching kernel the
+    solver uses), f.u = u.Ku and symmetry"""
+    from helpers import BC_CANTILEVER, MATERIAL, record_deltas
+    from ndr_amd import _lib, pyVoxelFEM as pv
+    ne, dom = (256, 256, 256), ([0.0, 0.0, 0.0], [2.0, 1.0, 1.0])
+    t = pv.TensorProductSimulator([2, 2, 2], dom, list(ne))
+    t.readMaterial(MATERIAL)
+    t.applyDisplacementsAndLoadsFromFile(BC_CANTILEVER)
+    t.E_min = 1e-4
+    g = torch.Generator(device="cuda").manual_seed(88)
+    t.setElementDensities(torch.rand(t.numElements(), dtype=torch.float64, device="cuda", generator=g))
+    mg = t.multigridSolver(6)
+    f = t.buildLoadVector_device()
+    u = mg.preconditionedConjugateGradient_device(torch.zeros_like(f), f, 100, 1e-4, None, 1, 2, True)
+    mask = torch.as_tensor(t.dirichletMask, device="cuda")
+    lib = _lib.load()
+    _lib.check(lib.vfem_gsim_set_option(t._h, 6, 1))                      # dense gather apply
+    r = f - t.applyK_device(u)
+    _lib.check(lib.vfem_gsim_set_option(t._h, 6, 0))
+    r[mask] = 0.0
+    relres = float(r.norm() / f.norm())
+    assert relres <= 1e-4 and abs(relres - mg.last_relative_residual) < 1e-6 * relres + 1e-12, (relres, mg.last_relative_residual)
+    Ku = t.applyK_device(u)
+    fu, uKu = float((f * u).sum()), float((u * Ku).sum())
+    assert abs(fu - uKu) < 2e-4 * abs(fu), (fu, uKu)
+    del r
+    v = torch.randn(u.shape, dtype=torch.float64, device="cuda", generator=g)
+    w = torch.randn(u.shape, dtype=torch.float64, device="cuda", generator=g)
+    a, b = float((v * t.applyK_device(w)).sum()), float((w * t.applyK_device(v)).sum())
+    assert abs(a - b) < 1e-12 * float(v.norm() * w.norm()) * float(Ku.norm() / u.norm()), (a, b)
+    record_deltas("config5_degree2_256x256x256", {"relative_residual_dense_gather_apply": relres, "iterations": mg.last_iterations,
+                                                  "compliance_f_dot_u": fu, "u_dot_Ku": uKu, "nodes": int(t.numNodes()),
+                                                  "symmetry_defect": abs(a - b) / max(abs(a), 1e-300)})
