@@ -577,10 +577,14 @@ int vfem_sim_compliance_gradient(const vfem_sim *sim, const double *u, double *g
 }
 int vfem_compliance(const vfem_sim *sim, const double *f, const double *u, double *value_host, void *stream) {
     VFEM_TRY
-    double *tmp = sim->red.p;              // persistent scratch (allocated with the simulator): no hipMalloc/hipFree per evaluation
+    // stream-ordered scratch: two evaluations of one simulator on different streams must not share partial sums (the simulator's
+    // persistent `red` buffer did, and the handle is const here)
+    double *tmp = nullptr;
+    VFEM_HIP(hipMallocAsync((void **) &tmp, (2048 + 8) * sizeof(double), S(stream)));
     launch_dot(3 * sim->d.nn, f, u, tmp + 8, tmp, S(stream));
     double v = 0.0;
     VFEM_HIP(hipMemcpyAsync(&v, tmp, sizeof(double), hipMemcpyDeviceToHost, S(stream)));
+    VFEM_HIP(hipFreeAsync(tmp, S(stream)));
     VFEM_HIP(hipStreamSynchronize(S(stream)));
     *value_host = 0.5 * v;
     VFEM_CATCH

@@ -1223,11 +1223,13 @@ int vfem_gsim_compliance_gradient(const vfem_gsim *sim, const double *u, double 
 
 int vfem_gsim_compliance(const vfem_gsim *sim, const double *f, const double *u, double *value_host, void *stream) {
     G_TRY
-    DevBuf<double> &tmp = const_cast<vfem_gsim *>(sim)->red;      // persistent reduction scratch (an allocation per call synchronises the device)
-    tmp.reserve(4096 + 1);
-    launch_dot((long long) sim->d.N * sim->d.nnodes, f, u, tmp.p, tmp.p + 4096, GS(stream));
+    // stream-ordered scratch (hipMallocAsync does not synchronise the device): evaluations on different streams share nothing
+    double *tmp = nullptr;
+    VFEM_HIP(hipMallocAsync((void **) &tmp, (4096 + 1) * sizeof(double), GS(stream)));
+    launch_dot((long long) sim->d.N * sim->d.nnodes, f, u, tmp, tmp + 4096, GS(stream));
     double v = 0.0;
-    VFEM_HIP(hipMemcpyAsync(&v, tmp.p + 4096, sizeof(double), hipMemcpyDeviceToHost, GS(stream)));
+    VFEM_HIP(hipMemcpyAsync(&v, tmp + 4096, sizeof(double), hipMemcpyDeviceToHost, GS(stream)));
+    VFEM_HIP(hipFreeAsync(tmp, GS(stream)));
     VFEM_HIP(hipStreamSynchronize(GS(stream)));
     *value_host = 0.5 * v;                                            // TopologyOptimizationObjective.hh:39-41
     G_CATCH

@@ -224,8 +224,8 @@ def seeded_slab_field(part, seed=7):
 def bench_pcg(ne, levels, tol=1e-4):
     """distributed CG-MG iterations/s with the reference settings (1 FMG cycle / iteration, 2+2 symmetric sweeps)"""
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    bc = os.path.join(here, "tests", "golden", "bcs", "3d", "cantilever_flexion.bc")
-    mat = os.path.join(here, "tests", "golden", "materials", "B9Creator.material")
+    bc = os.path.join(here, "bcs", "3d", "cantilever_flexion.bc")
+    mat = os.path.join(here, "VoxelFEM", "examples", "materials", "B9Creator.material")
     ds = DistributedMGSolver(ne, [0.0, 0.0, 0.0], [2.0, 1.0, 1.0], bc, mat, levels)
     g = torch.Generator(device="cuda").manual_seed(88)
     rho = torch.rand(ne[0] * ne[1] * ne[2], dtype=torch.float64, device="cuda", generator=g)   # same on every rank

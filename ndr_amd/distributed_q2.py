@@ -289,8 +289,8 @@ def bench_pcg_q2(ne, levels, tol=1e-4):
     import os
     import time
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    bc = os.path.join(here, "tests", "golden", "bcs", "3d", "cantilever_flexion.bc")
-    mat = os.path.join(here, "tests", "golden", "materials", "B9Creator.material")
+    bc = os.path.join(here, "bcs", "3d", "cantilever_flexion.bc")
+    mat = os.path.join(here, "VoxelFEM", "examples", "materials", "B9Creator.material")
     ds = DistributedMGSolverQ2(ne, [0.0, 0.0, 0.0], [2.0, 1.0, 1.0], bc, mat, levels)
     layer = ne[1] * ne[2]
     g = torch.Generator(device="cuda").manual_seed(88 + ds.rank)

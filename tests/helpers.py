@@ -5,9 +5,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-MATERIAL = os.path.join(GOLDEN, "materials", "B9Creator.material")
-BC_CANTILEVER = os.path.join(GOLDEN, "bcs", "3d", "cantilever_flexion.bc")
-BC_BRIDGE = os.path.join(GOLDEN, "bcs", "3d", "bridge.bc")
+MATERIAL = os.path.join(ROOT, "VoxelFEM", "examples", "materials", "B9Creator.material")      # the reference's input data, at the reference's paths
+BC_CANTILEVER = os.path.join(ROOT, "bcs", "3d", "cantilever_flexion.bc")
+BC_BRIDGE = os.path.join(ROOT, "bcs", "3d", "bridge.bc")
 
 
 def seeded_density(ne, seed=88, kind="uniform"):
@@ -95,3 +95,12 @@ def seeded_mlp_weights(es, nn_, nl, sigma, seed):
 
 def mlp_weight_checksum(B, Ws, bs):
     return float(np.sum([np.abs(w.astype(np.float64)).sum() for w in Ws + bs + [B]]))
+
+
+def free_port():
+    """a TCP port nobody listens on right now (rendezvous of the multi-process tests): asking the kernel beats arithmetic on
+    the pid, which collides with a lingering socket of an earlier run now and then"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]

@@ -89,7 +89,7 @@ def test_filters_and_constraint_match_oracle():
 
 def test_region_parser_matches_reference_semantics(tmp_path):
     from ndr_amd.pyVoxelFEM import _parse_regions
-    golden = os.path.join(ROOT, "tests", "golden", "bcs", "3d", "bridge.bc")
+    golden = os.path.join(ROOT, "bcs", "3d", "bridge.bc")
     regs = _parse_regions(golden)
     assert [r[0] for r in regs] == ["dirichlet", "dirichlet", "force"]
     assert regs[0][1] == "xyz" and regs[1][1] == "x"

@@ -99,7 +99,7 @@ def _worker(rank, world, port, ne, q):
 def test_slab_apply_matches_global(world, ne):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + world
+    port = __import__('helpers').free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, ne, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -160,7 +160,7 @@ def test_four_plane_halo_of_the_degree2_slabs(world):
     HaloExchanger: ghost planes receive the neighbours' owned planes, reductions count every plane once"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29300 + (os.getpid() % 500) + world
+    port = __import__('helpers').free_port()
     procs = [ctx.Process(target=_halo4_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()

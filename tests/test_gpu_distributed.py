@@ -52,7 +52,7 @@ def test_two_ranks_two_gpus_rccl_apply():
     ne, world = (24, 10, 70), 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29900 + (os.getpid() % 1000)
+    port = __import__('helpers').free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, ne, q, "nccl")) for r in range(world)]
     for p in procs:
         p.start()
@@ -69,7 +69,7 @@ def test_two_ranks_one_gpu_apply():
     ne, world = (24, 10, 70), 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 1000)
+    port = __import__('helpers').free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, ne, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -126,7 +126,7 @@ def _pcg_worker(rank, world, port, ne, levels, q, sharded=False):
 def test_distributed_pcg_matches_single_process(world, ne, levels):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29800 + (os.getpid() % 1000) + levels + 10 * world
+    port = __import__('helpers').free_port()
     procs = [ctx.Process(target=_pcg_worker, args=(r, world, port, ne, levels, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -147,7 +147,7 @@ def test_distributed_pcg_with_sharded_densities(world, ne, levels):
     single-process solve"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 1000) + levels + 10 * world
+    port = __import__('helpers').free_port()
     procs = [ctx.Process(target=_pcg_worker, args=(r, world, port, ne, levels, q, True)) for r in range(world)]
     for p in procs:
         p.start()
@@ -198,7 +198,7 @@ def test_mlp_training_step_sharded_over_ranks_equals_whole_grid():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29900 + (os.getpid() % 1000)
+    port = __import__('helpers').free_port()
     procs = [ctx.Process(target=_mlp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -258,7 +258,7 @@ def test_distributed_closure_equals_single_process_closure():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29950 + (os.getpid() % 1000)
+    port = __import__('helpers').free_port()
     procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()

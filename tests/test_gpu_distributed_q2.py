@@ -71,7 +71,7 @@ def _worker(rank, world, port, ne, levels, q, sharded, bc="cantilever", l1_mode=
 def _run(world, ne, levels, sharded, port_base, bc="cantilever", l1_mode=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = port_base + (os.getpid() % 1000) + levels + 10 * world
+    port = __import__('helpers').free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, ne, levels, q, sharded, bc, l1_mode)) for r in range(world)]
     for p in procs:
         p.start()

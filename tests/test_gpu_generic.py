@@ -7,12 +7,12 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN, MATERIAL
+from helpers import GOLDEN, MATERIAL, ROOT
 
 pytestmark = pytest.mark.gpu
-BC2D = os.path.join(GOLDEN, "bcs", "2d", "mbb_beam.bc")
-BC2D_BRIDGE = os.path.join(GOLDEN, "bcs", "2d", "bridge.bc")
-BC3D = os.path.join(GOLDEN, "bcs", "3d", "cantilever_flexion.bc")
+BC2D = os.path.join(ROOT, "bcs", "2d", "mbb_beam.bc")
+BC2D_BRIDGE = os.path.join(ROOT, "bcs", "2d", "bridge.bc")
+BC3D = os.path.join(ROOT, "bcs", "3d", "cantilever_flexion.bc")
 with open(os.path.join(GOLDEN, "reference_logs.json")) as fh:
     LOGS = json.load(fh)
 
@@ -149,7 +149,7 @@ def test_q1_q2_compliance_converge_on_the_same_problem():
         t.readMaterial(MATERIAL)
         t.setUniformDensities(1.0)
         # a face load instead of the point load of the BC file (a point load has unbounded energy under refinement)
-        t.applyDisplacementsAndLoadsFromFile(os.path.join(GOLDEN, "bcs", "3d", "bridge.bc"))
+        t.applyDisplacementsAndLoadsFromFile(os.path.join(ROOT, "bcs", "3d", "bridge.bc"))
         f = t.buildLoadVector_device()
         mg = t.multigridSolver(2)
         u = mg.preconditionedConjugateGradient_device(torch.zeros_like(f), f, 300, 1e-9, None, 1, 2, True)

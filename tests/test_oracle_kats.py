@@ -63,7 +63,7 @@ def _mbb(ne, dom, bc, v0):
 
 def test_2d_mbb_log_kat():
     k = LOGS["2d_mbb_300x100"]
-    sim, top = _mbb([300, 100], ([0, 0], [3, 1]), os.path.join(GOLDEN, "bcs", "2d", "mbb_beam.bc"), 0.3)
+    sim, top = _mbb([300, 100], ([0, 0], [3, 1]), os.path.join(ROOT, "bcs", "2d", "mbb_beam.bc"), 0.3)
     assert abs(2 * top.evaluate_objective() - k["compliance"][0]) < 5e-7 * k["compliance"][0]
     oc = vo.OracleOC(top)
     obj, con, lam = oc.step()
@@ -75,7 +75,7 @@ def test_2d_mbb_log_kat():
 
 def test_2d_bridge_log_kat():
     k = LOGS["2d_bridge_250x125"]
-    sim, top = _mbb([250, 125], ([0, 0], [2, 1]), os.path.join(GOLDEN, "bcs", "2d", "bridge.bc"), 0.4)
+    sim, top = _mbb([250, 125], ([0, 0], [2, 1]), os.path.join(ROOT, "bcs", "2d", "bridge.bc"), 0.4)
     assert abs(2 * top.evaluate_objective() - k["compliance"][0]) < 5e-7 * k["compliance"][0]
 
 
@@ -195,7 +195,7 @@ def test_generic_oracle_equals_element_loop_oracle_at_degree_1(N, ne, dom, bc):
     from oracle import generic_oracle as go
     from oracle import vfem_oracle as vo
     import helpers
-    bcp = os.path.join(helpers.GOLDEN, "bcs", bc)
+    bcp = os.path.join(helpers.ROOT, "bcs", bc)
     if not os.path.exists(bcp):
         pytest.skip("no such golden BC file")
     a = vo.OracleSim(dom, ne)
