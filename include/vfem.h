@@ -144,6 +144,13 @@ int vfem_mg_create_slab(vfem_mg **out, vfem_sim *fine_local, int n_levels, const
                         const uint8_t *const *masks_host);
 int vfem_mg_create_partial(vfem_mg **out, vfem_sim *fine, int num_coarsening_levels, int first_active_level);
 int vfem_mg_smooth_colors(vfem_mg *mg, int level, double *u, const double *b, int forward, int first, int count, void *stream);
+/* Colour group `group` (0: colours 0-3, 1: colours 4-7 of the sweep order = the four colours of one x parity, MG.hh:292-310) on the
+ * node planes [plane_lo, plane_hi] of the level's local grid only: a slab rank relaxes its interface planes, starts the halo
+ * exchange and relaxes the interior planes meanwhile.  vfem_mg_can_smooth_planes: 1 when the level is swept by the out-of-place
+ * marching kernel, which is what makes plane ranges possible. */
+int vfem_mg_can_smooth_planes(vfem_mg *mg, int level);
+int vfem_mg_smooth_group_planes(vfem_mg *mg, int level, double *u, const double *b, int forward, int group, int64_t plane_lo, int64_t plane_hi,
+                                void *stream);
 int vfem_mg_cycle_from_level(vfem_mg *mg, int level, double *x, const double *b, int num_smoothing_steps, int fmg, void *stream);
 int vfem_mg_num_levels(const vfem_mg *mg);                       /* = numCoarseningLevels + 1 */
 int vfem_mg_level_dims(const vfem_mg *mg, int level, int64_t nelems_host[3]);

@@ -53,6 +53,8 @@ SIGNATURES = {
     "vfem_mg_create_slab": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p, POINTER(c_void_p)]),
     "vfem_mg_create_partial": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
     "vfem_mg_smooth_colors": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "vfem_mg_can_smooth_planes": (c_int, [c_void_p, c_int]),
+    "vfem_mg_smooth_group_planes": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p]),
     "vfem_mg_cycle_from_level": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "vfem_mg_num_levels": (c_int, [c_void_p]),
     "vfem_mg_level_dims": (c_int, [c_void_p, c_int, POINTER(c_int64)]),

@@ -261,7 +261,7 @@ static void mg_smooth_n(vfem_mg *mg, int l, double *u, const double *b, int forw
 }
 
 // one colour group (half sweep `half` of the sweep order) of level 0 by the marching kernel, result back in u; false: not available
-static bool mg_smooth_half(vfem_mg *mg, int l, double *u, const double *b, int forward, int half, hipStream_t s) {
+static bool mg_smooth_half(vfem_mg *mg, int l, double *u, const double *b, int forward, int half, hipStream_t s, int plane_lo = 0, int plane_hi = -1) {
     MgLevel &L = mg->lv[l];
     const vfem_sim *sim = mg->fine;
     const Tuning &t = sim->tune;
@@ -272,8 +272,8 @@ static bool mg_smooth_half(vfem_mg *mg, int l, double *u, const double *b, int f
     L.tmp.reserve((size_t) L.d.nn * 3);
     gs_solve_data(mg, s);
     if (!launch_gs_march_mf0(L.d, sim->dGsTab.p + GS_TABLE_DOUBLES, level_E(mg, 0), sim->E.p, sim->E.p + sim->n_store(), u, u, L.tmp.p, b, L.gs_sd.p,
-                             cxl, forward, t.gs_march_chunks, s)) return false;
-    launch_copy_planes(L.d, cxl, L.tmp.p, u, s);
+                             cxl, forward, t.gs_march_chunks, s, plane_lo, plane_hi)) return false;
+    launch_copy_planes(L.d, cxl, L.tmp.p, u, s, plane_lo, plane_hi);
     return true;
 }
 
@@ -890,6 +890,27 @@ int vfem_mg_smooth_colors(vfem_mg *mg, int level, double *u, const double *b, in
     if (level >= 1) update_operators(mg, S(stream));          // no-op when the operators match the current moduli
     if (first % 4 == 0 && count == 4 && mg_smooth_half(mg, level, u, b, forward, first / 4, S(stream))) return 0;
     mg_smooth(mg, level, u, b, forward, S(stream), first, count);
+    VFEM_CATCH
+}
+/* one colour group (colours [4 group, 4 group + 4) of the sweep order) restricted to the node planes [plane_lo, plane_hi] of the
+ * level's local grid: what a slab rank needs to relax its interface planes first, start the halo exchange, and relax the
+ * interior meanwhile.  Only the marching finest-level sweep can do this (out of place, plane by plane); the return value of
+ * vfem_mg_can_smooth_planes says whether this level of this hierarchy does. */
+int vfem_mg_can_smooth_planes(vfem_mg *mg, int level) {
+    if (!mg || level != 0 || level > mg->L) return 0;
+    const vfem_sim *sim = mg->fine;
+    const MgLevel &L = mg->lv[0];
+    return (L.kind == OP_MF0 && gs_march_wanted(L, sim->tune) && sim->tune.gs_variant == 0 && sim->tune.gs_resident && sim->dGsTab.p) ? 1 : 0;
+}
+int vfem_mg_smooth_group_planes(vfem_mg *mg, int level, double *u, const double *b, int forward, int group, int64_t plane_lo, int64_t plane_hi,
+                                void *stream) {
+    VFEM_TRY
+    check_level(mg, level);
+    if (group < 0 || group > 1) throw Error("colour group must be 0 or 1");
+    if (plane_lo < 0 || plane_hi > mg->lv[(size_t) level].d.NX - 1) throw Error("plane range outside the level's node grid");
+    if (plane_lo > plane_hi) return 0;
+    if (!mg_smooth_half(mg, level, u, b, forward, group, S(stream), (int) plane_lo, (int) plane_hi))
+        throw Error("plane-range sweeps need the marching finest-level kernel (vfem_mg_can_smooth_planes)");
     VFEM_CATCH
 }
 int vfem_mg_cycle_from_level(vfem_mg *mg, int level, double *x, const double *b, int nsmooth, int fmg, void *stream) {

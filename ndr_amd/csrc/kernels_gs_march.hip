@@ -63,6 +63,7 @@ struct GsMarchArgs {
     int cxl;                       // local x parity of the relaxed planes
     int forward;                   // component order of the 3x3 solve (MG.hh:254-264)
     int steps_per_chunk;           // relaxed planes per block
+    int first_plane, num_planes;   // relaxed planes: first_plane + 2 mm, mm in [0, num_planes)  (first_plane has the parity cxl)
     long long *stamps;             // diagnostic (normally null): s_memtime stamps of one block, [wave][step < 8][16]
 };
 
@@ -110,13 +111,13 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
     const int lane = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.y);
 
-    // relaxed planes x = cxl + 2 mm, mm in [m0, m1)
-    const int M = (d.NX - 1 - A.cxl) / 2 + 1;
+    // relaxed planes x = first_plane + 2 mm, mm in [m0, m1)
+    const int M = A.num_planes;
     const int m0 = blockIdx.x * A.steps_per_chunk;
-    if (A.cxl > d.NX - 1 || m0 >= M) return;                          // block-uniform, before any barrier
+    if (m0 >= M) return;                                              // block-uniform, before any barrier
     const int m1 = m0 + A.steps_per_chunk < M ? m0 + A.steps_per_chunk : M;
     const int nsteps = m1 - m0;
-    const int x0 = A.cxl + 2 * m0;
+    const int x0 = A.first_plane + 2 * m0;
     // plane stream of this block: j = 0, 1, 2, ... <-> planes x0 - 1 + j; even j: fixed planes (uO), odd j: relaxed planes (uR).
     // a plane outside the grid is replaced by the nearest one of its parity (its values only ever meet elements outside the
     // grid, whose modulus is taken as 0)
@@ -479,17 +480,21 @@ void launch_gs_solve_data(const Dims &d, const double *K0, const double *E, cons
 long long *g_gsm_stamps = nullptr;       // diagnostic: device buffer of 7 x 8 x 8 stamps (vfem_debug_gsm_stamps), null in production
 
 // planes of local parity `par` copied from src to dst (the odd sweep left them in the scratch vector)
-__global__ void __launch_bounds__(256) k_copy_planes(Dims d, int par, const double *__restrict__ src, double *__restrict__ dst) {
+__global__ void __launch_bounds__(256) k_copy_planes(Dims d, int first, int last, const double *__restrict__ src, double *__restrict__ dst) {
     const long long per = 3LL * d.NY * d.NZ;
-    const int i = 2 * blockIdx.y + par;
-    if (i > d.NX - 1) return;
+    const int i = first + 2 * blockIdx.y;
+    if (i > last) return;
     for (long long q = (long long) blockIdx.x * 256 + threadIdx.x; q < per; q += (long long) gridDim.x * 256) dst[i * per + q] = src[i * per + q];
 }
-void launch_copy_planes(const Dims &d, int par, const double *src, double *dst, hipStream_t s) {
+void launch_copy_planes(const Dims &d, int par, const double *src, double *dst, hipStream_t s, int plane_lo, int plane_hi) {
     const long long per = 3LL * d.NY * d.NZ;
+    if (plane_hi < 0 || plane_hi > d.NX - 1) plane_hi = d.NX - 1;
+    if (plane_lo < 0) plane_lo = 0;
+    const int first = plane_lo + (((plane_lo & 1) != (par & 1)) ? 1 : 0);
+    if (first > plane_hi) return;
     unsigned gx = (unsigned) ((per + 255) / 256);
     if (gx > 64) gx = 64;
-    k_copy_planes<<<dim3(gx, (unsigned) ((d.NX + 1) / 2)), 256, 0, s>>>(d, par, src, dst);
+    k_copy_planes<<<dim3(gx, (unsigned) ((plane_hi - first) / 2 + 1)), 256, 0, s>>>(d, first, plane_hi, src, dst);
     VFEM_HIP(hipGetLastError());
 }
 
@@ -498,12 +503,15 @@ void launch_copy_planes(const Dims &d, int par, const double *src, double *dst, 
 // relaxed planes to dst (must differ from uR).  Returns false when the kernel cannot run on these buffers.
 bool launch_gs_march_mf0(const Dims &d, const double *coef36, const double *E, const double *E_alloc_begin, const double *E_alloc_end,
                          const double *uR, const double *uO, double *dst, const double *b, const double *solve_data,
-                         int cxl, int forward, int chunks, hipStream_t s) {
+                         int cxl, int forward, int chunks, hipStream_t s, int plane_lo, int plane_hi) {
     using namespace gsm;
     if (dst == uR) return false;
     if ((reinterpret_cast<uintptr_t>(uR) & 7u) || (reinterpret_cast<uintptr_t>(uO) & 7u) || (reinterpret_cast<uintptr_t>(E) & 7u)) return false;
     if (d.NX < 2 || d.NY < 2 || d.NZ < 2) return false;
-    if (cxl > d.NX - 1) return true;
+    if (plane_hi < 0 || plane_hi > d.NX - 1) plane_hi = d.NX - 1;
+    if (plane_lo < 0) plane_lo = 0;
+    const int first_plane = plane_lo + (((plane_lo & 1) != (cxl & 1)) ? 1 : 0);
+    if (first_plane > plane_hi) return true;                          // no plane of this parity in the range
     GsMarchArgs a;
     a.d = d;
     a.coef = coef36;
@@ -517,7 +525,8 @@ bool launch_gs_march_mf0(const Dims &d, const double *coef36, const double *E, c
     a.dst = dst; a.b = b; a.sd = solve_data;
     a.cxl = cxl; a.forward = forward;
     a.stamps = g_gsm_stamps;
-    const int M = (d.NX - 1 - cxl) / 2 + 1;
+    const int M = (plane_hi - first_plane) / 2 + 1;
+    a.first_plane = first_plane; a.num_planes = M;
     const int P = forward ? 0 : 1;
     const int nty = (d.NY + P + 2 * R - 1) / (2 * R), ntz = (d.NZ + P + 2 * C - 1) / (2 * C);
     if (chunks <= 0) {

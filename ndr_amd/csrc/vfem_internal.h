@@ -118,10 +118,10 @@ void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const doubl
 // relaxed planes read from uR, the others from uO, results to dst != uR.  false: cannot run on these buffers
 bool launch_gs_march_mf0(const Dims &d, const double *coef36, const double *E, const double *E_alloc_begin, const double *E_alloc_end,
                          const double *uR, const double *uO, double *dst, const double *b, const double *solve_data,
-                         int cxl, int forward, int chunks, hipStream_t s);
+                         int cxl, int forward, int chunks, hipStream_t s, int plane_lo = 0, int plane_hi = -1);
 // per node { 1/M00, 1/M11, 1/M22 (0 where the component is fixed), M10, M20, M21 } of the level-0 diagonal blocks M = sum_e E_e K0[n-block]
 void launch_gs_solve_data(const Dims &d, const double *K0, const double *E, const uint8_t *mask, double *sd, hipStream_t s);
-void launch_copy_planes(const Dims &d, int par, const double *src, double *dst, hipStream_t s);
+void launch_copy_planes(const Dims &d, int par, const double *src, double *dst, hipStream_t s, int plane_lo = 0, int plane_hi = -1);
 extern long long *g_gsm_stamps;         // diagnostic stamps of the marching kernel (tools/gs_march_stamps.py), null in production
 // level 1: diagonal 3x3 blocks of the virtual Galerkin operator, [nn][9] (once per operator update)
 void launch_mf1_diag(const Dims &d, const double *Dtab, const double *E, double *Mdiag, hipStream_t s);

@@ -76,8 +76,9 @@ class HaloExchanger:
         self.p = part
         self.group = group
 
-    def start(self, field):
-        """Begin the exchange of the two interface planes with each neighbour and return a handle for `finish`.  The transfers
+    def start(self, field, left=True, right=True):
+        """Begin the exchange of the two interface planes with each neighbour (`left` / `right`: only that side) and return a
+        handle for `finish`.  The transfers
         are posted as one batch of non-blocking sends / receives and run while the caller launches work that does not touch
         the ghost planes (DistributedStiffness.apply: the interior planes).  The same code serves both backends: under nccl
         (RCCL over xGMI) the plane views of the device tensor are sent as they are; under gloo (CPU tests, one-GPU
@@ -99,10 +100,13 @@ class HaloExchanger:
             if staged:
                 recvs.append((recv, rb))
 
-        if p.gl:   # left neighbour: send my planes first_owned+1 .., receive my ghost planes 0 ..
+        if p.gl and left:   # left neighbour: send my planes first_owned+1 .., receive my ghost planes 0 ..
             add(p.first_owned + 1, p.first_owned - w, p.rank - 1)
-        if p.gr:   # right neighbour: send my planes .. last_owned-1, receive my ghost planes last_owned+1 ..
+        if p.gr and right:  # right neighbour: send my planes .. last_owned-1, receive my ghost planes last_owned+1 ..
             add(p.last_owned - w, p.last_owned + 1, p.rank + 1)
+        if not ops:
+            return None
+        self.messages = getattr(self, "messages", 0) + len(ops) // 2
         return dist.batch_isend_irecv(ops), recvs, v
 
     def finish(self, handle):
@@ -493,6 +497,7 @@ class DistributedMGSolver:
         self.xT = torch.zeros((gT, 3), dtype=torch.float64, device=self.dev)
         self.bT = torch.zeros((gT, 3), dtype=torch.float64, device=self.dev)
         self.symmetric_gs = True
+        self.overlap_sweeps = True          # relax interface planes first and exchange them behind the interior planes (where possible)
         self.last_iterations, self.last_relative_residual = 0, 0.0
 
     # ---- small helpers -------------------------------------------------------------------
@@ -619,10 +624,51 @@ class DistributedMGSolver:
     def halo(self, l, f):
         self.halos[l].exchange(f)
 
+    PARITY_AWARE_HALO = True       # degree 1: a colour group changes the planes of ONE x parity (MG.hh:292-310)
+
     def smooth(self, l, x, b, forward):
-        for first, count in self.COLOR_GROUPS:
-            self._chk(self._mg("smooth_colors")(self.lmg, l, self._p(x), self._p(b), int(forward), first, count, self._s()))
-            self.halo(l, x)
+        """one multicoloured Gauss-Seidel sweep of a distributed level.  A colour group relaxes the planes of one global x parity,
+        so a neighbour's ghost plane is stale afterwards only if the plane it mirrors has that parity: the exchange after the
+        OTHER group would move unchanged data and is skipped (slab boundaries are even planes on all but possibly the deepest
+        distributed level: one exchange per sweep instead of two).  Where the level can be swept plane by plane (the marching
+        finest-level kernel), the planes a neighbour is waiting for are relaxed first and travel while the interior planes are
+        relaxed.  Same values as the blocking order: a group's planes do not read each other."""
+        if not self.PARITY_AWARE_HALO:
+            for first, count in self.COLOR_GROUPS:
+                self._chk(self._mg("smooth_colors")(self.lmg, l, self._p(x), self._p(b), int(forward), first, count, self._s()))
+                self.halo(l, x)
+            return
+        g, hx = self.geom[l], self.halos[l]
+        by_planes = self.overlap_sweeps and bool(self.lib.vfem_mg_can_smooth_planes(self.lmg, l))
+        for group, (first, count) in enumerate(self.COLOR_GROUPS):
+            cx = group if forward else 1 - group                     # global x parity of the planes this group relaxes
+            send_left = bool(g.gl) and ((g.xoffn + g.first_owned + 1) & 1) == cx
+            send_right = bool(g.gr) and ((g.xoffn + g.last_owned - 1) & 1) == cx
+            if not (send_left or send_right):
+                self._chk(self._mg("smooth_colors")(self.lmg, l, self._p(x), self._p(b), int(forward), first, count, self._s()))
+                continue
+            if not by_planes:
+                self._chk(self._mg("smooth_colors")(self.lmg, l, self._p(x), self._p(b), int(forward), first, count, self._s()))
+                hx.finish(hx.start(x, send_left, send_right))
+                continue
+            sweep = lambda lo, hi: self._chk(self.lib.vfem_mg_smooth_group_planes(self.lmg, l, self._p(x), self._p(b), int(forward), group,
+                                                                                 lo, hi, self._s()))
+            # the planes the neighbours wait for, then everything else between them (the ghost planes themselves are not relaxed:
+            # the exchange overwrites them)
+            lo_plane, hi_plane = g.first_owned + 1, g.last_owned - 1
+            inner_lo, inner_hi = g.first_owned, g.last_owned
+            if send_left:
+                sweep(lo_plane, lo_plane)
+                inner_lo = lo_plane + 1
+            if send_right and not (send_left and hi_plane == lo_plane):
+                sweep(hi_plane, hi_plane)
+                inner_hi = hi_plane - 1
+            elif send_right:
+                inner_hi = hi_plane - 1
+            handle = hx.start(x, send_left, send_right)             # (stream-ordered behind the two small sweeps above)
+            sweep(inner_lo, inner_hi)
+            # the relaxed parity also lives on planes outside [inner_lo, inner_hi] only as ghosts, which the exchange fills
+            hx.finish(handle)
 
     def residual(self, l, x, b, out):
         self._chk(self._mg("residual")(self.lmg, l, self._p(x), self._p(b), self._p(out), self._s()))

@@ -168,6 +168,7 @@ class DistributedMGSolverQ2(DistributedMGSolver):
     _MG_PREFIX = "vfem_gmg_"
     KE_DOUBLES = 81 * 81
     COLOR_GROUPS = ((0, 9), (9, 9), (18, 9))
+    PARITY_AWARE_HALO = False      # 27 colours in three groups, four ghost planes: every group is followed by an exchange
     MIN_SHARDED_T = 1
     ALWAYS_ASSEMBLE = True
 

@@ -104,3 +104,25 @@ def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def collect_from_ranks(q, procs, timeout=400):
+    """results of the rank processes of a multi-process test; a rank that dies (its traceback is on stderr) fails the test at
+    once instead of leaving the others waited for until the timeout"""
+    import queue
+    res, waited = [], 0
+    while len(res) < len(procs):
+        try:
+            res.append(q.get(timeout=5))
+        except queue.Empty:
+            waited += 5
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or waited > timeout:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError("rank process failed (exit codes %s) or timed out" % dead)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res

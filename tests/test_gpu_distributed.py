@@ -56,10 +56,7 @@ def test_two_ranks_two_gpus_rccl_apply():
     procs = [ctx.Process(target=_worker, args=(r, world, port, ne, q, "nccl")) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = __import__('helpers').collect_from_ranks(q, procs)
     for rank, err, nrm, ref in res:
         assert err < 1e-12, (rank, err)
         assert abs(nrm - ref) < 1e-10 * ref
@@ -73,16 +70,13 @@ def test_two_ranks_one_gpu_apply():
     procs = [ctx.Process(target=_worker, args=(r, world, port, ne, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = __import__('helpers').collect_from_ranks(q, procs)
     for rank, err, nrm, ref in res:
         assert err < 1e-12, (rank, err)
         assert abs(nrm - ref) < 1e-10 * ref
 
 
-def _pcg_worker(rank, world, port, ne, levels, q, sharded=False):
+def _pcg_worker(rank, world, port, ne, levels, q, sharded=False, march=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -94,6 +88,10 @@ def _pcg_worker(rank, world, port, ne, levels, q, sharded=False):
     dom = ([0.0, 0.0, 0.0], [2.0, 1.0, 1.0])
     rho = torch.from_numpy(seeded_density(ne, 88)).cuda()
     ds = vd.DistributedMGSolver(ne, dom[0], dom[1], BC_CANTILEVER, MATERIAL, levels)
+    if march is not None:      # (overlap, marching): finest-level sweeps by the marching kernel on the slabs, interface planes first
+        from ndr_amd import _lib
+        _lib.check(ds.lib.vfem_sim_set_option(ds.lsim._h, 19, 2))
+        ds.overlap_sweeps = bool(march)
     if sharded:       # the rank hands over its OWNED layers only; ghosts come from the neighbours, coarse operators from an all-gather
         ds.set_local_densities(rho.view(ne[0], -1)[ds.part.x0:ds.part.x1].reshape(-1).clone())
     else:
@@ -117,8 +115,40 @@ def _pcg_worker(rank, world, port, ne, levels, q, sharded=False):
     gs = t.complianceGradient_device(ug)[first:first + count]
     gerr = float((gd - gs).abs().max() / gs.abs().max())
     err = max(err, gerr)
-    q.put((rank, ds.Ld, ds.last_iterations, mg.last_iterations, comp, cg, err))
+    if march is not None:
+        q.put((rank, ds.Ld, ds.last_iterations, mg.last_iterations, comp, cg, err, [getattr(h, "messages", 0) for h in ds.halos],
+               u.view(g.n_planes, -1)[g.first_owned:g.last_owned + 1].cpu().numpy()))
+    else:
+        q.put((rank, ds.Ld, ds.last_iterations, mg.last_iterations, comp, cg, err))
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ne,levels", [(2, (32, 16, 64), 3), (3, (48, 16, 16), 3)])
+def test_distributed_sweeps_overlapped_with_the_halo_exchange(world, ne, levels):
+    """finest-level sweeps by the marching kernel on the slabs: the planes a neighbour waits for are relaxed first and travel while
+    the interior planes are relaxed (vfem_mg_smooth_group_planes) -- same iterates as the blocking order and as the single process;
+    and a colour group that did not change the planes the neighbours mirror is followed by no exchange at all"""
+    ctx = mp.get_context("spawn")
+    out = {}
+    for overlap in (1, 0):
+        q = ctx.Queue()
+        port = __import__('helpers').free_port()
+        procs = [ctx.Process(target=_pcg_worker, args=(r, world, port, ne, levels, q, False, overlap)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(__import__('helpers').collect_from_ranks(q, procs), key=lambda r: r[0])
+        out[overlap] = res
+        for rank, Ld, it_d, it_s, comp, cg, err, msgs, u in res:
+            assert Ld >= 1 and it_d == it_s, (it_d, it_s)
+            assert abs(comp - cg) < 1e-9 * abs(cg) and err < 1e-7, (comp, cg, err)
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(a[8], b[8])                            # overlapped order = blocking order, bit for bit
+        assert a[7] == b[7]                                          # and the same messages
+    # finest level, per PCG iteration: K d (1), FMG: right-hand side (1), prolongated start (1), 2 + 2 sweeps (4: ONE exchange per sweep,
+    # after the group that relaxes the odd planes -- two per sweep before), residual (1), prolongated correction (1) = 9 messages per
+    # neighbour (13 with an exchange after every colour group)
+    it_d, msgs0 = out[1][0][2], out[1][0][7][0]
+    assert msgs0 <= 9 * it_d + 4, (msgs0, it_d)
 
 
 @pytest.mark.parametrize("world,ne,levels", [(2, (32, 16, 16), 3), (2, (48, 8, 16), 2),
@@ -130,10 +160,7 @@ def test_distributed_pcg_matches_single_process(world, ne, levels):
     procs = [ctx.Process(target=_pcg_worker, args=(r, world, port, ne, levels, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=400) for _ in range(world)]
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = __import__('helpers').collect_from_ranks(q, procs)
     for rank, Ld, it_d, it_s, comp, cg, err in res:
         assert Ld >= 1
         assert it_d == it_s, (it_d, it_s)
@@ -151,10 +178,7 @@ def test_distributed_pcg_with_sharded_densities(world, ne, levels):
     procs = [ctx.Process(target=_pcg_worker, args=(r, world, port, ne, levels, q, True)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=400) for _ in range(world)]
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = __import__('helpers').collect_from_ranks(q, procs)
     for rank, Ld, it_d, it_s, comp, cg, err in res:
         assert Ld >= 1
         assert it_d == it_s, (it_d, it_s)
@@ -202,10 +226,7 @@ def test_mlp_training_step_sharded_over_ranks_equals_whole_grid():
     procs = [ctx.Process(target=_mlp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = __import__('helpers').collect_from_ranks(q, procs)
     for rank, err, same in res:
         assert same, rank
         assert err < 5e-3, (rank, err)       # fp16 operands: chunk boundaries differ between the two evaluations
@@ -262,10 +283,7 @@ def test_distributed_closure_equals_single_process_closure():
     procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=400) for _ in range(world)]
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = __import__('helpers').collect_from_ranks(q, procs)
     for rank, ld, ls, vol, gerr in res:
         assert abs(vol - 0.5) < 1e-6, vol
         assert abs(ld - ls) < 2e-5 * abs(ls), (ld, ls)          # float32 loss value of the autograd node
