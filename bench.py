@@ -54,6 +54,36 @@ def time_apply(tps, u, steps, warmup, variant=0):
     return float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e-3
 
 
+def hbm_stream_calibration(nbytes):
+    """What THIS device's HBM gives plain streaming kernels (torch elementwise ops on arrays of the apply's size): boxes of the pool
+    differ by up to 17 % on write-heavy streams (profiles/r03_apply_mixprobe.txt: 4.7 vs 5.5 TB/s on the apply's 1.5 : 1 read : write
+    mix), which moves the apply's fraction of the 8 TB/s peak with it.  Reported beside `roofline`, never used in it."""
+    n = nbytes // 8
+    a = torch.zeros(n, dtype=torch.float64, device="cuda")
+    b = torch.ones(n, dtype=torch.float64, device="cuda")
+    c = torch.empty(n, dtype=torch.float64, device="cuda")
+
+    def rate(fn, moved, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return moved * reps / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+    out = {"array_GB": nbytes / 1e9,
+           "fill_0R1W_TBs": rate(lambda: c.fill_(1.0), nbytes),
+           "copy_1R1W_TBs": rate(lambda: c.copy_(a), 2 * nbytes),
+           "add_2R1W_TBs": rate(lambda: torch.add(a, b, out=c), 3 * nbytes),
+           "note": "the apply moves 1.5 bytes read per byte written: its mix lies between copy and add"}
+    del a, b, c
+    torch.cuda.empty_cache()
+    return out
+
+
 def spmv_rate(ne, steps=50):
     """the metric's second grid (256^3): event-timed kernel rate of the same apply"""
     from helpers import make_hip
@@ -375,6 +405,7 @@ def main():
                 "frac": ab / kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "vfem::k_apply_dma", "algorithmic_bytes_per_launch": ab, "kernel_ms": kernel_s * 1e3}
     del out
+    roofline["same_device_streaming"] = hbm_stream_calibration(3 * (ne[0] + 1) * (ne[1] + 1) * (ne[2] + 1) * 8)
 
     result = {
         "metric": "matrix-free SpMV GVoxel/s (Q1 fp64, %dx%dx%d); CG-MG iterations/s reported in cg_mg" % ne,

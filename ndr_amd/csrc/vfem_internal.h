@@ -88,6 +88,8 @@ struct Tuning {
     int stencil_split = 1;  // stored-stencil levels above the wave-per-node threshold: 27 neighbour blocks shared by three waves (1) or one lane (0)
     int gs_march = 1;       // level 0: plane-resident x-marching half sweeps (kernels_gs_march.hip) where whole colour groups are swept; 0: row kernels
     int gs_march_chunks = 0;   // x-chunks of the marching sweep (0 = default)
+    int l1_stored = 0;      // level 1: 0 virtual Galerkin operator (sum_f E_f cK0[f] at every visit), 1 stored 27-point block stencil (1944 B per
+                            // node, built once per operator update) -- measured slower, kept as the comparison VERDICT r02 asked for
     int l1_diag = 0;        // level 1: diagonal blocks precomputed once per operator update instead of inside every sweep (measured
                             // 3 % SLOWER at 512^3, profiles/r02_gs_experiments.json: the sweep is not bound by its arithmetic)
 };
