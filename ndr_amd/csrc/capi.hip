@@ -191,12 +191,17 @@ static const double *level_E(const vfem_mg *mg, int l) {
 // level 1 with its operator stored as a stencil (VFEM_OPT_L1_STORED): the kernels of the deeper levels apply
 static bool level_uses_stencil(const vfem_mg *mg, int l) {
     const MgLevel &L = mg->lv[l];
-    return L.kind == OP_STENCIL || (l == 1 && L.kind == OP_MF1 && mg->fine->tune.l1_stored && L.S.p);
+    return L.kind == OP_STENCIL || (l == 1 && L.kind == OP_MF1 && mg->fine->tune.l1_stored == 1 && L.S.p);
+}
+static bool level_uses_half_stencil(const vfem_mg *mg, int l) {
+    const MgLevel &L = mg->lv[l];
+    return l == 1 && L.kind == OP_MF1 && mg->fine->tune.l1_stored == 2 && L.Sh.p;
 }
 
 static void mg_apply(vfem_mg *mg, int l, const double *u, const double *b, int res, double *out, hipStream_t s) {
     MgLevel &L = mg->lv[l];
-    if (level_uses_stencil(mg, l)) launch_apply_stencil(L.d, L.S.p, u, b, L.maskp, res, out, s);
+    if (level_uses_half_stencil(mg, l)) launch_apply_stencil_half(L.d, L.Sh.p, u, b, L.maskp, res, out, s);
+    else if (level_uses_stencil(mg, l)) launch_apply_stencil(L.d, L.S.p, u, b, L.maskp, res, out, s);
     else if (L.kind == OP_MF0 && mg->fine->fast_ok) {
         const vfem_sim *sim = mg->fine;
         const Tuning &t = sim->tune;
@@ -209,7 +214,8 @@ static void mg_apply(vfem_mg *mg, int l, const double *u, const double *b, int r
 
 static void mg_smooth(vfem_mg *mg, int l, double *u, const double *b, int forward, hipStream_t s, int first = 0, int count = 8) {
     MgLevel &L = mg->lv[l];
-    if (level_uses_stencil(mg, l)) launch_gs_sweep_stencil(L.d, L.S.p, u, b, L.maskp, forward, L.xparity, first, count, s, L.Sn.p, mg->fine->tune.stencil_split);
+    if (level_uses_half_stencil(mg, l)) launch_gs_sweep_stencil_half(L.d, L.Sh.p, u, b, L.maskp, forward, L.xparity, first, count, s);
+    else if (level_uses_stencil(mg, l)) launch_gs_sweep_stencil(L.d, L.S.p, u, b, L.maskp, forward, L.xparity, first, count, s, L.Sn.p, mg->fine->tune.stencil_split);
     else launch_gs_sweep_mf(L.d, L.kind, level_K(mg, l), l == 0 ? mg->fine->dGsTab.p : mg->mf1diag.p, level_E(mg, l), u, b, L.maskp,
                             forward, L.xparity, first, count, s, mg->fine->tune, mg->mf1_sym,
                             (l == 1 && mg->fine->tune.l1_diag) ? L.Mdiag.p : nullptr);
@@ -313,11 +319,16 @@ static void update_operators(vfem_mg *mg, hipStream_t s) {
     }
     if (mg->L >= 1 && mg->first_active <= 1 && !mg->slab) {                           // level 1 stored as a stencil (option, off by default)
         MgLevel &l1 = mg->lv[1];
-        if (sim->tune.l1_stored && l1.kind == OP_MF1 && L >= 2) {
+        if (sim->tune.l1_stored == 1 && l1.kind == OP_MF1 && L >= 2) {
             l1.S.alloc((size_t) stencil_storage_doubles(l1.d));
             launch_stencil_from_mf(l1.d, OP_MF1, level_K(mg, 1), level_E(mg, 1), l1.S.p, s);
             l1.Sn.release();
-        } else if (l1.kind == OP_MF1) l1.S.release();
+            l1.Sh.release();
+        } else if (sim->tune.l1_stored == 2 && l1.kind == OP_MF1 && L >= 2) {
+            l1.Sh.alloc((size_t) stencil_half_storage_doubles(l1.d));
+            launch_stencil_half_from_mf1(l1.d, level_K(mg, 1), level_E(mg, 1), l1.Sh.p, s);
+            l1.S.release();
+        } else if (l1.kind == OP_MF1) { l1.S.release(); l1.Sh.release(); }
     }
     for (int l = std::max(2, mg->first_active); l <= L; ++l) {
         MgLevel &lv = mg->lv[l];
@@ -507,7 +518,7 @@ int vfem_sim_set_option(vfem_sim *sim, int key, int value) {
         case VFEM_OPT_STENCIL_SPLIT: t.stencil_split = value != 0; break;
         case VFEM_OPT_GS_MARCH:      if (value < 0 || value > 2) throw Error("marching sweep mode 0..2"); t.gs_march = value; break;
         case VFEM_OPT_GS_MARCH_CHUNKS: if (value < 0) throw Error("negative chunk count"); t.gs_march_chunks = value; break;
-        case VFEM_OPT_L1_STORED:     t.l1_stored = value != 0; ++sim->operator_version; break;   // hierarchies (re)build the stencil
+        case VFEM_OPT_L1_STORED:     if (value < 0 || value > 2) throw Error("level-1 storage mode 0..2"); t.l1_stored = value; ++sim->operator_version; break;
         case VFEM_OPT_L1_DIAG:       t.l1_diag = value != 0; ++sim->operator_version; break;   // hierarchies (re)build the blocks
         default: throw Error("unknown simulator option " + std::to_string(key));
     }

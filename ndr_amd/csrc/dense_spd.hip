@@ -87,49 +87,42 @@ __global__ void __launch_bounds__(256) k_dense_pad(long long n, long long Np, co
 }
 
 // diagonal tile k: L_kk (written back, strict upper part zeroed) and D[k] = L_kk^-1, both by right-looking elimination in LDS.
-// info (0 on entry) receives 1 + the global index of the first non-positive pivot.
-__global__ void __launch_bounds__(256) k_chol_diag(long long Np, int k, double *__restrict__ L, double *__restrict__ D, int *__restrict__ info) {
+// ONE wave: lane = column; the 64 elimination steps are ordered by the wave's own program order (its LDS accesses execute in
+// order), so there is no workgroup barrier in the loop (with 256 threads and three barriers per step the tile took 97 us, and a
+// 2187-dof coarsest level has 35 of them in sequence).  info (0 on entry) receives 1 + the global index of the first
+// non-positive pivot.
+__global__ void __launch_bounds__(64) k_chol_diag(long long Np, int k, double *__restrict__ L, double *__restrict__ D, int *__restrict__ info) {
     using namespace dense;
     __shared__ double a[T][S], x[T][S];
     double *tile = L + ((long long) k * T) * Np + (long long) k * T;
-    const int c0 = threadIdx.x & 63, r0 = threadIdx.x >> 6;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int r = r0 + 4 * q;
-        a[r][c0] = tile[(long long) r * Np + c0];
-        x[r][c0] = r == c0 ? 1.0 : 0.0;
+    const int c = threadIdx.x;
+    for (int r = 0; r < T; ++r) {
+        a[r][c] = tile[(long long) r * Np + c];
+        x[r][c] = r == c ? 1.0 : 0.0;
     }
+    __builtin_amdgcn_wave_barrier();
     for (int j = 0; j < T; ++j) {
-        __syncthreads();
         const double piv = a[j][j];
-        if (!(piv > 0.0)) {                         // also catches NaN
-            if (threadIdx.x == 0 && *info == 0) *info = k * T + j + 1;
-        }
+        if (!(piv > 0.0) && c == 0 && *info == 0) *info = k * T + j + 1;      // (also catches NaN)
         const double ljj = sqrt(piv), inv = 1.0 / ljj;
-        __syncthreads();
-        // column j of L; row j of X scaled
-        if (threadIdx.x < 64) {
-            const int r = threadIdx.x;
-            if (r == j) a[j][j] = ljj;
-            else if (r > j) a[r][j] *= inv;
-        } else if (threadIdx.x < 128) {
-            const int c = threadIdx.x - 64;
-            if (c <= j) x[j][c] *= inv;
-        }
-        __syncthreads();
+        // column j of L (lane = row here: column access, conflict-free with the odd row stride); row j of X scaled
+        const double lcj = c > j ? a[c][j] * inv : (c == j ? ljj : 0.0);      // L[c][j]
+        __builtin_amdgcn_wave_barrier();
+        if (c >= j) a[c][j] = lcj;
+        double xjc = 0.0;
+        if (c <= j) { xjc = x[j][c] * inv; x[j][c] = xjc; }
+        __builtin_amdgcn_wave_barrier();
         // trailing update of A (lower part, columns j < c <= r) and elimination step on X (rows r > j, columns c <= j)
-        for (int r = j + 1 + r0; r < T; r += 4) {
-            const double lrj = a[r][j];
-            if (c0 > j && c0 <= r) a[r][c0] -= lrj * a[c0][j];
-            if (c0 <= j) x[r][c0] -= lrj * x[j][c0];
+        for (int r = j + 1; r < T; ++r) {
+            const double lrj = a[r][j];                                       // broadcast read
+            if (c > j && c <= r) a[r][c] -= lrj * lcj;
+            if (c <= j) x[r][c] -= lrj * xjc;
         }
+        __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int r = r0 + 4 * q;
-        tile[(long long) r * Np + c0] = c0 <= r ? a[r][c0] : 0.0;
-        D[((long long) k * T + r) * T + c0] = c0 <= r ? x[r][c0] : 0.0;
+    for (int r = 0; r < T; ++r) {
+        tile[(long long) r * Np + c] = c <= r ? a[r][c] : 0.0;
+        D[((long long) k * T + r) * T + c] = c <= r ? x[r][c] : 0.0;
     }
 }
 
@@ -229,7 +222,7 @@ void dense_spd_inverse(long long n, double *A, DenseWork &w, hipStream_t s) {
     VFEM_HIP(hipMemsetAsync(w.info.p, 0, sizeof(int), s));
     k_dense_pad<<<gsq, 256, 0, s>>>(n, Np, A, w.L.p);
     for (int k = 0; k < nb; ++k) {
-        k_chol_diag<<<1, 256, 0, s>>>(Np, k, w.L.p, w.D.p, w.info.p);
+        k_chol_diag<<<1, 64, 0, s>>>(Np, k, w.L.p, w.D.p, w.info.p);
         const int rest = nb - k - 1;
         if (rest > 0) {
             k_chol_panel<<<rest, 256, 0, s>>>(Np, k, w.L.p, w.D.p);

@@ -89,7 +89,7 @@ struct Tuning {
     int gs_march = 1;       // level 0: plane-resident x-marching half sweeps (kernels_gs_march.hip) where whole colour groups are swept; 0: row kernels
     int gs_march_chunks = 0;   // x-chunks of the marching sweep (0 = default)
     int l1_stored = 0;      // level 1: 0 virtual Galerkin operator (sum_f E_f cK0[f] at every visit), 1 stored 27-point block stencil (1944 B per
-                            // node, built once per operator update) -- measured slower, kept as the comparison VERDICT r02 asked for
+                            // node, built once per operator update; measured slower), 2 stored HALF stencil (symmetry: 1008 B per node)
     int l1_diag = 0;        // level 1: diagonal blocks precomputed once per operator update instead of inside every sweep (measured
                             // 3 % SLOWER at 512^3, profiles/r02_gs_experiments.json: the sweep is not bound by its arithmetic)
 };
@@ -135,6 +135,13 @@ void build_mf1_diag_table(const double *cK0_0, double *tab /* 8*12 */);
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
                              int forward, int xparity, int first, int count, hipStream_t s, const double *S_node_major = nullptr,
                              int stencil_split = 1);
+// level 1 stored as half a stencil (kernels_stencil_half.hip): diagonal block + the 13 later neighbours per node, 1008 B
+long long stencil_half_storage_doubles(const Dims &d);
+void launch_stencil_half_from_mf1(const Dims &d, const double *cK0, const double *Efine, double *Sh, hipStream_t s);
+void launch_gs_sweep_stencil_half(const Dims &d, const double *Sh, double *u, const double *b, const uint8_t *mask,
+                                  int forward, int xparity, int first, int count, hipStream_t s);
+void launch_apply_stencil_half(const Dims &d, const double *Sh, const double *u, const double *b, const uint8_t *mask, int res, double *out,
+                               hipStream_t s);
 // node-major copy of a level's stencil (levels small enough for the wave-per-node sweep, WAVE_SWEEP_MAX_NODES)
 void launch_stencil_node_major(const Dims &d, const double *St, double *Sn, hipStream_t s);
 constexpr long long WAVE_SWEEP_MAX_NODES = 40000;
@@ -255,6 +262,7 @@ struct MgLevel {
     const uint8_t *maskp = nullptr;
     std::vector<uint8_t> hmask;
     vfem::DevBuf<double> Ke, S;                 // Galerkin element matrices / stencil (levels >= 2)
+    vfem::DevBuf<double> Sh;                    // level 1: half stencil (diagonal block + 13 later neighbours per node), option l1_stored = 2
     vfem::DevBuf<double> Sn;                    // node-major copy of S on levels of at most WAVE_SWEEP_MAX_NODES nodes (wave-per-node sweep)
     vfem::DevBuf<double> Mdiag;                 // level 1: precomputed diagonal blocks [nn][9] of the virtual operator
     vfem::DevBuf<double> x, b, r;               // work vectors (m_x, m_b of MG.hh:755-756 + residual)
