@@ -198,6 +198,13 @@ static bool level_uses_half_stencil(const vfem_mg *mg, int l) {
     return l == 1 && L.kind == OP_MF1 && mg->fine->tune.l1_stored == 2 && L.Sh.p;
 }
 
+// level 1 evaluated per mirror class (VFEM_OPT_L1_MERGED): needs the mirror symmetry of the coarsened matrices
+static bool level_uses_merged_rows(const vfem_mg *mg, int l) {
+    const MgLevel &L = mg->lv[l];
+    return l == 1 && L.kind == OP_MF1 && mg->mf1_sym && mg->fine->tune.l1_merged && mg->fine->tune.gs_variant == 0 && mg->l1mtab.p &&
+           l1_merged_usable(L.d);
+}
+
 static void mg_apply(vfem_mg *mg, int l, const double *u, const double *b, int res, double *out, hipStream_t s) {
     MgLevel &L = mg->lv[l];
     if (level_uses_half_stencil(mg, l)) launch_apply_stencil_half(L.d, L.Sh.p, u, b, L.maskp, res, out, s);
@@ -209,6 +216,7 @@ static void mg_apply(vfem_mg *mg, int l, const double *u, const double *b, int r
             launch_apply_dma(L.d, sim->Dm, level_E(mg, 0), sim->E.p + sim->n_store(), u, out, s, 0, -1, t.dma_chunks, t.dma_strip)) return;
         launch_apply_fast(L.d, sim->Dm, level_E(mg, 0), u, b, L.maskp, res, out, s, t.apply_pd);
     }
+    else if (level_uses_merged_rows(mg, l)) launch_l1_merged_apply(L.d, mg->l1mtab.p, level_E(mg, l), u, b, L.maskp, res, out, s);
     else launch_apply_gather(L.d, L.kind, level_K(mg, l), level_E(mg, l), u, b, L.maskp, res, out, s);
 }
 
@@ -216,6 +224,7 @@ static void mg_smooth(vfem_mg *mg, int l, double *u, const double *b, int forwar
     MgLevel &L = mg->lv[l];
     if (level_uses_half_stencil(mg, l)) launch_gs_sweep_stencil_half(L.d, L.Sh.p, u, b, L.maskp, forward, L.xparity, first, count, s);
     else if (level_uses_stencil(mg, l)) launch_gs_sweep_stencil(L.d, L.S.p, u, b, L.maskp, forward, L.xparity, first, count, s, L.Sn.p, mg->fine->tune.stencil_split);
+    else if (level_uses_merged_rows(mg, l)) launch_l1_merged_sweep(L.d, mg->l1mtab.p, level_E(mg, l), u, b, L.maskp, forward, L.xparity, first, count, s);
     else launch_gs_sweep_mf(L.d, L.kind, level_K(mg, l), l == 0 ? mg->fine->dGsTab.p : mg->mf1diag.p, level_E(mg, l), u, b, L.maskp,
                             forward, L.xparity, first, count, s, mg->fine->tune, mg->mf1_sym,
                             (l == 1 && mg->fine->tune.l1_diag) ? L.Mdiag.p : nullptr);
@@ -519,6 +528,7 @@ int vfem_sim_set_option(vfem_sim *sim, int key, int value) {
         case VFEM_OPT_GS_MARCH:      if (value < 0 || value > 2) throw Error("marching sweep mode 0..2"); t.gs_march = value; break;
         case VFEM_OPT_GS_MARCH_CHUNKS: if (value < 0) throw Error("negative chunk count"); t.gs_march_chunks = value; break;
         case VFEM_OPT_L1_STORED:     if (value < 0 || value > 2) throw Error("level-1 storage mode 0..2"); t.l1_stored = value; ++sim->operator_version; break;
+        case VFEM_OPT_L1_MERGED:     t.l1_merged = value != 0; break;
         case VFEM_OPT_L1_DIAG:       t.l1_diag = value != 0; ++sim->operator_version; break;   // hierarchies (re)build the blocks
         default: throw Error("unknown simulator option " + std::to_string(key));
     }
@@ -692,6 +702,10 @@ static void finish_mg_create(vfem_mg *mg) {
         build_mf1_diag_table(c.data(), dt);
         mg->mf1diag.alloc(96);
         VFEM_HIP(hipMemcpy(mg->mf1diag.p, dt, sizeof(dt), hipMemcpyHostToDevice));
+        double mt[L1M_TABLE_DOUBLES];
+        build_l1_merged_table(c.data(), mt);
+        mg->l1mtab.alloc(L1M_TABLE_DOUBLES);
+        VFEM_HIP(hipMemcpy(mg->l1mtab.p, mt, sizeof(mt), hipMemcpyHostToDevice));
     }
     for (int l = mg->first_active; l <= mg->L; ++l) {
         MgLevel &lv = mg->lv[(size_t) l];

@@ -1,0 +1,260 @@
+// Level-1 colour sweep / apply / residual with the node row evaluated per mirror class (l1_merged_core.h).
+//
+// Reference semantics: m_smoothNode MultigridSolver.hh:193-265 on the level-1 operator Ke = sum_f E_f cK0[f]
+// (MultigridSolver.hh:639-657), applyK TensorProductSimulator.hh:905-952 for the residual.  Same operator as
+// k_gs_color_mf1_sym / k_apply_gather<1> (kernels_mg.hip), different association of the sums: results agree to rounding.
+//
+// One node is the work of THREE waves (lane = node): the neighbours of the x-plane below (threadIdx.y = 0), of the node's own
+// plane and the diagonal block (1), of the plane above (2).  Each wave holds its nine neighbours (54 registers) and the fine
+// moduli it needs (32 / 64 / 32 doubles) in registers, walks the eight mirror classes with compile-time register indices and
+// scalar-loaded coefficients (l1m::build_table, 6 KB: resident in the scalar cache), and the partial sums meet in LDS in a
+// fixed order.  All loads are buffer loads: a neighbour or element outside the grid is given an out-of-range offset (or a
+// zero-length plane) and reads as 0, so there is no clamping, no select on the loaded values and no divergent control flow.
+// Per node ~3 150 multiply-adds + additions in ~80 vector loads against 5 184 + 576 in 256 loads of the per-element form.
+#include "vfem_internal.h"
+#include "device_utils.h"
+#include "l1_merged_core.h"
+
+namespace vfem {
+
+namespace {
+
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+
+constexpr unsigned OOB = 0x7ffffff0u;                  // beyond any plane (launchers refuse planes of 2^31 bytes or more)
+
+// Coefficient rows (9 doubles per class and neighbour kind) come through the scalar cache one row AHEAD of their use: a wave walks
+// 32 rows, and with the request and the wait in one place (sload12) the ~200-cycle round trip of each is exposed -- more than
+// the ~45 multiply-adds between two rows.  The request for row r + 1 is issued when row r is taken; the two register sets
+// alternate.  A request in flight across asm statements is only safe while the allocator keeps its destination registers
+// (device_utils.h, sload12_issue): this kernel must compile without SGPR spills (checked by the Makefile's resource report and
+// tools/check_sload_pipeline.py).
+template <int OFF>
+__device__ __forceinline__ void srow_issue(const double *p, d8_t &a, double &b) {
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4" : "=&s"(a), "=&s"(b) : "s"(p), "n"(OFF), "n"(OFF + 64));
+}
+__device__ __forceinline__ void srow_wait(d8_t &a, double &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
+
+// MID: the rows of the middle part (w = 3, 2, 1, 0 per class), otherwise of a side part (w = 7, 6, 5, 4)
+template <bool MID>
+struct DevCoef {
+    const double *tab;
+    d8_t a0, a1;
+    double b0, b1;
+    static constexpr int row_offset(int r) { return ((r / 4) * 8 + (MID ? 3 : 7) - r % 4) * l1m::TAB_ROW * 8; }
+    __device__ __forceinline__ void prime() { srow_issue<row_offset(0)>(tab, a0, b0); }
+    template <int G, int W>
+    __device__ __forceinline__ void get(double c[9]) {
+        constexpr int r = G * 4 + (MID ? 3 : 7) - W;
+        if constexpr (r % 2 == 0) {
+            srow_wait(a0, b0);
+            if constexpr (r + 1 < 32) srow_issue<row_offset(r + 1 < 32 ? r + 1 : 0)>(tab, a1, b1);
+            c[0] = a0[0]; c[1] = a0[1]; c[2] = a0[2]; c[3] = a0[3]; c[4] = a0[4]; c[5] = a0[5]; c[6] = a0[6]; c[7] = a0[7]; c[8] = b0;
+        } else {
+            srow_wait(a1, b1);
+            if constexpr (r + 1 < 32) srow_issue<row_offset(r + 1 < 32 ? r + 1 : 0)>(tab, a0, b0);
+            c[0] = a1[0]; c[1] = a1[1]; c[2] = a1[2]; c[3] = a1[3]; c[4] = a1[4]; c[5] = a1[5]; c[6] = a1[6]; c[7] = a1[7]; c[8] = b1;
+        }
+    }
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const double *base, long long plane_doubles, int plane, int planes) {
+    const bool ok = plane >= 0 && plane < planes;
+    const double *p = base + (long long) (ok ? plane : 0) * plane_doubles;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p), 0, ok ? (int) (plane_doubles * 8) : 0, 0x00020000);
+}
+__device__ __forceinline__ double mk(unsigned lo, unsigned hi) { return __longlong_as_double(((unsigned long long) hi << 32) | lo); }
+
+// the 3 x 3 nodes (j + o_y, k + o_z) of one x-plane: un[o_y + 1][3 (o_z + 1) + c]
+__device__ __forceinline__ void load_nodes(__amdgpu_buffer_rsrc_t r, const Dims &d, int j, int k, double (&un)[3][9]) {
+#pragma unroll
+    for (int oy = -1; oy <= 1; ++oy)
+#pragma unroll
+        for (int oz = -1; oz <= 1; ++oz) {
+            const int jj = j + oy, kk = k + oz;
+            const bool ok = jj >= 0 && jj < d.NY && kk >= 0 && kk < d.NZ;
+            const unsigned off = ok ? (unsigned) (jj * d.NZ + kk) * 24u : OOB;
+#ifdef L1M_NOLOAD
+            const u4_t v = {off, 0x3ff00000u, off, 0x3ff00000u}; const u2_t w = {off, 0x3ff00000u}; (void) r;
+#else
+            const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+            const u2_t w = __builtin_amdgcn_raw_buffer_load_b64(r, off + 16, 0, 0);
+#endif
+            un[oy + 1][3 * (oz + 1) + 0] = mk(v.x, v.y);
+            un[oy + 1][3 * (oz + 1) + 1] = mk(v.z, v.w);
+            un[oy + 1][3 * (oz + 1) + 2] = mk(w.x, w.y);
+        }
+}
+// the 4 x 4 fine moduli (2j - 2 + p_y, 2k - 2 + p_z) of one fine x-plane
+__device__ __forceinline__ void load_moduli(__amdgpu_buffer_rsrc_t r, const unsigned (&off)[4][2], double (&e)[4][4]) {
+#pragma unroll
+    for (int py = 0; py < 4; ++py)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#ifdef L1M_NOLOAD
+            const u4_t v = {off[py][h], 0x3ff00000u, off[py][h] + 1, 0x3ff00000u}; (void) r;
+#else
+            const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off[py][h], 0, 0);
+#endif
+            e[py][2 * h] = mk(v.x, v.y);
+            e[py][2 * h + 1] = mk(v.z, v.w);
+        }
+}
+
+template <int SIDE, int G>
+__device__ __forceinline__ void side_classes(const double (&Es)[2][4][4], const double (&un)[3][9], DevCoef<false> &cf, double S[3]) {
+#ifdef L1M_NOCOMP
+    if constexpr (G == 0) { for (auto &p : Es) for (auto &r : p) for (double v : r) S[0] += v; for (auto &r : un) for (double v : r) S[1] += v; }
+#else
+    l1m::side_class<SIDE, G>(Es, un, cf, S);
+#endif
+    if constexpr (G + 1 < 8) side_classes<SIDE, G + 1>(Es, un, cf, S);
+}
+template <int G>
+__device__ __forceinline__ void mid_classes(const double (&Em)[4][4][4], const double (&un)[3][9], DevCoef<true> &cf, double S[3], double M[9]) {
+#ifdef L1M_NOCOMP
+    if constexpr (G == 0) { for (auto &p : Em) for (auto &r : p) for (double v : r) S[0] += v; for (auto &r : un) for (double v : r) S[1] += v; M[0] = M[4] = M[8] = 1.0; }
+#else
+    l1m::mid_class<G>(Em, un, cf, S, M);
+#endif
+    if constexpr (G + 1 < 8) mid_classes<G + 1>(Em, un, cf, S, M);
+}
+
+template <int SIDE>
+__device__ __forceinline__ void side_part(const Dims &d, const double *tab, const double *E, const double *u, int i, int j, int k,
+                                          const unsigned (&eoff)[4][2], double S[3]) {
+    const long long eplane = 4LL * d.ny * d.nz;
+    double un[3][9], Es[2][4][4];
+    load_nodes(plane_rsrc(u, 3LL * d.NY * d.NZ, i + (SIDE ? 1 : -1), d.NX), d, j, k, un);
+    // mirror class bit g_x = 0: the fine plane next to the node, 1: the one beyond; a side outside the grid has no planes
+    const bool ok = SIDE ? i < d.NX - 1 : i > 0;
+    load_moduli(plane_rsrc(E, eplane, ok ? (SIDE ? 2 * i : 2 * i - 1) : -1, 2 * d.nx), eoff, Es[0]);
+    load_moduli(plane_rsrc(E, eplane, ok ? (SIDE ? 2 * i + 1 : 2 * i - 2) : -1, 2 * d.nx), eoff, Es[1]);
+    DevCoef<false> cf{tab};
+#ifndef L1M_NOCOMP
+    cf.prime();
+#endif
+    S[0] = S[1] = S[2] = 0.0;
+    side_classes<SIDE, 0>(Es, un, cf, S);
+}
+
+// MODE 0: relax the nodes of one colour in place; 1: out = A u; 2: out = b - A u, 0 at fixed components
+template <int MODE>
+__global__ void __launch_bounds__(192) k_l1_merged(Dims d, const double *__restrict__ tab, const double *__restrict__ E,
+                                                   const double *u, const double *__restrict__ b, const uint8_t *__restrict__ mask,
+                                                   double *out, int cx, int cy, int cz, int forward) {
+    __shared__ double part[2][3][64];
+    const int lane = threadIdx.x, role = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    int i, j, k;
+    bool live;
+    if (MODE == 0) {       // lanes packed over the colour's nodes of an x-plane, row after row (rows have 2^k + 1 nodes)
+        const int cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
+        const int q = blockIdx.x * 64 + lane;
+        live = q < cnty * cntz;
+        const int qq = live ? q : cnty * cntz - 1, jq = qq / cntz;
+        k = 2 * (qq - jq * cntz) + cz; j = 2 * jq + cy; i = 2 * blockIdx.z + cx;
+    } else {
+        const int q = blockIdx.x * 64 + lane;
+        live = q < d.NY * d.NZ;
+        const int qq = live ? q : d.NY * d.NZ - 1;
+        j = qq / d.NZ; k = qq - j * d.NZ; i = blockIdx.z;
+    }
+    // byte offsets of the lane's 4 x 2 pieces (16 B: two moduli) in a fine x-plane; pieces outside the grid read as 0
+    unsigned eoff[4][2];
+    {
+        const int nzf = 2 * d.nz;
+#pragma unroll
+        for (int py = 0; py < 4; ++py)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool ok = (py < 2 ? j >= 1 : j <= d.ny - 1) && (h == 0 ? k >= 1 : k <= d.nz - 1);
+                eoff[py][h] = ok ? (unsigned) ((2 * j - 2 + py) * nzf + 2 * k - 2 + 2 * h) * 8u : OOB;
+            }
+    }
+    double S[3];
+    if (role == 0) {
+        side_part<0>(d, tab, E, u, i, j, k, eoff, S);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) part[0][c][lane] = S[c];
+    } else if (role == 2) {
+        side_part<1>(d, tab, E, u, i, j, k, eoff, S);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) part[1][c][lane] = S[c];
+    }
+    double M[9], uc[3];
+    if (role == 1) {
+        const long long eplane = 4LL * d.ny * d.nz;
+        double un[3][9], Em[4][4][4];
+        load_nodes(plane_rsrc(u, 3LL * d.NY * d.NZ, i, d.NX), d, j, k, un);
+        const bool lo = i > 0, hi = i < d.NX - 1;
+        load_moduli(plane_rsrc(E, eplane, lo ? 2 * i - 2 : -1, 2 * d.nx), eoff, Em[0]);
+        load_moduli(plane_rsrc(E, eplane, lo ? 2 * i - 1 : -1, 2 * d.nx), eoff, Em[1]);
+        load_moduli(plane_rsrc(E, eplane, hi ? 2 * i : -1, 2 * d.nx), eoff, Em[2]);
+        load_moduli(plane_rsrc(E, eplane, hi ? 2 * i + 1 : -1, 2 * d.nx), eoff, Em[3]);
+        DevCoef<true> cf{tab};
+#ifndef L1M_NOCOMP
+        cf.prime();
+#endif
+        S[0] = S[1] = S[2] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) M[q] = 0.0;
+        mid_classes<0>(Em, un, cf, S, M);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) uc[c] = un[1][3 + c];
+    }
+    __syncthreads();
+    if (role != 1 || !live) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) S[c] = (part[0][c][lane] + S[c]) + part[1][c][lane];
+    const long long n = ((long long) i * d.NY + j) * d.NZ + k;
+    if (MODE == 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[3 * n + c] = S[c] + (M[3 * c] * uc[0] + M[3 * c + 1] * uc[1] + M[3 * c + 2] * uc[2]);
+        return;
+    }
+    double bms[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bms[c] = b[3 * n + c] - (S[c] + (M[3 * c] * uc[0] + M[3 * c + 1] * uc[1] + M[3 * c + 2] * uc[2]));
+    const uint8_t m = mask ? mask[n] : 0;
+    if (MODE == 2) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[3 * n + c] = ((m >> c) & 1) ? 0.0 : bms[c];
+        return;
+    }
+    double ud[3];
+    gs_solve(bms, M, m, forward != 0, ud);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[3 * n + c] = uc[c] + ud[c];
+}
+
+}  // namespace
+
+void build_l1_merged_table(const double *cK0_0, double *tab /* L1M_TABLE_DOUBLES */) { l1m::build_table(cK0_0, tab); }
+
+// planes are addressed with 32-bit byte offsets
+bool l1_merged_usable(const Dims &d) {
+    return d.nx >= 1 && d.ny >= 1 && d.nz >= 1 && 24LL * d.NY * d.NZ < 0x7f000000LL && 32LL * d.ny * d.nz < 0x7f000000LL;
+}
+
+void launch_l1_merged_sweep(const Dims &d, const double *tab, const double *E, double *u, const double *b, const uint8_t *mask,
+                            int forward, int xparity, int first, int count, hipStream_t s) {
+    for (int ci = first; ci < first + count; ++ci) {
+        const int lni = forward ? ci : 7 - ci;
+        const int cx = ((lni >> 2) & 1) ^ (xparity & 1), cy = (lni >> 1) & 1, cz = lni & 1;
+        if (cx > d.NX - 1 || cy > d.NY - 1 || cz > d.NZ - 1) continue;
+        const int cntx = (d.NX - 1 - cx) / 2 + 1, cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
+        k_l1_merged<0><<<dim3((cnty * cntz + 63) / 64, 1, cntx), dim3(64, 3, 1), 0, s>>>(d, tab, E, u, b, mask, u, cx, cy, cz, forward);
+    }
+    VFEM_HIP(hipGetLastError());
+}
+
+void launch_l1_merged_apply(const Dims &d, const double *tab, const double *E, const double *u, const double *b, const uint8_t *mask,
+                            int res, double *out, hipStream_t s) {
+    const dim3 grd((d.NY * d.NZ + 63) / 64, 1, d.NX), blk(64, 3, 1);
+    if (res) k_l1_merged<2><<<grd, blk, 0, s>>>(d, tab, E, u, b, mask, out, 0, 0, 0, 0);
+    else     k_l1_merged<1><<<grd, blk, 0, s>>>(d, tab, E, u, b, mask, out, 0, 0, 0, 0);
+    VFEM_HIP(hipGetLastError());
+}
+
+}  // namespace vfem

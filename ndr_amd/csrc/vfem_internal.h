@@ -90,6 +90,8 @@ struct Tuning {
     int gs_march_chunks = 0;   // x-chunks of the marching sweep (0 = default)
     int l1_stored = 0;      // level 1: 0 virtual Galerkin operator (sum_f E_f cK0[f] at every visit), 1 stored 27-point block stencil (1944 B per
                             // node, built once per operator update; measured slower), 2 stored HALF stencil (symmetry: 1008 B per node)
+    int l1_merged = 1;      // level 1: node rows evaluated per mirror class by three waves per node (kernels_l1_merged.hip; 1) or per incident
+                            // element (k_gs_color_mf1_sym*, k_apply_gather<1>; 0)
     int l1_diag = 0;        // level 1: diagonal blocks precomputed once per operator update instead of inside every sweep (measured
                             // 3 % SLOWER at 512^3, profiles/r02_gs_experiments.json: the sweep is not bound by its arithmetic)
 };
@@ -132,6 +134,14 @@ constexpr int GS_TABLE_DOUBLES = 72 * 12;
 bool build_gs_coef(const double *K0, double *coef /* 36 doubles; false: K0 lacks the box-voxel / isotropic structure */);
 bool coarsened_matrices_are_mirror_images(const double *cK0_host /* 8 x 576 */);
 void build_mf1_diag_table(const double *cK0_0, double *tab /* 8*12 */);
+// level 1, node rows per mirror class (kernels_l1_merged.hip); the table holds cK0[0] regrouped by class with the signs folded in
+constexpr int L1M_TABLE_DOUBLES = 8 * 8 * 12;
+void build_l1_merged_table(const double *cK0_0, double *tab /* L1M_TABLE_DOUBLES */);
+bool l1_merged_usable(const Dims &d);
+void launch_l1_merged_sweep(const Dims &d, const double *tab, const double *E, double *u, const double *b, const uint8_t *mask,
+                            int forward, int xparity, int first, int count, hipStream_t s);
+void launch_l1_merged_apply(const Dims &d, const double *tab, const double *E, const double *u, const double *b, const uint8_t *mask,
+                            int res, double *out, hipStream_t s);
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
                              int forward, int xparity, int first, int count, hipStream_t s, const double *S_node_major = nullptr,
                              int stencil_split = 1);
@@ -277,6 +287,7 @@ struct vfem_mg {
     std::vector<MgLevel> lv;
     vfem::DevBuf<double> cK0;                   // 8 x 576 coarsened reference matrices (MG.hh:644-648)
     vfem::DevBuf<double> mf1diag;               // 8 x 12: diagonal blocks of cK0[0] (level-1 Gauss-Seidel)
+    vfem::DevBuf<double> l1mtab;                // cK0[0] by mirror class (build_l1_merged_table)
     vfem::DevBuf<double> c2K0;                  // 64 x 576: I_g^T cK0[f] I_g (level-2 element matrices from the fine moduli)
     vfem::DevBuf<double> Ainv;                  // coarsest-level dense inverse
     vfem::DevBuf<double> pr, pd, pAd, ps;       // PCG vectors
