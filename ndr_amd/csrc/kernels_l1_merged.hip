@@ -15,6 +15,7 @@
 #include "device_utils.h"
 #include "l1_merged_core.h"
 
+
 namespace vfem {
 
 namespace {
@@ -36,17 +37,20 @@ __device__ __forceinline__ void srow_issue(const double *p, d8_t &a, double &b) 
 }
 __device__ __forceinline__ void srow_wait(d8_t &a, double &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
 
-// MID: the rows of the middle part (w = 3, 2, 1, 0 per class), otherwise of a side part (w = 7, 6, 5, 4)
+// position of neighbour kind w in the row order of a part: side parts w = 7, 6, 5, 4; the middle part w = 3, 2, 0, 1
+template <bool MID> constexpr int row_pos(int w) { return MID ? (w == 3 ? 0 : w == 2 ? 1 : w == 0 ? 2 : 3) : 7 - w; }
+template <bool MID> constexpr int row_kind(int pos) { return MID ? (pos == 0 ? 3 : pos == 1 ? 2 : pos == 2 ? 0 : 1) : 7 - pos; }
+
 template <bool MID>
 struct DevCoef {
     const double *tab;
     d8_t a0, a1;
     double b0, b1;
-    static constexpr int row_offset(int r) { return ((r / 4) * 8 + (MID ? 3 : 7) - r % 4) * l1m::TAB_ROW * 8; }
+    static constexpr int row_offset(int r) { return ((r / 4) * 8 + row_kind<MID>(r % 4)) * l1m::TAB_ROW * 8; }
     __device__ __forceinline__ void prime() { srow_issue<row_offset(0)>(tab, a0, b0); }
     template <int G, int W>
     __device__ __forceinline__ void get(double c[9]) {
-        constexpr int r = G * 4 + (MID ? 3 : 7) - W;
+        constexpr int r = G * 4 + row_pos<MID>(W);
         if constexpr (r % 2 == 0) {
             srow_wait(a0, b0);
             if constexpr (r + 1 < 32) srow_issue<row_offset(r + 1 < 32 ? r + 1 : 0)>(tab, a1, b1);
@@ -107,16 +111,21 @@ __device__ __forceinline__ void side_classes(const double (&Es)[2][4][4], const 
 #ifdef L1M_NOCOMP
     if constexpr (G == 0) { for (auto &p : Es) for (auto &r : p) for (double v : r) S[0] += v; for (auto &r : un) for (double v : r) S[1] += v; }
 #else
-    l1m::side_class<SIDE, G>(Es, un, cf, S);
+    double a[2][2];
+    l1m::class_window<G>(Es[(G >> 2) & 1], a);
+    l1m::side_class<SIDE, G>(a, un, cf, S);
 #endif
     if constexpr (G + 1 < 8) side_classes<SIDE, G + 1>(Es, un, cf, S);
 }
 template <int G>
-__device__ __forceinline__ void mid_classes(const double (&Em)[4][4][4], const double (&un)[3][9], DevCoef<true> &cf, double S[3], double M[9]) {
+__device__ __forceinline__ void mid_classes(const double (&Em)[4][4][4], const double (&un)[3][9], DevCoef<true> &cf, double S[3], double M[6]) {
 #ifdef L1M_NOCOMP
-    if constexpr (G == 0) { for (auto &p : Em) for (auto &r : p) for (double v : r) S[0] += v; for (auto &r : un) for (double v : r) S[1] += v; M[0] = M[4] = M[8] = 1.0; }
+    if constexpr (G == 0) { for (auto &p : Em) for (auto &r : p) for (double v : r) S[0] += v; for (auto &r : un) for (double v : r) S[1] += v; M[0] = M[3] = M[5] = 1.0; }
 #else
-    l1m::mid_class<G>(Em, un, cf, S, M);
+    double a0[2][2], a1[2][2];
+    l1m::class_window<G>(Em[1 - ((G >> 2) & 1)], a0);
+    l1m::class_window<G>(Em[2 + ((G >> 2) & 1)], a1);
+    l1m::mid_class<G>(a0, a1, un, cf, S, M);
 #endif
     if constexpr (G + 1 < 8) mid_classes<G + 1>(Em, un, cf, S, M);
 }
@@ -139,27 +148,13 @@ __device__ __forceinline__ void side_part(const Dims &d, const double *tab, cons
     side_classes<SIDE, 0>(Es, un, cf, S);
 }
 
-// MODE 0: relax the nodes of one colour in place; 1: out = A u; 2: out = b - A u, 0 at fixed components
+// One group of 64 nodes (lane = node (i, j, k), i and j uniform over the wave or not -- only i must be): three waves (role = 0: plane
+// below, 1: own plane and the relaxation, 2: plane above).  MODE 0: relax in place; 1: out = A u; 2: out = b - A u, 0 at fixed
+// components.  Contains one workgroup barrier; `part` is the workgroup's exchange area.
 template <int MODE>
-__global__ void __launch_bounds__(192) k_l1_merged(Dims d, const double *__restrict__ tab, const double *__restrict__ E,
-                                                   const double *u, const double *__restrict__ b, const uint8_t *__restrict__ mask,
-                                                   double *out, int cx, int cy, int cz, int forward) {
-    __shared__ double part[2][3][64];
-    const int lane = threadIdx.x, role = __builtin_amdgcn_readfirstlane(threadIdx.y);
-    int i, j, k;
-    bool live;
-    if (MODE == 0) {       // lanes packed over the colour's nodes of an x-plane, row after row (rows have 2^k + 1 nodes)
-        const int cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
-        const int q = blockIdx.x * 64 + lane;
-        live = q < cnty * cntz;
-        const int qq = live ? q : cnty * cntz - 1, jq = qq / cntz;
-        k = 2 * (qq - jq * cntz) + cz; j = 2 * jq + cy; i = 2 * blockIdx.z + cx;
-    } else {
-        const int q = blockIdx.x * 64 + lane;
-        live = q < d.NY * d.NZ;
-        const int qq = live ? q : d.NY * d.NZ - 1;
-        j = qq / d.NZ; k = qq - j * d.NZ; i = blockIdx.z;
-    }
+__device__ __forceinline__ void node_group(const Dims &d, const double *__restrict__ tab, const double *__restrict__ E, const double *u,
+                                           const double *__restrict__ b, const uint8_t *__restrict__ mask, double *out, int i, int j, int k,
+                                           bool live, int role, int lane, int forward, double (&part)[2][3][64]) {
     // byte offsets of the lane's 4 x 2 pieces (16 B: two moduli) in a fine x-plane; pieces outside the grid read as 0
     unsigned eoff[4][2];
     {
@@ -182,7 +177,7 @@ __global__ void __launch_bounds__(192) k_l1_merged(Dims d, const double *__restr
 #pragma unroll
         for (int c = 0; c < 3; ++c) part[1][c][lane] = S[c];
     }
-    double M[9], uc[3];
+    double M6[6], uc[3];
     if (role == 1) {
         const long long eplane = 4LL * d.ny * d.nz;
         double un[3][9], Em[4][4][4];
@@ -198,8 +193,8 @@ __global__ void __launch_bounds__(192) k_l1_merged(Dims d, const double *__restr
 #endif
         S[0] = S[1] = S[2] = 0.0;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) M[q] = 0.0;
-        mid_classes<0>(Em, un, cf, S, M);
+        for (int q = 0; q < 6; ++q) M6[q] = 0.0;
+        mid_classes<0>(Em, un, cf, S, M6);
 #pragma unroll
         for (int c = 0; c < 3; ++c) uc[c] = un[1][3 + c];
     }
@@ -208,6 +203,7 @@ __global__ void __launch_bounds__(192) k_l1_merged(Dims d, const double *__restr
 #pragma unroll
     for (int c = 0; c < 3; ++c) S[c] = (part[0][c][lane] + S[c]) + part[1][c][lane];
     const long long n = ((long long) i * d.NY + j) * d.NZ + k;
+    const double M[9] = {M6[0], M6[1], M6[2], M6[1], M6[3], M6[4], M6[2], M6[4], M6[5]};
     if (MODE == 1) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) out[3 * n + c] = S[c] + (M[3 * c] * uc[0] + M[3 * c + 1] * uc[1] + M[3 * c + 2] * uc[2]);
@@ -226,6 +222,29 @@ __global__ void __launch_bounds__(192) k_l1_merged(Dims d, const double *__restr
     gs_solve(bms, M, m, forward != 0, ud);
 #pragma unroll
     for (int c = 0; c < 3; ++c) out[3 * n + c] = uc[c] + ud[c];
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(192) k_l1_merged(Dims d, const double *__restrict__ tab, const double *__restrict__ E,
+                                                   const double *u, const double *__restrict__ b, const uint8_t *__restrict__ mask,
+                                                   double *out, int cx, int cy, int cz, int forward) {
+    __shared__ double part[2][3][64];
+    const int lane = threadIdx.x, role = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    int i, j, k;
+    bool live;
+    if (MODE == 0) {       // lanes packed over the colour's nodes of an x-plane, row after row (rows have 2^k + 1 nodes)
+        const int cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
+        const int q = blockIdx.x * 64 + lane;
+        live = q < cnty * cntz;
+        const int qq = live ? q : cnty * cntz - 1, jq = qq / cntz;
+        k = 2 * (qq - jq * cntz) + cz; j = 2 * jq + cy; i = 2 * blockIdx.z + cx;
+    } else {
+        const int q = blockIdx.x * 64 + lane;
+        live = q < d.NY * d.NZ;
+        const int qq = live ? q : d.NY * d.NZ - 1;
+        j = qq / d.NZ; k = qq - j * d.NZ; i = blockIdx.z;
+    }
+    node_group<MODE>(d, tab, E, u, b, mask, out, i, j, k, live, role, lane, forward, part);
 }
 
 }  // namespace

@@ -44,6 +44,16 @@ inline void build_table(const double *cK0_0, double *tab) {
         }
 }
 
+// index (fine offset + 2) of the class-g element on side d of the node along one axis
+__host__ __device__ constexpr int class_index(int d, int g) { return d ? 2 + g : 1 - g; }
+// the 2 x 2 moduli of class G in one fine x-plane given as plane[p_y][p_z]
+template <int G>
+__host__ __device__ __forceinline__ void class_window(const double (&plane)[4][4], double (&a)[2][2]) {
+    constexpr int gy = (G >> 1) & 1, gz = G & 1;
+    a[0][0] = plane[class_index(0, gy)][class_index(0, gz)]; a[0][1] = plane[class_index(0, gy)][class_index(1, gz)];
+    a[1][0] = plane[class_index(1, gy)][class_index(0, gz)]; a[1][1] = plane[class_index(1, gy)][class_index(1, gz)];
+}
+
 // T[a][b] (+)= W_ab n[b]  with  W_aa = wd, W_xy = wxy, W_xz = wxz, W_yz = wyz  (callers pass compile-time signs as negations)
 template <bool FIRST>
 __host__ __device__ __forceinline__ void add_neighbour(double T[9], const double *n, double wd, double wxy, double wxz, double wyz) {
@@ -69,14 +79,12 @@ __host__ __device__ __forceinline__ void fold(double S[3], const double T[9], co
 }
 
 // ---- SIDE part of mirror class G: neighbours (o_x = SIDE ? +1 : -1, o_y, o_z) -----------------------------------------------
-// Es[g_x][p_y][p_z]: moduli of the two fine x-planes of that side (g_x = 0: the plane next to the node), p = fine offset + 2
+// a[d_y][d_z]: the four moduli of the class on that side, fine offsets (d ? g : -1 - g) in y and z, in the fine x-plane at offset
+//              (SIDE ? g_x : -1 - g_x)  -- see class_window()
 // un[o_y + 1][3 (o_z + 1) + b]: the nine neighbours of that x-plane
 template <int SIDE, int G, class Coef>
-__host__ __device__ __forceinline__ void side_class(const double (&Es)[2][4][4], const double (&un)[3][9], Coef &coef, double S[3]) {
-    constexpr int gx = (G >> 2) & 1, gy = (G >> 1) & 1, gz = G & 1;
-    constexpr int py[2] = {1 - gy, 2 + gy}, pz[2] = {1 - gz, 2 + gz};
+__host__ __device__ __forceinline__ void side_class(const double (&a)[2][2], const double (&un)[3][9], Coef &coef, double S[3]) {
     constexpr double sx = SIDE ? 1.0 : -1.0;
-    const double a[2][2] = {{Es[gx][py[0]][pz[0]], Es[gx][py[0]][pz[1]]}, {Es[gx][py[1]][pz[0]], Es[gx][py[1]][pz[1]]}};
     double T[9], c[9];
     // w = 111: corners
     coef.template get<G, 7>(c);
@@ -103,25 +111,14 @@ __host__ __device__ __forceinline__ void side_class(const double (&Es)[2][4][4],
     fold(S, T, c);
 }
 
-// ---- MID part of mirror class G: neighbours (0, o_y, o_z) and the diagonal block ------------------------------------------------
-// Em[p_x][p_y][p_z]: all 64 moduli; un as above for the node's own x-plane (un[1][3..5] = the node itself, not used here)
+// ---- MID part of mirror class G: neighbours (0, o_y, o_z) and the diagonal block; coefficient rows in the order w = 3, 2, 0, 1 ------
+// a0 / a1 [d_y][d_z]: the class's moduli in the fine x-planes below (offset -1 - g_x) and above (offset g_x) the node; un as above
+// for the node's own x-plane (un[1][3..5] = the node itself, not used here)
 template <int G, class Coef>
-__host__ __device__ __forceinline__ void mid_class(const double (&Em)[4][4][4], const double (&un)[3][9], Coef &coef, double S[3], double M[9]) {
-    constexpr int gx = (G >> 2) & 1, gy = (G >> 1) & 1, gz = G & 1;
-    constexpr int px[2] = {1 - gx, 2 + gx}, py[2] = {1 - gy, 2 + gy}, pz[2] = {1 - gz, 2 + gz};
-    double Sx[2][2], Dx[2][2];
-#ifdef __HIP_DEVICE_COMPILE__
-#pragma unroll
-#endif
-    for (int dy = 0; dy < 2; ++dy)
-#ifdef __HIP_DEVICE_COMPILE__
-#pragma unroll
-#endif
-        for (int dz = 0; dz < 2; ++dz) {
-            const double a0 = Em[px[0]][py[dy]][pz[dz]], a1 = Em[px[1]][py[dy]][pz[dz]];
-            Sx[dy][dz] = a1 + a0;
-            Dx[dy][dz] = a1 - a0;
-        }
+__host__ __device__ __forceinline__ void mid_class(const double (&a0)[2][2], const double (&a1)[2][2], const double (&un)[3][9], Coef &coef,
+                                                   double S[3], double M6[6]) {
+    const double Sx[2][2] = {{a1[0][0] + a0[0][0], a1[0][1] + a0[0][1]}, {a1[1][0] + a0[1][0], a1[1][1] + a0[1][1]}};
+    const double Dx[2][2] = {{a1[0][0] - a0[0][0], a1[0][1] - a0[0][1]}, {a1[1][0] - a0[1][0], a1[1][1] - a0[1][1]}};
     double T[9], c[9];
     // w = 011
     coef.template get<G, 3>(c);
@@ -137,6 +134,12 @@ __host__ __device__ __forceinline__ void mid_class(const double (&Em)[4][4][4], 
     add_neighbour<true>(T, &un[0][3], P[0], -Q[0], R[0], -U[0]);
     add_neighbour<false>(T, &un[2][3], P[1], Q[1], R[1], U[1]);
     fold(S, T, c);
+    // w = 000: the diagonal block, merged over all eight elements (symmetric: M6 = {xx, xy, xz, yy, yz, zz}); before w = 001 so that
+    // P, Q, R, U end here
+    coef.template get<G, 0>(c);
+    const double wd = P[0] + P[1], wxy = Q[1] - Q[0], wxz = R[0] + R[1], wyz = U[1] - U[0];
+    M6[0] = __builtin_fma(c[0], wd, M6[0]);  M6[1] = __builtin_fma(c[1], wxy, M6[1]); M6[2] = __builtin_fma(c[2], wxz, M6[2]);
+    M6[3] = __builtin_fma(c[4], wd, M6[3]);  M6[4] = __builtin_fma(c[5], wyz, M6[4]); M6[5] = __builtin_fma(c[8], wd, M6[5]);
     // w = 001: merged over x and y
     const double P2[2] = {Sx[0][0] + Sx[1][0], Sx[0][1] + Sx[1][1]}, Q2[2] = {Dx[1][0] - Dx[0][0], Dx[1][1] - Dx[0][1]};
     const double R2[2] = {Dx[0][0] + Dx[1][0], Dx[0][1] + Dx[1][1]}, U2[2] = {Sx[1][0] - Sx[0][0], Sx[1][1] - Sx[0][1]};
@@ -144,12 +147,6 @@ __host__ __device__ __forceinline__ void mid_class(const double (&Em)[4][4][4], 
     add_neighbour<true>(T, &un[1][0], P2[0], Q2[0], -R2[0], -U2[0]);
     add_neighbour<false>(T, &un[1][6], P2[1], Q2[1], R2[1], U2[1]);
     fold(S, T, c);
-    // w = 000: the diagonal block, merged over all eight elements
-    coef.template get<G, 0>(c);
-    const double wd = P[0] + P[1], wxy = Q[1] - Q[0], wxz = R[0] + R[1], wyz = U[1] - U[0];
-    M[0] += c[0] * wd;  M[1] += c[1] * wxy; M[2] += c[2] * wxz;
-    M[3] += c[3] * wxy; M[4] += c[4] * wd;  M[5] += c[5] * wyz;
-    M[6] += c[6] * wxz; M[7] += c[7] * wyz; M[8] += c[8] * wd;
 }
 
 }  // namespace l1m

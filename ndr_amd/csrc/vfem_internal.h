@@ -90,8 +90,8 @@ struct Tuning {
     int gs_march_chunks = 0;   // x-chunks of the marching sweep (0 = default)
     int l1_stored = 0;      // level 1: 0 virtual Galerkin operator (sum_f E_f cK0[f] at every visit), 1 stored 27-point block stencil (1944 B per
                             // node, built once per operator update; measured slower), 2 stored HALF stencil (symmetry: 1008 B per node)
-    int l1_merged = 1;      // level 1: node rows evaluated per mirror class by three waves per node (kernels_l1_merged.hip; 1) or per incident
-                            // element (k_gs_color_mf1_sym*, k_apply_gather<1>; 0)
+    int l1_merged = 1;      // level 1: node rows evaluated per incident element (k_gs_color_mf1_sym*, k_apply_gather<1>; 0) or per mirror class
+                            // by three waves per node (kernels_l1_merged.hip; 1)
     int l1_diag = 0;        // level 1: diagonal blocks precomputed once per operator update instead of inside every sweep (measured
                             // 3 % SLOWER at 512^3, profiles/r02_gs_experiments.json: the sweep is not bound by its arithmetic)
 };

@@ -14,14 +14,20 @@ struct HostCoef {
 };
 
 template <int G>
-static void all_classes(const double (&E)[4][4][4], const double (&u)[3][3][9], HostCoef &cf, double S[3], double M[9]) {
+static void all_classes(const double (&E)[4][4][4], const double (&u)[3][3][9], HostCoef &cf, double S[3], double M[6]) {
     double Es0[2][4][4], Es1[2][4][4];
     for (int gx = 0; gx < 2; ++gx)
         for (int y = 0; y < 4; ++y)
             for (int z = 0; z < 4; ++z) { Es0[gx][y][z] = E[1 - gx][y][z]; Es1[gx][y][z] = E[2 + gx][y][z]; }
-    side_class<0, G>(Es0, u[0], cf, S);
-    mid_class<G>(E, u[1], cf, S, M);
-    side_class<1, G>(Es1, u[2], cf, S);
+    constexpr int gx = (G >> 2) & 1;
+    double a[2][2], a0[2][2], a1[2][2];
+    class_window<G>(Es0[gx], a);
+    side_class<0, G>(a, u[0], cf, S);
+    class_window<G>(E[1 - gx], a0);
+    class_window<G>(E[2 + gx], a1);
+    mid_class<G>(a0, a1, u[1], cf, S, M);
+    class_window<G>(Es1[gx], a);
+    side_class<1, G>(a, u[2], cf, S);
     if constexpr (G + 1 < 8) all_classes<G + 1>(E, u, cf, S, M);
 }
 
@@ -39,8 +45,9 @@ int main() {
         double tab[TAB_DOUBLES];
         build_table(&K[0][0], tab);
         HostCoef cf{tab};
-        double S[3] = {0, 0, 0}, M[9] = {0};
-        all_classes<0>(E, u, cf, S, M);
+        double S[3] = {0, 0, 0}, M6[6] = {0};
+        all_classes<0>(E, u, cf, S, M6);
+        const double M[9] = {M6[0], M6[1], M6[2], M6[1], M6[3], M6[4], M6[2], M6[4], M6[5]};
         // direct
         double S0[3] = {0, 0, 0}, M0[9] = {0};
         auto bit = [](int v, int a) { return (v >> (2 - a)) & 1; };

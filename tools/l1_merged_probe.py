@@ -30,7 +30,7 @@ def both(tps, mg, u, b, what):
 if "check" in args:
     args.remove("check")
     worst = 0.0
-    for ne in ((8, 8, 8), (16, 8, 24), (24, 40, 8), (136, 24, 264), (40, 72, 200)):
+    for ne in ((8, 8, 8), (16, 8, 24), (24, 40, 8), (136, 24, 264), (40, 72, 200), (8, 24, 512), (24, 8, 504), (16, 16, 760)):
         tps = make_hip(ne, ([0, 0, 0], [2, 1, 1]), BC_CANTILEVER, None, v0=0.5)
         g = torch.Generator(device="cuda").manual_seed(5)
         tps.setElementDensities(torch.rand(tps.numElements(), dtype=torch.float64, device="cuda", generator=g) ** 3)
