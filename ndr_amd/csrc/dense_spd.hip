@@ -86,43 +86,65 @@ __global__ void __launch_bounds__(256) k_dense_pad(long long n, long long Np, co
     W[gid] = (r < n && c < n) ? A[r * n + c] : (r == c ? 1.0 : 0.0);
 }
 
-// diagonal tile k: L_kk (written back, strict upper part zeroed) and D[k] = L_kk^-1, both by right-looking elimination in LDS.
-// ONE wave: lane = column; the 64 elimination steps are ordered by the wave's own program order (its LDS accesses execute in
-// order), so there is no workgroup barrier in the loop (with 256 threads and three barriers per step the tile took 97 us, and a
-// 2187-dof coarsest level has 35 of them in sequence).  info (0 on entry) receives 1 + the global index of the first
-// non-positive pivot.
-__global__ void __launch_bounds__(64) k_chol_diag(long long Np, int k, double *__restrict__ L, double *__restrict__ D, int *__restrict__ info) {
+// diagonal tile k: L_kk (written back, strict upper part zeroed) and D[k] = L_kk^-1, both by right-looking elimination.
+// The tile and the inverse under construction live in REGISTERS (thread (r0, c) of 4 x 64 owns the rows r0 + 4 q, q < 16, of column
+// c: 32 doubles); a step publishes only column j of A and row j of X through LDS (double-buffered: one workgroup barrier per step)
+// and every thread scales them itself (the same products a[r][j] * inv, x[j][c] * inv as an in-place scaling, so the result does not
+// depend on the thread layout).  With both matrices in LDS and three barriers per step the tile took 97 us (a chain of dependent
+// LDS round trips per row of the trailing update), as one wave without workgroup barriers 259 us; a 2187-dof coarsest level has 35
+// such tiles in sequence.  info (0 on entry) receives 1 + the global index of the first non-positive pivot.
+__global__ void __launch_bounds__(256) k_chol_diag(long long Np, int k, double *__restrict__ L, double *__restrict__ D, int *__restrict__ info) {
     using namespace dense;
-    __shared__ double a[T][S], x[T][S];
+    __shared__ double col[2][T], row[2][T];
     double *tile = L + ((long long) k * T) * Np + (long long) k * T;
-    const int c = threadIdx.x;
-    for (int r = 0; r < T; ++r) {
-        a[r][c] = tile[(long long) r * Np + c];
-        x[r][c] = r == c ? 1.0 : 0.0;
+    const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+    double a[16], x[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = r0 + 4 * q;
+        a[q] = tile[(long long) r * Np + c];
+        x[q] = r == c ? 1.0 : 0.0;
     }
-    __builtin_amdgcn_wave_barrier();
     for (int j = 0; j < T; ++j) {
-        const double piv = a[j][j];
-        if (!(piv > 0.0) && c == 0 && *info == 0) *info = k * T + j + 1;      // (also catches NaN)
-        const double ljj = sqrt(piv), inv = 1.0 / ljj;
-        // column j of L (lane = row here: column access, conflict-free with the odd row stride); row j of X scaled
-        const double lcj = c > j ? a[c][j] * inv : (c == j ? ljj : 0.0);      // L[c][j]
-        __builtin_amdgcn_wave_barrier();
-        if (c >= j) a[c][j] = lcj;
-        double xjc = 0.0;
-        if (c <= j) { xjc = x[j][c] * inv; x[j][c] = xjc; }
-        __builtin_amdgcn_wave_barrier();
-        // trailing update of A (lower part, columns j < c <= r) and elimination step on X (rows r > j, columns c <= j)
-        for (int r = j + 1; r < T; ++r) {
-            const double lrj = a[r][j];                                       // broadcast read
-            if (c > j && c <= r) a[r][c] -= lrj * lcj;
-            if (c <= j) x[r][c] -= lrj * xjc;
+        const int buf = j & 1;
+        // publish column j of A (pivot included) and row j of X as they stand
+        if (c == j) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) col[buf][r0 + 4 * q] = a[q];
         }
-        __builtin_amdgcn_wave_barrier();
+        if (r0 == (j & 3)) {
+            double xv = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) xv = (j >> 2) == q ? x[q] : xv;
+            row[buf][c] = xv;
+        }
+        __syncthreads();
+        const double piv = col[buf][j];
+        if (!(piv > 0.0) && threadIdx.x == 0 && *info == 0) *info = k * T + j + 1;      // (also catches NaN)
+        // 1 / sqrt(piv) from the hardware estimate and two Newton steps (a short dependent chain: the correctly rounded sqrt and
+        // division cost ~60 dependent instructions per step, and the 64 steps of a tile are one chain); deterministic, within an
+        // ulp or two of the rounded values
+        double inv = __builtin_amdgcn_rsq(piv);
+        inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+        inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+        const double ljj = piv * inv;
+        const double lcj = col[buf][c] * inv;          // L[c][j] (used where c > j)
+        const double xjc = row[buf][c] * inv;          // X[j][c] (used where c <= j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {                 // (selects, no branches: the conditions differ from lane to lane)
+            const int r = r0 + 4 * q;
+            const double lrj = col[buf][r] * inv;      // L[r][j]
+            const double an = (c > j && c <= r) ? fma(-lrj, lcj, a[q]) : (c == j ? lrj : a[q]);
+            const double xn = c <= j ? fma(-lrj, xjc, x[q]) : x[q];
+            a[q] = r > j ? an : ((r == j && c == j) ? ljj : a[q]);
+            x[q] = r > j ? xn : ((r == j && c <= j) ? xjc : x[q]);
+        }
     }
-    for (int r = 0; r < T; ++r) {
-        tile[(long long) r * Np + c] = c <= r ? a[r][c] : 0.0;
-        D[((long long) k * T + r) * T + c] = c <= r ? x[r][c] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = r0 + 4 * q;
+        tile[(long long) r * Np + c] = c <= r ? a[q] : 0.0;
+        D[((long long) k * T + r) * T + c] = c <= r ? x[q] : 0.0;
     }
 }
 
@@ -222,7 +244,7 @@ void dense_spd_inverse(long long n, double *A, DenseWork &w, hipStream_t s) {
     VFEM_HIP(hipMemsetAsync(w.info.p, 0, sizeof(int), s));
     k_dense_pad<<<gsq, 256, 0, s>>>(n, Np, A, w.L.p);
     for (int k = 0; k < nb; ++k) {
-        k_chol_diag<<<1, 64, 0, s>>>(Np, k, w.L.p, w.D.p, w.info.p);
+        k_chol_diag<<<1, 256, 0, s>>>(Np, k, w.L.p, w.D.p, w.info.p);
         const int rest = nb - k - 1;
         if (rest > 0) {
             k_chol_panel<<<rest, 256, 0, s>>>(Np, k, w.L.p, w.D.p);

@@ -90,74 +90,82 @@ __device__ __forceinline__ void load_nodes(__amdgpu_buffer_rsrc_t r, const Dims 
             un[oy + 1][3 * (oz + 1) + 2] = mk(w.x, w.y);
         }
 }
-// the 4 x 4 fine moduli (2j - 2 + p_y, 2k - 2 + p_z) of one fine x-plane
-__device__ __forceinline__ void load_moduli(__amdgpu_buffer_rsrc_t r, const unsigned (&off)[4][2], double (&e)[4][4]) {
+// The moduli of a node group in LDS: sE[fine x-plane p_x][4 p_y + p_z][lane] (32 KB per workgroup, every lane reads back only what it
+// wrote: no bank conflicts, no ordering beyond the one workgroup barrier).  The wave of the plane below loads the two fine planes below
+// the node, the wave of the plane above the two above; the wave of the node's own plane -- whose sums run over all four -- loads
+// none.  Windows of 2 x 2 moduli are read when a mirror class is reached, so a wave holds 4 (8) moduli in registers instead of 32 (64):
+// 128 registers per wave, four waves per SIMD instead of two (the kernel is bound by the latency of its loads, not by bandwidth or
+// arithmetic: profiles/r03_l1_merged.txt).
+typedef double d2_t __attribute__((ext_vector_type(2)));
+struct ModuliLds {
+    double (*sE)[16][64];
+    int lane;
+    template <int G>
+    __device__ __forceinline__ void window(int px, double (&a)[2][2]) const {
+        constexpr int gy = (G >> 1) & 1, gz = G & 1;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dz = 0; dz < 2; ++dz) a[dy][dz] = sE[px][4 * l1m::class_index(dy, gy) + l1m::class_index(dz, gz)][lane];
+    }
+};
+// the lane's 4 x 4 moduli of one fine x-plane, memory -> LDS
+__device__ __forceinline__ void stage_moduli(__amdgpu_buffer_rsrc_t r, const unsigned (&off)[4][2], double (*plane)[64], int lane) {
+    u4_t v[4][2];
 #pragma unroll
     for (int py = 0; py < 4; ++py)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #ifdef L1M_NOLOAD
-            const u4_t v = {off[py][h], 0x3ff00000u, off[py][h] + 1, 0x3ff00000u}; (void) r;
+            v[py][h] = u4_t{off[py][h], 0x3ff00000u, off[py][h] + 1, 0x3ff00000u}; (void) r;
 #else
-            const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off[py][h], 0, 0);
+            v[py][h] = __builtin_amdgcn_raw_buffer_load_b128(r, off[py][h], 0, 0);
 #endif
-            e[py][2 * h] = mk(v.x, v.y);
-            e[py][2 * h + 1] = mk(v.z, v.w);
+        }
+#pragma unroll
+    for (int py = 0; py < 4; ++py)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            plane[4 * py + 2 * h][lane] = mk(v[py][h].x, v[py][h].y);
+            plane[4 * py + 2 * h + 1][lane] = mk(v[py][h].z, v[py][h].w);
         }
 }
 
 template <int SIDE, int G>
-__device__ __forceinline__ void side_classes(const double (&Es)[2][4][4], const double (&un)[3][9], DevCoef<false> &cf, double S[3]) {
+__device__ __forceinline__ void side_classes(const ModuliLds &m, const double (&un)[3][9], DevCoef<false> &cf, double S[3]) {
 #ifdef L1M_NOCOMP
-    if constexpr (G == 0) { for (auto &p : Es) for (auto &r : p) for (double v : r) S[0] += v; for (auto &r : un) for (double v : r) S[1] += v; }
+    if constexpr (G == 0) { for (auto &r : un) for (double v : r) S[1] += v; }
 #else
     double a[2][2];
-    l1m::class_window<G>(Es[(G >> 2) & 1], a);
+    m.template window<G>(SIDE ? 2 + ((G >> 2) & 1) : 1 - ((G >> 2) & 1), a);
     l1m::side_class<SIDE, G>(a, un, cf, S);
 #endif
-    if constexpr (G + 1 < 8) side_classes<SIDE, G + 1>(Es, un, cf, S);
+    if constexpr (G + 1 < 8) side_classes<SIDE, G + 1>(m, un, cf, S);
 }
 template <int G>
-__device__ __forceinline__ void mid_classes(const double (&Em)[4][4][4], const double (&un)[3][9], DevCoef<true> &cf, double S[3], double M[6]) {
+__device__ __forceinline__ void mid_classes(const ModuliLds &m, const double (&un)[3][9], DevCoef<true> &cf, double S[3], double M[6]) {
 #ifdef L1M_NOCOMP
-    if constexpr (G == 0) { for (auto &p : Em) for (auto &r : p) for (double v : r) S[0] += v; for (auto &r : un) for (double v : r) S[1] += v; M[0] = M[3] = M[5] = 1.0; }
+    if constexpr (G == 0) { for (auto &r : un) for (double v : r) S[1] += v; M[0] = M[3] = M[5] = 1.0; }
 #else
     double a0[2][2], a1[2][2];
-    l1m::class_window<G>(Em[1 - ((G >> 2) & 1)], a0);
-    l1m::class_window<G>(Em[2 + ((G >> 2) & 1)], a1);
+    m.template window<G>(1 - ((G >> 2) & 1), a0);
+    m.template window<G>(2 + ((G >> 2) & 1), a1);
     l1m::mid_class<G>(a0, a1, un, cf, S, M);
 #endif
-    if constexpr (G + 1 < 8) mid_classes<G + 1>(Em, un, cf, S, M);
+    if constexpr (G + 1 < 8) mid_classes<G + 1>(m, un, cf, S, M);
 }
 
-template <int SIDE>
-__device__ __forceinline__ void side_part(const Dims &d, const double *tab, const double *E, const double *u, int i, int j, int k,
-                                          const unsigned (&eoff)[4][2], double S[3]) {
-    const long long eplane = 4LL * d.ny * d.nz;
-    double un[3][9], Es[2][4][4];
-    load_nodes(plane_rsrc(u, 3LL * d.NY * d.NZ, i + (SIDE ? 1 : -1), d.NX), d, j, k, un);
-    // mirror class bit g_x = 0: the fine plane next to the node, 1: the one beyond; a side outside the grid has no planes
-    const bool ok = SIDE ? i < d.NX - 1 : i > 0;
-    load_moduli(plane_rsrc(E, eplane, ok ? (SIDE ? 2 * i : 2 * i - 1) : -1, 2 * d.nx), eoff, Es[0]);
-    load_moduli(plane_rsrc(E, eplane, ok ? (SIDE ? 2 * i + 1 : 2 * i - 2) : -1, 2 * d.nx), eoff, Es[1]);
-    DevCoef<false> cf{tab};
-#ifndef L1M_NOCOMP
-    cf.prime();
-#endif
-    S[0] = S[1] = S[2] = 0.0;
-    side_classes<SIDE, 0>(Es, un, cf, S);
-}
-
-// One group of 64 nodes (lane = node (i, j, k), i and j uniform over the wave or not -- only i must be): three waves (role = 0: plane
-// below, 1: own plane and the relaxation, 2: plane above).  MODE 0: relax in place; 1: out = A u; 2: out = b - A u, 0 at fixed
-// components.  Contains one workgroup barrier; `part` is the workgroup's exchange area.
+// One group of 64 nodes (lane = node (i, j, k); i uniform over the workgroup): three waves (role = 0: plane below, 1: own plane and the
+// relaxation, 2: plane above).  MODE 0: relax in place; 1: out = A u; 2: out = b - A u, 0 at fixed components.  Two workgroup barriers.
 template <int MODE>
 __device__ __forceinline__ void node_group(const Dims &d, const double *__restrict__ tab, const double *__restrict__ E, const double *u,
                                            const double *__restrict__ b, const uint8_t *__restrict__ mask, double *out, int i, int j, int k,
-                                           bool live, int role, int lane, int forward, double (&part)[2][3][64]) {
-    // byte offsets of the lane's 4 x 2 pieces (16 B: two moduli) in a fine x-plane; pieces outside the grid read as 0
-    unsigned eoff[4][2];
-    {
+                                           bool live, int role, int lane, int forward, double (&part)[2][3][64], double (*sE)[16][64]) {
+    double un[3][9];
+    load_nodes(plane_rsrc(u, 3LL * d.NY * d.NZ, i + role - 1, d.NX), d, j, k, un);
+    if (role != 1) {
+        // byte offsets of the lane's 4 x 2 pieces (16 B: two moduli) in a fine x-plane; pieces outside the grid read as 0
+        unsigned eoff[4][2];
         const int nzf = 2 * d.nz;
 #pragma unroll
         for (int py = 0; py < 4; ++py)
@@ -166,42 +174,44 @@ __device__ __forceinline__ void node_group(const Dims &d, const double *__restri
                 const bool ok = (py < 2 ? j >= 1 : j <= d.ny - 1) && (h == 0 ? k >= 1 : k <= d.nz - 1);
                 eoff[py][h] = ok ? (unsigned) ((2 * j - 2 + py) * nzf + 2 * k - 2 + 2 * h) * 8u : OOB;
             }
-    }
-    double S[3];
-    if (role == 0) {
-        side_part<0>(d, tab, E, u, i, j, k, eoff, S);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) part[0][c][lane] = S[c];
-    } else if (role == 2) {
-        side_part<1>(d, tab, E, u, i, j, k, eoff, S);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) part[1][c][lane] = S[c];
-    }
-    double M6[6], uc[3];
-    if (role == 1) {
         const long long eplane = 4LL * d.ny * d.nz;
-        double un[3][9], Em[4][4][4];
-        load_nodes(plane_rsrc(u, 3LL * d.NY * d.NZ, i, d.NX), d, j, k, un);
-        const bool lo = i > 0, hi = i < d.NX - 1;
-        load_moduli(plane_rsrc(E, eplane, lo ? 2 * i - 2 : -1, 2 * d.nx), eoff, Em[0]);
-        load_moduli(plane_rsrc(E, eplane, lo ? 2 * i - 1 : -1, 2 * d.nx), eoff, Em[1]);
-        load_moduli(plane_rsrc(E, eplane, hi ? 2 * i : -1, 2 * d.nx), eoff, Em[2]);
-        load_moduli(plane_rsrc(E, eplane, hi ? 2 * i + 1 : -1, 2 * d.nx), eoff, Em[3]);
+        const int p0 = role == 0 ? 0 : 2;                      // fine planes 2 i - 2 + p; a side outside the grid has no planes
+        const bool ok = role == 0 ? i > 0 : i < d.NX - 1;
+        stage_moduli(plane_rsrc(E, eplane, ok ? 2 * i - 2 + p0 : -1, 2 * d.nx), eoff, sE[p0], lane);
+        stage_moduli(plane_rsrc(E, eplane, ok ? 2 * i - 1 + p0 : -1, 2 * d.nx), eoff, sE[p0 + 1], lane);
+    }
+    __syncthreads();
+    const ModuliLds m{sE, lane};
+    double S[3] = {0.0, 0.0, 0.0}, M6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    // (a coefficient request in flight must not cross a branch: each role primes its own pipeline inside its branch)
+    if (role == 1) {
         DevCoef<true> cf{tab};
 #ifndef L1M_NOCOMP
         cf.prime();
 #endif
-        S[0] = S[1] = S[2] = 0.0;
+        mid_classes<0>(m, un, cf, S, M6);
+    } else if (role == 0) {
+        DevCoef<false> cf{tab};
+#ifndef L1M_NOCOMP
+        cf.prime();
+#endif
+        side_classes<0, 0>(m, un, cf, S);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) M6[q] = 0.0;
-        mid_classes<0>(Em, un, cf, S, M6);
+        for (int c = 0; c < 3; ++c) part[0][c][lane] = S[c];
+    } else {
+        DevCoef<false> cf{tab};
+#ifndef L1M_NOCOMP
+        cf.prime();
+#endif
+        side_classes<1, 0>(m, un, cf, S);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) uc[c] = un[1][3 + c];
+        for (int c = 0; c < 3; ++c) part[1][c][lane] = S[c];
     }
     __syncthreads();
     if (role != 1 || !live) return;
 #pragma unroll
     for (int c = 0; c < 3; ++c) S[c] = (part[0][c][lane] + S[c]) + part[1][c][lane];
+    const double uc[3] = {un[1][3], un[1][4], un[1][5]};
     const long long n = ((long long) i * d.NY + j) * d.NZ + k;
     const double M[9] = {M6[0], M6[1], M6[2], M6[1], M6[3], M6[4], M6[2], M6[4], M6[5]};
     if (MODE == 1) {
@@ -212,23 +222,27 @@ __device__ __forceinline__ void node_group(const Dims &d, const double *__restri
     double bms[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) bms[c] = b[3 * n + c] - (S[c] + (M[3 * c] * uc[0] + M[3 * c + 1] * uc[1] + M[3 * c + 2] * uc[2]));
-    const uint8_t m = mask ? mask[n] : 0;
+    const uint8_t mk8 = mask ? mask[n] : 0;
     if (MODE == 2) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) out[3 * n + c] = ((m >> c) & 1) ? 0.0 : bms[c];
+        for (int c = 0; c < 3; ++c) out[3 * n + c] = ((mk8 >> c) & 1) ? 0.0 : bms[c];
         return;
     }
     double ud[3];
-    gs_solve(bms, M, m, forward != 0, ud);
+    gs_solve(bms, M, mk8, forward != 0, ud);
 #pragma unroll
     for (int c = 0; c < 3; ++c) out[3 * n + c] = uc[c] + ud[c];
 }
 
+#ifndef L1M_WAVES
+#define L1M_WAVES 3
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(192) k_l1_merged(Dims d, const double *__restrict__ tab, const double *__restrict__ E,
+__global__ void __launch_bounds__(192, L1M_WAVES) k_l1_merged(Dims d, const double *__restrict__ tab, const double *__restrict__ E,
                                                    const double *u, const double *__restrict__ b, const uint8_t *__restrict__ mask,
                                                    double *out, int cx, int cy, int cz, int forward) {
     __shared__ double part[2][3][64];
+    __shared__ double sE[4][16][64];
     const int lane = threadIdx.x, role = __builtin_amdgcn_readfirstlane(threadIdx.y);
     int i, j, k;
     bool live;
@@ -244,7 +258,7 @@ __global__ void __launch_bounds__(192) k_l1_merged(Dims d, const double *__restr
         const int qq = live ? q : d.NY * d.NZ - 1;
         j = qq / d.NZ; k = qq - j * d.NZ; i = blockIdx.z;
     }
-    node_group<MODE>(d, tab, E, u, b, mask, out, i, j, k, live, role, lane, forward, part);
+    node_group<MODE>(d, tab, E, u, b, mask, out, i, j, k, live, role, lane, forward, part, sE);
 }
 
 }  // namespace
