@@ -212,8 +212,9 @@ static void mg_apply(vfem_mg *mg, int l, const double *u, const double *b, int r
     else if (L.kind == OP_MF0 && mg->fine->fast_ok) {
         const vfem_sim *sim = mg->fine;
         const Tuning &t = sim->tune;
-        if (res == 0 && t.apply_impl == 0 &&
-            launch_apply_dma(L.d, sim->Dm, level_E(mg, 0), sim->E.p + sim->n_store(), u, out, s, 0, -1, t.dma_chunks, t.dma_strip)) return;
+        if (t.apply_impl == 0 &&
+            launch_apply_dma(L.d, sim->Dm, level_E(mg, 0), sim->E.p + sim->n_store(), u, out, s, 0, -1, t.dma_chunks, t.dma_strip,
+                             res ? b : nullptr, res ? L.maskp : nullptr)) return;
         launch_apply_fast(L.d, sim->Dm, level_E(mg, 0), u, b, L.maskp, res, out, s, t.apply_pd);
     }
     else if (level_uses_merged_rows(mg, l)) launch_l1_merged_apply(L.d, mg->l1mtab.p, level_E(mg, l), u, b, L.maskp, res, out, s);

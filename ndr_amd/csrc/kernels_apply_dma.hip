@@ -74,11 +74,14 @@ __device__ __forceinline__ void glds16(const void *g, void *l) {
                                      (__attribute__((address_space(3))) void *) l, 16, 0, 0);
 }
 
-template <int EXP, class C>
+// RES: out = b - K u with 0 at the fixed components (the residual of the V-cycle) instead of K u: right-hand side and mask of the
+// node a thread emits are requested one phase ahead, before the arithmetic of the plane in between
+template <int EXP, class C, bool RES = false>
 __device__ __forceinline__ void apply_tile(const Dims &d, const DmArgs2 &dm, const double *__restrict__ E,
                                            const double *__restrict__ u, double *__restrict__ out,
                                            int planes_per_chunk, const char *u_last, const char *e_last,
-                                           int plane_lo, int plane_hi, int kz_origin, int ztile, int ytile) {
+                                           int plane_lo, int plane_hi, int kz_origin, int ztile, int ytile,
+                                           const double *__restrict__ rhs = nullptr, const uint8_t *__restrict__ fixed = nullptr) {
     using namespace dma;
     constexpr int TY = C::TY, TZ = C::TZ, PU = C::PU, PE = C::PE, ROW_D = C::ROW_D, EROW_D = C::EROW_D;
     constexpr int U_INSTR = C::U_INSTR, NQ = C::NQ, NI = C::NI, SLOT_BYTES = C::SLOT_BYTES, SS_DOUBLES = C::SS_DOUBLES;
@@ -236,7 +239,16 @@ __device__ __forceinline__ void apply_tile(const Dims &d, const DmArgs2 &dm, con
             sX[(c * TY + ty) * TZ + tz] = (r - t) + lane_below(r + t);
         }
     };
-    auto emit_plane = [&](int i, const double wa[3], int buf) {
+    auto request_rhs = [&](int i, double rhs_n[3], unsigned &fixed_n) {      // for the node emit_plane(i, ...) will write
+        rhs_n[0] = rhs_n[1] = rhs_n[2] = 0.0;
+        fixed_n = 0;
+        if (!RES || !out_ok) return;
+        const long long n = (long long) i * plane + (long long) ej * d.NZ + ek;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rhs_n[c] = rhs[3 * n + c];
+        if (fixed != nullptr) fixed_n = fixed[n];
+    };
+    auto emit_plane = [&](int i, const double wa[3], int buf, const double rhs_n[3], unsigned fixed_n) {
         if (X == 5) return;
         if (EXP == 11 ? !(ty >= 1 && ej < d.NY) : !out_ok) return;
         const double *sX = sS + buf * SS_DOUBLES;
@@ -245,6 +257,10 @@ __device__ __forceinline__ void apply_tile(const Dims &d, const DmArgs2 &dm, con
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             w[c] = (X == 1 || X >= 3) ? wa[c] : wa[c] + sX[(c * TY + ty - 1) * TZ + tz];
+        if (RES) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) w[c] = ((fixed_n >> c) & 1) ? 0.0 : rhs_n[c] - w[c];
+        }
         if (EXP == 11) {      // timing only: the row written as contiguous 16-byte pieces (piece = lane, then 64 + lane), values meaningless
             const long long n0 = (long long) i * plane + (long long) ej * d.NZ + (k0 + 1);     // first output node of the row
             double *row = out + 3 * n0;
@@ -362,11 +378,14 @@ __device__ __forceinline__ void apply_tile(const Dims &d, const DmArgs2 &dm, con
         cur = cur + 1 == RING ? 0 : cur + 1;
         double wa[3];
         const double Enext = su[eoff2[k]];             // modulus of layer ii, used in the next phase
+        double rhs_n[3];
+        unsigned fixed_n;
+        request_rhs(ii - 1 >= p0 ? ii - 1 : p0, rhs_n, fixed_n);
         process(Eprev, su, qoff[k], buf, wa);
         Eprev = Enext;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                  // the DMA waves arrive here once plane ii + 1 has landed
-        if (ii - 1 >= p0) emit_plane(ii - 1, wa, buf);
+        if (ii - 1 >= p0) emit_plane(ii - 1, wa, buf, rhs_n, fixed_n);
         buf ^= 1;
     };
     for (int ii = i_start + 1; ii <= i_end; ii += 2) {
@@ -374,11 +393,13 @@ __device__ __forceinline__ void apply_tile(const Dims &d, const DmArgs2 &dm, con
         if (ii + 1 <= i_end) run_phase(ii + 1, 1);
     }
     if (p1 == d.NX - 1) {
-        double wa[3];
+        double wa[3], rhs_n[3];
+        unsigned fixed_n;
+        request_rhs(d.NX - 1, rhs_n, fixed_n);
         scatter_face(carry, wa, buf);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        emit_plane(d.NX - 1, wa, buf);
+        emit_plane(d.NX - 1, wa, buf, rhs_n, fixed_n);
     }
 }
 
@@ -400,9 +421,25 @@ __global__ void __launch_bounds__(64 * (dma::WAVES + dma::NW)) k_apply_dma(Dims 
     }
 }
 
-// chunks: number of x-chunks of the marching blocks (0 = default); strip: 0 tiles the whole row with the main shape
+__global__ void __launch_bounds__(64 * (dma::WAVES + dma::NW)) k_residual_dma(Dims d, DmArgs2 dm, const double *__restrict__ E,
+                                                      const double *__restrict__ u, double *__restrict__ out,
+                                                      int planes_per_chunk, const char *u_last, const char *e_last,
+                                                      int plane_lo, int plane_hi, int n_main, int strip_origin, int strip_ytiles, int strip_ppc,
+                                                      const double *__restrict__ rhs, const uint8_t *__restrict__ fixed) {
+    if ((int) blockIdx.y < n_main) {
+        if ((int) blockIdx.z * (dma::Main::TY - 1) > d.NY - 1) return;
+        apply_tile<0, dma::Main, true>(d, dm, E, u, out, planes_per_chunk, u_last, e_last, plane_lo, plane_hi, 0, (int) blockIdx.y, (int) blockIdx.z, rhs, fixed);
+    } else {
+        if ((int) blockIdx.z >= strip_ytiles) return;
+        apply_tile<0, dma::Strip, true>(d, dm, E, u, out, strip_ppc, u_last, e_last, plane_lo, plane_hi, strip_origin, 0, (int) blockIdx.z, rhs, fixed);
+    }
+}
+
+// chunks: number of x-chunks of the marching blocks (0 = default); strip: 0 tiles the whole row with the main shape;
+// rhs != null: out = rhs - K u, 0 where `fixed` (may be null) has the component's bit set
 bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, const double *E_alloc_end, const double *u,
-                      double *out, hipStream_t s, int plane_lo, int plane_hi, int g_dma_chunks, int g_dma_strip) {
+                      double *out, hipStream_t s, int plane_lo, int plane_hi, int g_dma_chunks, int g_dma_strip,
+                      const double *rhs, const uint8_t *fixed) {
     using namespace dma;
     if (plane_hi < 0 || plane_hi > d.NX - 1) plane_hi = d.NX - 1;
     if (plane_lo < 0) plane_lo = 0;
@@ -443,6 +480,16 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
         }                                                                                                                    \
         k_apply_dma<X><<<grd, blk, Main::LDS_BYTES, s>>>(d, dm, E, u, out, ppc, ul, el, plane_lo, plane_hi, n_main, wz * n_main, strip_ytiles, strip_ppc); \
     } while (0)
+    if (rhs) {
+        static bool attr = false;
+        if (!attr) {
+            VFEM_HIP(hipFuncSetAttribute((const void *) k_residual_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int) Main::LDS_BYTES));
+            attr = true;
+        }
+        k_residual_dma<<<grd, blk, Main::LDS_BYTES, s>>>(d, dm, E, u, out, ppc, ul, el, plane_lo, plane_hi, n_main, wz * n_main, strip_ytiles, strip_ppc, rhs, fixed);
+        VFEM_HIP(hipGetLastError());
+        return true;
+    }
 #ifdef VFEM_ABLATION
     switch (g_apply_skeleton) {
         case 1: VFEM_DMA_LAUNCH(1); break;

@@ -196,16 +196,16 @@ __device__ __forceinline__ void node_group(const Dims &d, const double *__restri
         cf.prime();
 #endif
         side_classes<0, 0>(m, un, cf, S);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) part[0][c][lane] = S[c];
     } else {
         DevCoef<false> cf{tab};
 #ifndef L1M_NOCOMP
         cf.prime();
 #endif
         side_classes<1, 0>(m, un, cf, S);
+    }
+    if (role != 1) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) part[1][c][lane] = S[c];
+        for (int c = 0; c < 3; ++c) part[role >> 1][c][lane] = S[c];
     }
     __syncthreads();
     if (role != 1 || !live) return;
@@ -242,7 +242,8 @@ __global__ void __launch_bounds__(192, L1M_WAVES) k_l1_merged(Dims d, const doub
                                                    const double *u, const double *__restrict__ b, const uint8_t *__restrict__ mask,
                                                    double *out, int cx, int cy, int cz, int forward) {
     __shared__ double part[2][3][64];
-    __shared__ double sE[4][16][64];
+    __shared__ double sE[4][16][64];     // (35 KB with the exchange area: four workgroups per CU.  Exactly 32 KB -- exchange area inside it, a
+                                         // third barrier -- and five workgroups measured no faster: 2.91 against 2.88 ms per sweep at 257^3)
     const int lane = threadIdx.x, role = __builtin_amdgcn_readfirstlane(threadIdx.y);
     int i, j, k;
     bool live;

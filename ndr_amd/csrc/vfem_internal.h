@@ -111,7 +111,8 @@ void launch_apply_fast(const Dims &d, const double *Dm_host, const double *E, co
                        const uint8_t *mask, int mode, double *out, hipStream_t s, int planes_in_flight = 2);
 // LDS-DMA version of the plain apply (mode 0); returns false when it must not be used for these buffers
 bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, const double *E_alloc_end, const double *u,
-                      double *out, hipStream_t s, int plane_lo = 0, int plane_hi = -1, int chunks = 0, int strip = 1);
+                      double *out, hipStream_t s, int plane_lo = 0, int plane_hi = -1, int chunks = 0, int strip = 1,
+                      const double *rhs = nullptr, const uint8_t *fixed = nullptr);      // rhs: out = rhs - K u, 0 at fixed components
 
 // colours are processed in the reference order (global parity); `xparity` = global x-parity of local plane 0,
 // [first, first+count) selects a sub-range of the 8 colours (half sweeps between halo exchanges)
