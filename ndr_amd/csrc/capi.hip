@@ -139,12 +139,29 @@ void vfem_sim::update_k0() {
         if (!used[q] && std::fabs(Dfull[q]) > 1e-13 * maxabs) fast_ok = false;
     dK0.alloc(576);
     VFEM_HIP(hipMemcpy(dK0.p, K0, sizeof(K0), hipMemcpyHostToDevice));
-    double tab[GS_TABLE_DOUBLES + 36 + 48];
+    double tab[GS_TABLE_DOUBLES + 36 + 48 + 96];
     vfem::build_gs_table(K0, tab);
     gs_resident_ok = vfem::build_gs_coef(K0, tab + GS_TABLE_DOUBLES);
     vfem::build_gs_coef_parts(tab + GS_TABLE_DOUBLES, tab + GS_TABLE_DOUBLES + 36, tab + GS_TABLE_DOUBLES + 60);
     tune.gs_resident = gs_resident_ok ? 1 : 0;
-    dGsTab.alloc(GS_TABLE_DOUBLES + 36 + 48);
+    {   // K0 by neighbour kind for the node-per-lane marching sweep (class 0 of l1m::build_table applied to K0 itself); it relies on
+        // K0[(n^f,a),(m^f,b)] = s_a(f) s_b(f) K0[(n,a),(m,b)] (box voxel, isotropic / orthotropic tensor), checked here
+        double full[L1M_TABLE_DOUBLES];
+        vfem::build_l1_merged_table(K0, full);
+        std::memcpy(tab + GS_TABLE_DOUBLES + 84, full, 96 * sizeof(double));
+        double scale = 0.0, err = 0.0;
+        for (int q = 0; q < 576; ++q) scale = std::max(scale, std::fabs(K0[q]));
+        for (int f = 1; f < 8; ++f)
+            for (int n = 0; n < 8; ++n)
+                for (int a = 0; a < 3; ++a)
+                    for (int m = 0; m < 8; ++m)
+                        for (int b = 0; b < 3; ++b) {
+                            const double sg = (((f >> (2 - a)) ^ (f >> (2 - b))) & 1) ? -1.0 : 1.0;
+                            err = std::max(err, std::fabs(K0[(3 * n + a) * 24 + 3 * m + b] - sg * K0[(3 * (n ^ f) + a) * 24 + 3 * (m ^ f) + b]));
+                        }
+        k0_mirror_ok = err <= 1e-13 * scale;
+    }
+    dGsTab.alloc(GS_TABLE_DOUBLES + 36 + 48 + 96);
     VFEM_HIP(hipMemcpy(dGsTab.p, tab, sizeof(tab), hipMemcpyHostToDevice));
 }
 
@@ -247,6 +264,12 @@ static void gs_solve_data(vfem_mg *mg, hipStream_t s) {
     L.gs_sd_version = sim->operator_version;
 }
 
+// the marching sweep's form: one node per lane (the neighbour-kind table of K0) when K0 has the mirror symmetry it needs, else
+// (or by VFEM_OPT_GS_MARCH_FORM = 1) the mirrored half waves
+static const double *march_form2_table(const vfem_sim *sim) {
+    return (sim->tune.gs_march_form == 2 && sim->k0_mirror_ok) ? sim->dGsTab.p + GS_TABLE_DOUBLES + 84 : nullptr;
+}
+
 // n consecutive sweeps of level l in one direction.  Level 0 runs them as marching half sweeps (kernels_gs_march.hip) when
 // it can: those are out of place, so the planes of either parity alternate between u and the level's scratch vector; an even
 // number of sweeps ends in u, an odd one is followed by a copy of the planes left in the scratch vector.
@@ -269,7 +292,7 @@ static void mg_smooth_n(vfem_mg *mg, int l, double *u, const double *b, int forw
             if (cxl > L.d.NX - 1) continue;
             double *dst = cur[cxl] == u ? L.tmp.p : u;
             if (!launch_gs_march_mf0(L.d, coef, level_E(mg, 0), sim->E.p, sim->E.p + sim->n_store(), cur[cxl], cur[1 - cxl], dst, b, L.gs_sd.p,
-                                     cxl, forward, t.gs_march_chunks, s)) {
+                                     cxl, forward, t.gs_march_chunks, s, 0, -1, march_form2_table(sim), t.gs_march_form)) {
                 // buffers the kernel cannot take: finish in place with the row kernels
                 for (int par = 0; par < 2; ++par)
                     if (cur[par] != u) { launch_copy_planes(L.d, par, cur[par], u, s); cur[par] = u; }
@@ -294,7 +317,7 @@ static bool mg_smooth_half(vfem_mg *mg, int l, double *u, const double *b, int f
     L.tmp.reserve((size_t) L.d.nn * 3);
     gs_solve_data(mg, s);
     if (!launch_gs_march_mf0(L.d, sim->dGsTab.p + GS_TABLE_DOUBLES, level_E(mg, 0), sim->E.p, sim->E.p + sim->n_store(), u, u, L.tmp.p, b, L.gs_sd.p,
-                             cxl, forward, t.gs_march_chunks, s, plane_lo, plane_hi)) return false;
+                             cxl, forward, t.gs_march_chunks, s, plane_lo, plane_hi, march_form2_table(sim), t.gs_march_form)) return false;
     launch_copy_planes(L.d, cxl, L.tmp.p, u, s, plane_lo, plane_hi);
     return true;
 }
@@ -527,6 +550,7 @@ int vfem_sim_set_option(vfem_sim *sim, int key, int value) {
         case VFEM_OPT_L1_SPLIT:      if (value != 1 && value != 2 && value != 4 && value != 8) throw Error("level-1 slot split 1, 2, 4 or 8"); t.l1_split = value; break;
         case VFEM_OPT_STENCIL_SPLIT: t.stencil_split = value != 0; break;
         case VFEM_OPT_GS_MARCH:      if (value < 0 || value > 2) throw Error("marching sweep mode 0..2"); t.gs_march = value; break;
+        case VFEM_OPT_GS_MARCH_FORM: if (value != 1 && value != 2) throw Error("marching sweep form 1 or 2"); t.gs_march_form = value; break;
         case VFEM_OPT_GS_MARCH_CHUNKS: if (value < 0) throw Error("negative chunk count"); t.gs_march_chunks = value; break;
         case VFEM_OPT_L1_STORED:     if (value < 0 || value > 2) throw Error("level-1 storage mode 0..2"); t.l1_stored = value; ++sim->operator_version; break;
         case VFEM_OPT_L1_MERGED:     t.l1_merged = value != 0; break;

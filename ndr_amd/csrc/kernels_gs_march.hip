@@ -28,13 +28,17 @@
 #include "vfem_internal.h"
 #include "device_utils.h"
 #include "gs_coef.h"
+#include "coef_rows.h"
 
 namespace vfem {
 
 namespace gsm {
 constexpr int R = 6;                          // owned row pairs of a tile (2R owned node rows)
 constexpr int C = 29;                         // owned column pairs (2C owned node columns); C + 3 = 32 lanes in the widest colour
-constexpr int CW = R + 1;                     // compute waves
+constexpr int CW = R + 1;                     // compute waves, form 1 (a wave = one row of the colour, as two x-mirrored half waves)
+constexpr int CW2 = (R + 2) / 2;               // form 2 (a wave = two rows of the colour, one node per lane)
+constexpr int compute_waves(int form) { return form == 2 ? CW2 : CW; }
+
 constexpr int LY = 2 * R + 3, LZ = 2 * C + 7; // staged node rows / columns (15 x 65)
 constexpr int EY = 2 * R + 2, EZ = 2 * C + 6; // staged element rows / columns (14 x 64)
 constexpr int PU = (LZ * 24 + 8 + 15) / 16;   // 16-byte pieces per staged node row incl. the alignment shift (98)
@@ -52,6 +56,7 @@ static_assert(2 * (U_INSTR + E_INSTR) <= 63, "one step of DMA must fit the 6-bit
 
 struct GsMarchArgs {
     Dims d;
+    const double *tab;             // form 2: K0 by neighbour kind, signs folded in (l1m::build_table of K0, class 0: 8 rows of 12 doubles)
     const double *coef;            // 36 resident coefficients (build_gs_coef) followed by the two 24-entry part tables (build_gs_coef_parts)
     const double *E;               // moduli of the level's elements, [nx][ny][nz]
     const char *e_first, *e_last;  // first / last admissible 16-byte piece of the moduli allocation
@@ -68,6 +73,7 @@ struct GsMarchArgs {
 };
 
 typedef double d2a_t __attribute__((ext_vector_type(2), aligned(16)));
+
 
 __device__ __forceinline__ void gsm_glds16(const void *g, void *l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) g,
@@ -100,9 +106,16 @@ __device__ __forceinline__ long long gsm_now() {
 // tile origins have the parity of P, so nothing in it depends on the tile, and the planes of a launch have fixed parities.  It is
 // therefore QF + k + ALT (ro + dy) for the far planes and QM + k + ALT (ro + dy) for the relaxed plane with launch-uniform QF, QM,
 // which are template parameters: every register index in the multiply-adds is a compile-time constant.
-template <int ALT, int QF, int QM>
-__global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs A) {
+//
+// FORM 2 (round 3, second half): one node per LANE.  Form 1 spends 2 x 270 fp64 operations per node (two mirrored half waves, each
+// with its own products against K0 and its own moduli sums); summed per NEIGHBOUR instead -- the moduli of the elements that share
+// a neighbour are combined first (sums and differences over the sides: l1_merged_core.h, the level-1 arithmetic with a single
+// mirror class) -- a node costs 26 x 9 + 63 + 18 multiply-adds and ~100 additions = ~400 operations.  A wave relaxes TWO rows of
+// the colour (lanes 0-31 / 32-63), four compute waves instead of seven, one per SIMD.
+template <int ALT, int QF, int QM, int FORM>
+__global__ void __launch_bounds__(64 * (gsm::compute_waves(FORM) + 1)) k_gs_march_mf0(GsMarchArgs A) {
     using namespace gsm;
+    constexpr int CWv = compute_waves(FORM);
     const int P = A.forward ? 0 : 1;              // parity of the first in-plane colour: 0 forward colour order, 1 reverse
     extern __shared__ __align__(16) unsigned char smem[];
     double *sU = reinterpret_cast<double *>(smem);
@@ -143,7 +156,7 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
     const bool fix_yz = yl < 0 || yl + EY - 1 > d.ny - 1 || zl < 0 || zl + EZ - 1 > d.nz - 1;
 
     // =========================== DMA wave ===========================
-    if (wave == CW) {
+    if (wave == CWv) {
         unsigned ugo[U_INSTR], ego[E_INSTR];          // (double offset of the lane's piece from the plane / layer start) * 2 + row-start parity
 #pragma unroll
         for (int t = 0; t < U_INSTR; ++t) {
@@ -203,6 +216,7 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
 
     // =========================== compute waves ===========================
     const int h = lane >> 5, cl = lane & 31;                            // half (0: low side, 1: high side, computed on mirrored data), column index
+    const int hq = h, clq = cl;
     const unsigned long long sgn = h ? 0x8000000000000000ull : 0ull;
     const int z0s = zb < 0 ? 0 : zb;                                    // owned columns inside the grid: [z0s, z1s]
     const int z1s = zb + 2 * C - 1 > d.NZ - 1 ? d.NZ - 1 : zb + 2 * C - 1;
@@ -219,10 +233,12 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
     // their use (bd[k & 1])
     double bd[2][9];
     auto request = [&](auto kc, int xx) {
+        if constexpr (FORM == 2) return;                                // (form 2 requests at the start of the colour itself)
         constexpr int k = decltype(kc)::value, ro = k >> 1;
         constexpr int nrows = R + 1 - ro, ncols = C + 3 - k;
-        const int y = yl + 1 + ro + 2 * wave, z = zl + 1 + k + 2 * cl;
-        const bool mine = h == 0 && wave < nrows && cl < ncols && y >= 0 && y < d.NY && z >= 0 && z < d.NZ;
+        const int rwq = FORM == 2 ? 2 * wave + h : wave;                   // row of the colour this lane works on
+        const int y = yl + 1 + ro + 2 * rwq, z = zl + 1 + k + 2 * cl;
+        const bool mine = (FORM == 2 || h == 0) && rwq < nrows && cl < ncols && y >= 0 && y < d.NY && z >= 0 && z < d.NZ;
 #pragma unroll
         for (int q = 0; q < 9; ++q) bd[k & 1][q] = 0.0;
         if (mine) {
@@ -254,7 +270,7 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
         };
         if (fix_yz || !lay_ok[0] || !lay_ok[1]) {
             // moduli of elements outside the grid are zero: written over whatever the (clamped) DMA brought, once per layer
-            for (int q = threadIdx.y * 64 + lane; q < 2 * EY * (EZ + 1); q += CW * 64) {
+            for (int q = threadIdx.y * 64 + lane; q < 2 * EY * (EZ + 1); q += CWv * 64) {
                 const int layer = q / (EY * (EZ + 1)), q2 = q - layer * (EY * (EZ + 1));
                 const int r = q2 / (EZ + 1), ci = q2 - r * (EZ + 1);
                 const int ey = yl + r, ez = ek0u + ci;
@@ -264,7 +280,117 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
             __builtin_amdgcn_s_barrier();
         }
 
+        // ---- form 2: one node per lane, rows 2 wave + h of the colour ----
+        auto phase2 = [&](auto kc) {
+            constexpr int k = decltype(kc)::value, ro = k >> 1;
+            constexpr int nrows = R + 1 - ro, ncols = C + 3 - k;
+            // (opaque copies: the row / column arithmetic below does not depend on the step, and hoisted out of the step loop for all
+            // four colours it would hold ~50 registers for the whole march)
+            int h = hq, cl = clq;
+            asm volatile("" : "+v"(h), "+v"(cl));
+            const int rw = 2 * wave + h;
+            const int rwe = rw < nrows ? rw : nrows - 1;                // half waves beyond the colour's rows shadow the last one
+            const int ry = 1 + ro + 2 * rwe;
+            const int y = yl + ry;
+            const int ce = cl < ncols ? cl : ncols - 1;
+            const int czn = 1 + k + 2 * ce;
+            const int z = zl + czn;
+            const bool mine = rw < nrows && cl < ncols && y >= 0 && y < d.NY && z >= 0 && z < d.NZ;
+            // right-hand side and solve data of the node: requested now, used after the ~400 operations below (clamped node for the lanes
+            // that relax nothing: no branch, the values are not used)
+            double B[3], D[6];
+            {
+                const int yc = min(max(y, 0), d.NY - 1), zc = min(max(z, 0), d.NZ - 1);
+                const long long n = ((long long) x * d.NY + yc) * d.NZ + zc;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) B[q] = A.b[3 * n + q];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) D[q] = A.sd[6 * n + q];
+            }
+            int ni = czn - 1 - cshift;
+            ni = max(ni, ni & 1);
+            const int rlo = y - 1 >= 0 ? ry - 1 : ry + 1, rhi = y + 1 <= d.NY - 1 ? ry + 1 : ry - 1;
+            constexpr int OFC = (QF + k + ALT * ro) & 1, OFS = (QF + k + ALT * (ro + 1)) & 1;
+            constexpr int OMC = (QM + k + ALT * ro) & 1, OMS = (QM + k + ALT * (ro + 1)) & 1;
+            const int lowoff = ((2 * m) % NU) * U_SLOT_D, highoff = ((2 * m + 2) % NU) * U_SLOT_D;
+            const int shc = (shF + row_par(ry)) & 1, shs = (shF + row_par(rlo)) & 1;
+            const int mhc = (shM + row_par(ry)) & 1, mhs = (shM + row_par(rlo)) & 1;
+            // the three rows of a plane as the 3 x 3 window of l1m::side_class / mid_class
+            auto window = [&](int slotoff, int sh_c, int sh_s, auto offc, auto offs, double (&un)[3][9]) {
+                constexpr int oc = decltype(offc)::value, os = decltype(offs)::value;
+                double w0[10], w1[10], w2[10];
+                read10(sU, slotoff + rlo * ROW_D + 3 * ni + sh_s - os, w0);
+                read10(sU, slotoff + ry * ROW_D + 3 * ni + sh_c - oc, w1);
+                read10(sU, slotoff + rhi * ROW_D + 3 * ni + sh_s - os, w2);
+#pragma unroll
+                for (int c = 0; c < 9; ++c) { un[0][c] = w0[os + c]; un[1][c] = w1[oc + c]; un[2][c] = w2[os + c]; }
+            };
+            // moduli of the eight incident elements (layer, y - 1 + dj, z - 1 + dk); zero outside the grid (fixed up in LDS above)
+            const int ecol = max(czn - 1 - ecshift, 0);
+            double a0[2][2], a1[2][2];
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+                const int r = ry - 1 + dj;
+                const int e0 = eoffs[0] + r * EROW_D + ecol + erow_shift(0, r), e1 = eoffs[1] + r * EROW_D + ecol + erow_shift(1, r);
+#pragma unroll
+                for (int dk = 0; dk < 2; ++dk) { a0[dj][dk] = sE[e0 + dk]; a1[dj][dk] = sE[e1 + dk]; }
+            }
+            // Software pipeline over the three planes, fenced by scheduling barriers: the windows of the next plane are read while the
+            // current one is multiplied, and no more (left alone the scheduler issues all nine rows' reads and all twelve coefficient
+            // rows up front: 180 registers of windows, 600 spilled scalars).  Coefficient rows come through the scalar cache one row
+            // ahead (coef_rows.h); as LDS reads at a wave-uniform address they were slower (a colour 2.4-3.4 us against 1.8).
+            double S[3] = {0.0, 0.0, 0.0}, M6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, uself[3];
+            double unA[3][9], unB[3][9];
+            __builtin_amdgcn_sched_barrier(0);
+            window(lowoff, shc, shs, std::integral_constant<int, OFC>{}, std::integral_constant<int, OFS>{}, unA);
+            RowPipe<12, L0NodeRows> rows{A.tab};
+            asm volatile("" : "+v"(S[0]) : "v"(a0[0][0]));               // (the chain of row waits starts behind the moduli reads)
+            rows.prime();
+            __builtin_amdgcn_sched_barrier(0);
+            window(midoff, mhc, mhs, std::integral_constant<int, OMC>{}, std::integral_constant<int, OMS>{}, unB);
+            {
+                L0Coef<false, 0> cf{rows, S[0]};
+                l1m::side_class<0, 0>(a0, unA, cf, S);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            window(highoff, shc, shs, std::integral_constant<int, OFC>{}, std::integral_constant<int, OFS>{}, unA);
+            {
+                L0Coef<true, 4> cf{rows, S[0]};
+                l1m::mid_class<0>(a0, a1, unB, cf, S, M6);
+                uself[0] = unB[1][3]; uself[1] = unB[1][4]; uself[2] = unB[1][5];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                L0Coef<false, 8> cf{rows, S[0]};
+                l1m::side_class<1, 0>(a1, unA, cf, S);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                // residual form of m_smoothNode (MG.hh:199-264): S also takes the node's own block; component-sequential solve with the
+                // stored inverse diagonal (0 for a fixed component) and the stored strict lower part (D: i00 i11 i22 m10 m20 m21)
+                const double s0 = S[0] + (M6[0] * uself[0] + M6[1] * uself[1] + M6[2] * uself[2]);
+                const double s1 = S[1] + (M6[1] * uself[0] + M6[3] * uself[1] + M6[4] * uself[2]);
+                const double s2 = S[2] + (M6[2] * uself[0] + M6[4] * uself[1] + M6[5] * uself[2]);
+                const double b0 = B[0] - s0, b1 = B[1] - s1, b2 = B[2] - s2;
+                double ud0, ud1, ud2;
+                if (A.forward) {
+                    ud0 = b0 * D[0];
+                    ud1 = (b1 - D[3] * ud0) * D[1];
+                    ud2 = (b2 - (D[4] * ud0 + D[5] * ud1)) * D[2];
+                } else {
+                    ud2 = b2 * D[2];
+                    ud1 = (b1 - D[5] * ud2) * D[1];
+                    ud0 = (b0 - (D[3] * ud1 + D[4] * ud2)) * D[0];
+                }
+                if (mine) {
+                    const int iself = midoff + ry * ROW_D + 3 * (czn - cshift) + mhc;
+                    sU[iself] = uself[0] + ud0; sU[iself + 1] = uself[1] + ud1; sU[iself + 2] = uself[2] + ud2;
+                }
+            }
+        };
+
         auto phase = [&](auto kc) {
+            if constexpr (FORM == 2) { phase2(kc); return; }
             constexpr int k = decltype(kc)::value, ro = k >> 1;
             constexpr int nrows = R + 1 - ro, ncols = C + 3 - k;
             if (wave >= nrows) return;
@@ -419,7 +545,27 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
             double *dp = A.dst + 3 * (((long long) x * d.NY + y) * d.NZ + z0s);
             for (int i = lane; i < nd_store; i += 64) dp[i] = src[i];
         };
-
+        // two finished rows of a wave (form 2): all LDS reads first, then the stores (3 x 58 doubles per row: three 8-byte pieces per lane)
+        auto store_rows2 = [&](int ry0) {
+            double v[2][3];
+            bool ok[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ry = ry0 + 2 * q, y = yl + ry;
+                ok[q] = ry >= 1 && ry <= 2 * R && y >= 0 && y <= d.NY - 1;
+                const double *src = sU + midoff + (ok[q] ? ry : 1) * ROW_D + 3 * (z0s - k0u) + ((shM + row_par(ok[q] ? ry : 1)) & 1);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) v[q][t] = (ok[q] && lane + 64 * t < nd_store) ? src[lane + 64 * t] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int y = yl + ry0 + 2 * q;
+                double *dp = A.dst + 3 * (((long long) x * d.NY + (ok[q] ? y : 0)) * d.NZ + z0s);
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    if (ok[q] && lane + 64 * t < nd_store) dp[lane + 64 * t] = v[q][t];
+            }
+        };
         // rows of parity P: colours (P,P) then (P,Q); the second reads the first's updates of its own row only, so the two are
         // ordered inside the wave (its LDS accesses execute in order) and need no workgroup barrier
         request(std::integral_constant<int, 1>{}, x);
@@ -430,7 +576,8 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
         phase(std::integral_constant<int, 1>{});
         __builtin_amdgcn_wave_barrier();
         stamp(m, 3);
-        store_row(1 + 2 * wave);
+        if (FORM == 2) store_rows2(1 + 4 * wave);
+        else store_row(1 + 2 * wave);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stamp(m, 4);
         __builtin_amdgcn_s_barrier();                                   // B1: the rows of parity P are final
@@ -442,7 +589,8 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
         if (m + 1 < nsteps) request(std::integral_constant<int, 0>{}, x + 2);
         phase(std::integral_constant<int, 3>{});
         __builtin_amdgcn_wave_barrier();
-        if (wave < R) store_row(2 + 2 * wave);
+        if (FORM == 2) store_rows2(2 + 4 * wave);
+        else if (wave < R) store_row(2 + 2 * wave);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stamp(m, 7);
     }
@@ -503,8 +651,9 @@ void launch_copy_planes(const Dims &d, int par, const double *src, double *dst, 
 // relaxed planes to dst (must differ from uR).  Returns false when the kernel cannot run on these buffers.
 bool launch_gs_march_mf0(const Dims &d, const double *coef36, const double *E, const double *E_alloc_begin, const double *E_alloc_end,
                          const double *uR, const double *uO, double *dst, const double *b, const double *solve_data,
-                         int cxl, int forward, int chunks, hipStream_t s, int plane_lo, int plane_hi) {
+                         int cxl, int forward, int chunks, hipStream_t s, int plane_lo, int plane_hi, const double *tab_form2, int form) {
     using namespace gsm;
+    if (!tab_form2 || form != 2) form = 1;
     if (dst == uR) return false;
     if ((reinterpret_cast<uintptr_t>(uR) & 7u) || (reinterpret_cast<uintptr_t>(uO) & 7u) || (reinterpret_cast<uintptr_t>(E) & 7u)) return false;
     if (d.NX < 2 || d.NY < 2 || d.NZ < 2) return false;
@@ -515,6 +664,7 @@ bool launch_gs_march_mf0(const Dims &d, const double *coef36, const double *E, c
     GsMarchArgs a;
     a.d = d;
     a.coef = coef36;
+    a.tab = tab_form2;
     a.E = E;
     auto first_piece = [](const void *p) { return reinterpret_cast<const char *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t) 15); };
     auto last_piece = [](const void *end) { return reinterpret_cast<const char *>((reinterpret_cast<uintptr_t>(end) - 1) & ~(uintptr_t) 15); };
@@ -538,32 +688,34 @@ bool launch_gs_march_mf0(const Dims &d, const double *coef36, const double *E, c
     if (chunks > M) chunks = M;
     a.steps_per_chunk = (M + chunks - 1) / chunks;
     const unsigned gx = (unsigned) ((M + a.steps_per_chunk - 1) / a.steps_per_chunk);
-    const dim3 grd(gx, (unsigned) ntz, (unsigned) nty), blk(64, CW + 1, 1);
+    const dim3 grd(gx, (unsigned) ntz, (unsigned) nty), blk(64, compute_waves(form) + 1, 1);
     // launch-uniform window parities (see the kernel's comment)
     const long long plane = (long long) d.NY * d.NZ;
     const int ppar = (int) ((3 * plane) & 1), ALT = d.NZ & 1;
     const int bparR = (int) ((reinterpret_cast<uintptr_t>(uR) >> 3) & 1), bparO = (int) ((reinterpret_cast<uintptr_t>(uO) >> 3) & 1);
     const int QF = ((P + 1) + bparO + ((cxl + 1) & ppar) + ALT * P) & 1, QM = ((P + 1) + bparR + (cxl & ppar) + ALT * P) & 1;
-    static bool attr[8] = {false, false, false, false, false, false, false, false};
-#define VFEM_GSM_LAUNCH(A_, F_, M_)                                                                                               \
+    static bool attr[16] = {false};
+#define VFEM_GSM_LAUNCH(A_, F_, M_, V_)                                                                                           \
     do {                                                                                                                          \
-        constexpr int v_ = A_ * 4 + F_ * 2 + M_;                                                                                  \
+        constexpr int v_ = (V_ - 1) * 8 + A_ * 4 + F_ * 2 + M_;                                                                   \
         if (!attr[v_]) {                                                                                                          \
-            VFEM_HIP(hipFuncSetAttribute((const void *) k_gs_march_mf0<A_, F_, M_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES)); \
+            VFEM_HIP(hipFuncSetAttribute((const void *) k_gs_march_mf0<A_, F_, M_, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES)); \
             attr[v_] = true;                                                                                                      \
         }                                                                                                                         \
-        k_gs_march_mf0<A_, F_, M_><<<grd, blk, LDS_BYTES, s>>>(a);                                                              \
+        k_gs_march_mf0<A_, F_, M_, V_><<<grd, blk, LDS_BYTES, s>>>(a);                                                          \
     } while (0)
+#define VFEM_GSM_FORMS(A_, F_, M_) do { if (form == 2) VFEM_GSM_LAUNCH(A_, F_, M_, 2); else VFEM_GSM_LAUNCH(A_, F_, M_, 1); } while (0)
     switch (ALT * 4 + QF * 2 + QM) {
-        case 0: VFEM_GSM_LAUNCH(0, 0, 0); break;
-        case 1: VFEM_GSM_LAUNCH(0, 0, 1); break;
-        case 2: VFEM_GSM_LAUNCH(0, 1, 0); break;
-        case 3: VFEM_GSM_LAUNCH(0, 1, 1); break;
-        case 4: VFEM_GSM_LAUNCH(1, 0, 0); break;
-        case 5: VFEM_GSM_LAUNCH(1, 0, 1); break;
-        case 6: VFEM_GSM_LAUNCH(1, 1, 0); break;
-        default: VFEM_GSM_LAUNCH(1, 1, 1); break;
+        case 0: VFEM_GSM_FORMS(0, 0, 0); break;
+        case 1: VFEM_GSM_FORMS(0, 0, 1); break;
+        case 2: VFEM_GSM_FORMS(0, 1, 0); break;
+        case 3: VFEM_GSM_FORMS(0, 1, 1); break;
+        case 4: VFEM_GSM_FORMS(1, 0, 0); break;
+        case 5: VFEM_GSM_FORMS(1, 0, 1); break;
+        case 6: VFEM_GSM_FORMS(1, 1, 0); break;
+        default: VFEM_GSM_FORMS(1, 1, 1); break;
     }
+#undef VFEM_GSM_FORMS
 #undef VFEM_GSM_LAUNCH
     VFEM_HIP(hipGetLastError());
     return true;

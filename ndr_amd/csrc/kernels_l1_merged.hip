@@ -14,6 +14,7 @@
 #include "vfem_internal.h"
 #include "device_utils.h"
 #include "l1_merged_core.h"
+#include "coef_rows.h"
 
 
 namespace vfem {
@@ -24,44 +25,6 @@ typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
 
 constexpr unsigned OOB = 0x7ffffff0u;                  // beyond any plane (launchers refuse planes of 2^31 bytes or more)
-
-// Coefficient rows (9 doubles per class and neighbour kind) come through the scalar cache one row AHEAD of their use: a wave walks
-// 32 rows, and with the request and the wait in one place (sload12) the ~200-cycle round trip of each is exposed -- more than
-// the ~45 multiply-adds between two rows.  The request for row r + 1 is issued when row r is taken; the two register sets
-// alternate.  A request in flight across asm statements is only safe while the allocator keeps its destination registers
-// (device_utils.h, sload12_issue): this kernel must compile without SGPR spills (checked by the Makefile's resource report and
-// tools/check_sload_pipeline.py).
-template <int OFF>
-__device__ __forceinline__ void srow_issue(const double *p, d8_t &a, double &b) {
-    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4" : "=&s"(a), "=&s"(b) : "s"(p), "n"(OFF), "n"(OFF + 64));
-}
-__device__ __forceinline__ void srow_wait(d8_t &a, double &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
-
-// position of neighbour kind w in the row order of a part: side parts w = 7, 6, 5, 4; the middle part w = 3, 2, 0, 1
-template <bool MID> constexpr int row_pos(int w) { return MID ? (w == 3 ? 0 : w == 2 ? 1 : w == 0 ? 2 : 3) : 7 - w; }
-template <bool MID> constexpr int row_kind(int pos) { return MID ? (pos == 0 ? 3 : pos == 1 ? 2 : pos == 2 ? 0 : 1) : 7 - pos; }
-
-template <bool MID>
-struct DevCoef {
-    const double *tab;
-    d8_t a0, a1;
-    double b0, b1;
-    static constexpr int row_offset(int r) { return ((r / 4) * 8 + row_kind<MID>(r % 4)) * l1m::TAB_ROW * 8; }
-    __device__ __forceinline__ void prime() { srow_issue<row_offset(0)>(tab, a0, b0); }
-    template <int G, int W>
-    __device__ __forceinline__ void get(double c[9]) {
-        constexpr int r = G * 4 + row_pos<MID>(W);
-        if constexpr (r % 2 == 0) {
-            srow_wait(a0, b0);
-            if constexpr (r + 1 < 32) srow_issue<row_offset(r + 1 < 32 ? r + 1 : 0)>(tab, a1, b1);
-            c[0] = a0[0]; c[1] = a0[1]; c[2] = a0[2]; c[3] = a0[3]; c[4] = a0[4]; c[5] = a0[5]; c[6] = a0[6]; c[7] = a0[7]; c[8] = b0;
-        } else {
-            srow_wait(a1, b1);
-            if constexpr (r + 1 < 32) srow_issue<row_offset(r + 1 < 32 ? r + 1 : 0)>(tab, a0, b0);
-            c[0] = a1[0]; c[1] = a1[1]; c[2] = a1[2]; c[3] = a1[3]; c[4] = a1[4]; c[5] = a1[5]; c[6] = a1[6]; c[7] = a1[7]; c[8] = b1;
-        }
-    }
-};
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const double *base, long long plane_doubles, int plane, int planes) {
     const bool ok = plane >= 0 && plane < planes;
@@ -185,19 +148,19 @@ __device__ __forceinline__ void node_group(const Dims &d, const double *__restri
     double S[3] = {0.0, 0.0, 0.0}, M6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     // (a coefficient request in flight must not cross a branch: each role primes its own pipeline inside its branch)
     if (role == 1) {
-        DevCoef<true> cf{tab};
+        DevCoef<true> cf(tab);
 #ifndef L1M_NOCOMP
         cf.prime();
 #endif
         mid_classes<0>(m, un, cf, S, M6);
     } else if (role == 0) {
-        DevCoef<false> cf{tab};
+        DevCoef<false> cf(tab);
 #ifndef L1M_NOCOMP
         cf.prime();
 #endif
         side_classes<0, 0>(m, un, cf, S);
     } else {
-        DevCoef<false> cf{tab};
+        DevCoef<false> cf(tab);
 #ifndef L1M_NOCOMP
         cf.prime();
 #endif

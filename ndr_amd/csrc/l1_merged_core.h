@@ -114,39 +114,55 @@ __host__ __device__ __forceinline__ void side_class(const double (&a)[2][2], con
 // ---- MID part of mirror class G: neighbours (0, o_y, o_z) and the diagonal block; coefficient rows in the order w = 3, 2, 0, 1 ------
 // a0 / a1 [d_y][d_z]: the class's moduli in the fine x-planes below (offset -1 - g_x) and above (offset g_x) the node; un as above
 // for the node's own x-plane (un[1][3..5] = the node itself, not used here)
-template <int G, class Coef>
-__host__ __device__ __forceinline__ void mid_class(const double (&a0)[2][2], const double (&a1)[2][2], const double (&un)[3][9], Coef &coef,
-                                                   double S[3], double M6[6]) {
+// PARTS: bit 0 the four neighbours (0, +-1, +-1), bit 1 (0, +-1, 0), bit 2 the diagonal block, bit 3 (0, 0, +-1) -- all of them
+// (mid_class) or shared between two waves (the level-0 marching sweep: {0, 2} and {1, 2, 3}; the diagonal block then comes out of
+// the same instructions in both, bit for bit)
+template <int G, int PARTS, class Coef>
+__host__ __device__ __forceinline__ void mid_class_parts(const double (&a0)[2][2], const double (&a1)[2][2], const double (&un)[3][9], Coef &coef,
+                                                         double S[3], double M6[6]) {
     const double Sx[2][2] = {{a1[0][0] + a0[0][0], a1[0][1] + a0[0][1]}, {a1[1][0] + a0[1][0], a1[1][1] + a0[1][1]}};
     const double Dx[2][2] = {{a1[0][0] - a0[0][0], a1[0][1] - a0[0][1]}, {a1[1][0] - a0[1][0], a1[1][1] - a0[1][1]}};
     double T[9], c[9];
-    // w = 011
-    coef.template get<G, 3>(c);
-    add_neighbour<true>(T, &un[0][0], Sx[0][0], -Dx[0][0], -Dx[0][0], Sx[0][0]);
-    add_neighbour<false>(T, &un[0][6], Sx[0][1], -Dx[0][1], Dx[0][1], -Sx[0][1]);
-    add_neighbour<false>(T, &un[2][0], Sx[1][0], Dx[1][0], -Dx[1][0], -Sx[1][0]);
-    add_neighbour<false>(T, &un[2][6], Sx[1][1], Dx[1][1], Dx[1][1], Sx[1][1]);
-    fold(S, T, c);
-    // w = 010: merged over x and z
-    const double P[2] = {Sx[0][0] + Sx[0][1], Sx[1][0] + Sx[1][1]}, Q[2] = {Dx[0][0] + Dx[0][1], Dx[1][0] + Dx[1][1]};
-    const double R[2] = {Dx[0][1] - Dx[0][0], Dx[1][1] - Dx[1][0]}, U[2] = {Sx[0][1] - Sx[0][0], Sx[1][1] - Sx[1][0]};
-    coef.template get<G, 2>(c);
-    add_neighbour<true>(T, &un[0][3], P[0], -Q[0], R[0], -U[0]);
-    add_neighbour<false>(T, &un[2][3], P[1], Q[1], R[1], U[1]);
-    fold(S, T, c);
-    // w = 000: the diagonal block, merged over all eight elements (symmetric: M6 = {xx, xy, xz, yy, yz, zz}); before w = 001 so that
-    // P, Q, R, U end here
-    coef.template get<G, 0>(c);
-    const double wd = P[0] + P[1], wxy = Q[1] - Q[0], wxz = R[0] + R[1], wyz = U[1] - U[0];
-    M6[0] = __builtin_fma(c[0], wd, M6[0]);  M6[1] = __builtin_fma(c[1], wxy, M6[1]); M6[2] = __builtin_fma(c[2], wxz, M6[2]);
-    M6[3] = __builtin_fma(c[4], wd, M6[3]);  M6[4] = __builtin_fma(c[5], wyz, M6[4]); M6[5] = __builtin_fma(c[8], wd, M6[5]);
-    // w = 001: merged over x and y
-    const double P2[2] = {Sx[0][0] + Sx[1][0], Sx[0][1] + Sx[1][1]}, Q2[2] = {Dx[1][0] - Dx[0][0], Dx[1][1] - Dx[0][1]};
-    const double R2[2] = {Dx[0][0] + Dx[1][0], Dx[0][1] + Dx[1][1]}, U2[2] = {Sx[1][0] - Sx[0][0], Sx[1][1] - Sx[0][1]};
-    coef.template get<G, 1>(c);
-    add_neighbour<true>(T, &un[1][0], P2[0], Q2[0], -R2[0], -U2[0]);
-    add_neighbour<false>(T, &un[1][6], P2[1], Q2[1], R2[1], U2[1]);
-    fold(S, T, c);
+    if constexpr (PARTS & 1) {                 // w = 011
+        coef.template get<G, 3>(c);
+        add_neighbour<true>(T, &un[0][0], Sx[0][0], -Dx[0][0], -Dx[0][0], Sx[0][0]);
+        add_neighbour<false>(T, &un[0][6], Sx[0][1], -Dx[0][1], Dx[0][1], -Sx[0][1]);
+        add_neighbour<false>(T, &un[2][0], Sx[1][0], Dx[1][0], -Dx[1][0], -Sx[1][0]);
+        add_neighbour<false>(T, &un[2][6], Sx[1][1], Dx[1][1], Dx[1][1], Sx[1][1]);
+        fold(S, T, c);
+    }
+    if constexpr (PARTS & 6) {
+        // merged over x and z
+        const double P[2] = {Sx[0][0] + Sx[0][1], Sx[1][0] + Sx[1][1]}, Q[2] = {Dx[0][0] + Dx[0][1], Dx[1][0] + Dx[1][1]};
+        const double R[2] = {Dx[0][1] - Dx[0][0], Dx[1][1] - Dx[1][0]}, U[2] = {Sx[0][1] - Sx[0][0], Sx[1][1] - Sx[1][0]};
+        if constexpr (PARTS & 2) {             // w = 010
+            coef.template get<G, 2>(c);
+            add_neighbour<true>(T, &un[0][3], P[0], -Q[0], R[0], -U[0]);
+            add_neighbour<false>(T, &un[2][3], P[1], Q[1], R[1], U[1]);
+            fold(S, T, c);
+        }
+        if constexpr (PARTS & 4) {
+            // w = 000: the diagonal block, merged over all eight elements (symmetric: M6 = {xx, xy, xz, yy, yz, zz}); before w = 001 so
+            // that P, Q, R, U end here
+            coef.template get<G, 0>(c);
+            const double wd = P[0] + P[1], wxy = Q[1] - Q[0], wxz = R[0] + R[1], wyz = U[1] - U[0];
+            M6[0] = __builtin_fma(c[0], wd, M6[0]);  M6[1] = __builtin_fma(c[1], wxy, M6[1]); M6[2] = __builtin_fma(c[2], wxz, M6[2]);
+            M6[3] = __builtin_fma(c[4], wd, M6[3]);  M6[4] = __builtin_fma(c[5], wyz, M6[4]); M6[5] = __builtin_fma(c[8], wd, M6[5]);
+        }
+    }
+    if constexpr (PARTS & 8) {                 // w = 001: merged over x and y
+        const double P2[2] = {Sx[0][0] + Sx[1][0], Sx[0][1] + Sx[1][1]}, Q2[2] = {Dx[1][0] - Dx[0][0], Dx[1][1] - Dx[0][1]};
+        const double R2[2] = {Dx[0][0] + Dx[1][0], Dx[0][1] + Dx[1][1]}, U2[2] = {Sx[1][0] - Sx[0][0], Sx[1][1] - Sx[0][1]};
+        coef.template get<G, 1>(c);
+        add_neighbour<true>(T, &un[1][0], P2[0], Q2[0], -R2[0], -U2[0]);
+        add_neighbour<false>(T, &un[1][6], P2[1], Q2[1], R2[1], U2[1]);
+        fold(S, T, c);
+    }
+}
+template <int G, class Coef>
+__host__ __device__ __forceinline__ void mid_class(const double (&a0)[2][2], const double (&a1)[2][2], const double (&un)[3][9], Coef &coef,
+                                                   double S[3], double M6[6]) {
+    mid_class_parts<G, 15>(a0, a1, un, coef, S, M6);
 }
 
 }  // namespace l1m

@@ -88,6 +88,8 @@ struct Tuning {
     int stencil_split = 1;  // stored-stencil levels above the wave-per-node threshold: 27 neighbour blocks shared by three waves (1) or one lane (0)
     int gs_march = 1;       // level 0: plane-resident x-marching half sweeps (kernels_gs_march.hip) where whole colour groups are swept; 0: row kernels
     int gs_march_chunks = 0;   // x-chunks of the marching sweep (0 = default)
+    int gs_march_form = 1;     // marching sweep: 1 a node as two x-mirrored half waves (seven compute waves); 2 one node per lane, the moduli summed per
+                               // neighbour (four compute waves; a quarter fewer operations, the same time: DESIGN 3.2)
     int l1_stored = 0;      // level 1: 0 virtual Galerkin operator (sum_f E_f cK0[f] at every visit), 1 stored 27-point block stencil (1944 B per
                             // node, built once per operator update; measured slower), 2 stored HALF stencil (symmetry: 1008 B per node)
     int l1_merged = 1;      // level 1: node rows evaluated per incident element (k_gs_color_mf1_sym*, k_apply_gather<1>; 0) or per mirror class
@@ -123,7 +125,8 @@ void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const doubl
 // relaxed planes read from uR, the others from uO, results to dst != uR.  false: cannot run on these buffers
 bool launch_gs_march_mf0(const Dims &d, const double *coef36, const double *E, const double *E_alloc_begin, const double *E_alloc_end,
                          const double *uR, const double *uO, double *dst, const double *b, const double *solve_data,
-                         int cxl, int forward, int chunks, hipStream_t s, int plane_lo = 0, int plane_hi = -1);
+                         int cxl, int forward, int chunks, hipStream_t s, int plane_lo = 0, int plane_hi = -1,
+                         const double *tab_form2 = nullptr, int form = 1);     // form 2 needs the neighbour-kind table of K0
 // per node { 1/M00, 1/M11, 1/M22 (0 where the component is fixed), M10, M20, M21 } of the level-0 diagonal blocks M = sum_e E_e K0[n-block]
 void launch_gs_solve_data(const Dims &d, const double *K0, const double *E, const uint8_t *mask, double *sd, hipStream_t s);
 void launch_copy_planes(const Dims &d, int par, const double *src, double *dst, hipStream_t s, int plane_lo = 0, int plane_hi = -1);
@@ -245,6 +248,7 @@ struct vfem_sim {
     double Dm[64];                              // symmetry-reduced (mode-space) coefficients, host
     bool   fast_ok = false;                     // mode-space sparsity pattern verified for this K0
     bool   gs_resident_ok = false;              // the 36-value structure of K0 verified (build_gs_coef)
+    bool k0_mirror_ok = false;                  // K0 commutes with the axis reflections (update_k0)
     vfem::DevBuf<double> dK0, dGsTab, rho, E, dvals, loads;
     vfem::DevBuf<uint8_t> dmask;
     std::vector<uint8_t> hmask;                 // host copy of the Dirichlet mask

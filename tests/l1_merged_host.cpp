@@ -25,7 +25,12 @@ static void all_classes(const double (&E)[4][4][4], const double (&u)[3][3][9], 
     side_class<0, G>(a, u[0], cf, S);
     class_window<G>(E[1 - gx], a0);
     class_window<G>(E[2 + gx], a1);
-    mid_class<G>(a0, a1, u[1], cf, S, M);
+    if (G & 1) mid_class<G>(a0, a1, u[1], cf, S, M);
+    else {                                    // the two shares of the marching sweep's waves: together the whole, the diagonal block once
+        double Mb[6] = {0, 0, 0, 0, 0, 0};
+        mid_class_parts<G, 5>(a0, a1, u[1], cf, S, Mb);
+        mid_class_parts<G, 14>(a0, a1, u[1], cf, S, M);
+    }
     class_window<G>(Es1[gx], a);
     side_class<1, G>(a, u[2], cf, S);
     if constexpr (G + 1 < 8) all_classes<G + 1>(E, u, cf, S, M);

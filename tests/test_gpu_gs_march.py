@@ -9,27 +9,29 @@ import torch
 from helpers import BC_BRIDGE, BC_CANTILEVER, make_hip, make_oracle, seeded_density
 
 pytestmark = pytest.mark.gpu
-GS_MARCH = 19
+GS_MARCH, GS_MARCH_FORM = 19, 23      # form 1: a node as two x-mirrored half waves; 2: one node per lane, moduli summed per neighbour
 
 
 def relerr(a, b):
     return float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max())
 
 
-def _force(t, mode):
+def _force(t, mode, form=1):
     from ndr_amd import _lib
     _lib.check(_lib.load().vfem_sim_set_option(t._h, GS_MARCH, mode))
+    _lib.check(_lib.load().vfem_sim_set_option(t._h, GS_MARCH_FORM, form))
 
 
+@pytest.mark.parametrize("form", [1, 2])
 @pytest.mark.parametrize("ne,bc,dom", [((8, 14, 60), BC_CANTILEVER, ([0, 0, 0], [2, 1, 1])),        # one seam in y and in z
                                        ((6, 26, 118), BC_BRIDGE, ([0, 0, 0], [4, 2, 1])),            # NZ odd / even planes, two seams each way
                                        ((5, 12, 58), BC_CANTILEVER, ([0, 0, 0], [2, 1, 1]))])        # tile edge = grid edge, odd element count in x
-def test_marching_sweep_matches_oracle(ne, bc, dom):
+def test_marching_sweep_matches_oracle(ne, bc, dom, form):
     from oracle import vfem_oracle as vo
     rho = seeded_density(ne, 88, "proxy")
     o = make_oracle(ne, dom, bc, rho)
     t = make_hip(ne, dom, bc, rho)
-    _force(t, 2)
+    _force(t, 2, form)
     omg = vo.OracleMG(o, 0, nthreads=4)
     omg.update_element_stiffness()
     tmg = t.multigridSolver(0)
@@ -47,7 +49,8 @@ def test_marching_sweep_matches_oracle(ne, bc, dom):
         assert np.array_equal(got[fixed], u[fixed])                  # constrained components are not touched (MG.hh:258-262)
 
 
-def test_marching_and_row_kernels_agree_over_sweep_sequences():
+@pytest.mark.parametrize("form", [1, 2])
+def test_marching_and_row_kernels_agree_over_sweep_sequences(form):
     """forward / backward sweeps in sequence (the scratch vector ping-pong: even counts end in place, odd ones copy back), and the
     colour groups one by one as the slab solver calls them (vfem_mg_smooth_colors)"""
     import ctypes
@@ -62,7 +65,7 @@ def test_marching_and_row_kernels_agree_over_sweep_sequences():
     b = torch.randn((mg._nn(0), 3), dtype=torch.float64, device="cuda", generator=g)
     out = {}
     for mode in (0, 2):
-        _force(t, mode)
+        _force(t, mode, form)
         res = []
         for fwd, sweeps in ((1, 1), (0, 1), (1, 2), (0, 3)):
             x = u.clone()
