@@ -131,7 +131,8 @@ __global__ void __launch_bounds__(256) k_chol_diag(long long Np, int k, double *
         const double lcj = col[buf][c] * inv;          // L[c][j] (used where c > j)
         const double xjc = row[buf][c] * inv;          // X[j][c] (used where c <= j)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {                 // (selects, no branches: the conditions differ from lane to lane)
+        for (int q = 0; q < 16; ++q) {                 // (selects, no lane-dependent branches: the conditions differ from lane to lane)
+            if (4 * q + 3 < j) continue;               // all four rows of this slot lie above the pivot row: finished (uniform over the workgroup)
             const int r = r0 + 4 * q;
             const double lrj = col[buf][r] * inv;      // L[r][j]
             const double an = (c > j && c <= r) ? fma(-lrj, lcj, a[q]) : (c == j ? lrj : a[q]);
