@@ -88,8 +88,8 @@ struct Tuning {
     int stencil_split = 1;  // stored-stencil levels above the wave-per-node threshold: 27 neighbour blocks shared by three waves (1) or one lane (0)
     int gs_march = 1;       // level 0: plane-resident x-marching half sweeps (kernels_gs_march.hip) where whole colour groups are swept; 0: row kernels
     int gs_march_chunks = 0;   // x-chunks of the marching sweep (0 = default)
-    int gs_march_form = 1;     // marching sweep: 1 a node as two x-mirrored half waves (seven compute waves); 2 one node per lane, the moduli summed per
-                               // neighbour (four compute waves; a quarter fewer operations, the same time: DESIGN 3.2)
+    int gs_march_form = 2;     // marching sweep: 1 a node as two x-mirrored half waves (seven compute waves); 2 one node per lane, the moduli summed per
+                               // neighbour (four compute waves; a quarter fewer operations, 4 % faster: DESIGN 3.2)
     int l1_stored = 0;      // level 1: 0 virtual Galerkin operator (sum_f E_f cK0[f] at every visit), 1 stored 27-point block stencil (1944 B per
                             // node, built once per operator update; measured slower), 2 stored HALF stencil (symmetry: 1008 B per node)
     int l1_merged = 1;      // level 1: node rows evaluated per incident element (k_gs_color_mf1_sym*, k_apply_gather<1>; 0) or per mirror class
