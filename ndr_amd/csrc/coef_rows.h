@@ -79,13 +79,24 @@ struct DevCoef {                      // the `Coef` of l1m::side_class / mid_cla
 struct L0NodeRows {
     static constexpr int at(int r) { return (r < 4 ? 7 - r : r < 8 ? row_kind<true>(r - 4) : 7 - (r - 8)) * l1m::TAB_ROW * 8; }
 };
-template <bool MID, int BASE>
-struct L0Coef {                       // adapter of one part onto the node's pipeline; tie: the accumulator the rows' arithmetic chains through
+// adapter of one part onto the node's pipeline; tie: the accumulator the rows' arithmetic chains through; after_first: called right
+// behind the wait for the part's first row -- the place to issue LDS reads that must not be drained by a row wait (LDS and scalar
+// loads share one counter, and a scalar load can only be awaited with lgkmcnt(0): whatever LDS read is in flight at a row wait is
+// waited for as well)
+template <bool MID, int BASE, class Hook>
+struct L0Coef {
     RowPipe<12, L0NodeRows> &pipe;
     double &tie;
+    Hook after_first;
     template <int G, int W>
-    __device__ __forceinline__ void get(double c[9]) { static_assert(G == 0, "level 0 has one class"); pipe.template take<BASE + row_pos<MID>(W)>(c, tie); }
+    __device__ __forceinline__ void get(double c[9]) {
+        static_assert(G == 0, "level 0 has one class");
+        pipe.template take<BASE + row_pos<MID>(W)>(c, tie);
+        if constexpr (row_pos<MID>(W) == 0) after_first();
+    }
 };
+template <bool MID, int BASE, class Hook>
+__device__ __forceinline__ L0Coef<MID, BASE, Hook> l0_coef(RowPipe<12, L0NodeRows> &pipe, double &tie, Hook hook) { return L0Coef<MID, BASE, Hook>{pipe, tie, hook}; }
 
 
 }  // namespace vfem

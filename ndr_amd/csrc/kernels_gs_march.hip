@@ -346,21 +346,26 @@ __global__ void __launch_bounds__(64 * (gsm::compute_waves(FORM) + 1)) k_gs_marc
             asm volatile("" : "+v"(S[0]) : "v"(a0[0][0]));               // (the chain of row waits starts behind the moduli reads)
             rows.prime();
             __builtin_amdgcn_sched_barrier(0);
-            window(midoff, mhc, mhs, std::integral_constant<int, OMC>{}, std::integral_constant<int, OMS>{}, unB);
+            // the next plane's windows are requested right BEHIND the wait for a part's first coefficient row: a row wait is
+            // lgkmcnt(0) and would drain them (requested in front of it, every part paid the full LDS latency: waves 44 % of their
+            // time in s_waitcnt, gpurun_out/r03_gsm_pmc3)
             {
-                L0Coef<false, 0> cf{rows, S[0]};
+                auto cf = l0_coef<false, 0>(rows, S[0], [&] {
+                    window(midoff, mhc, mhs, std::integral_constant<int, OMC>{}, std::integral_constant<int, OMS>{}, unB);
+                });
                 l1m::side_class<0, 0>(a0, unA, cf, S);
             }
             __builtin_amdgcn_sched_barrier(0);
-            window(highoff, shc, shs, std::integral_constant<int, OFC>{}, std::integral_constant<int, OFS>{}, unA);
             {
-                L0Coef<true, 4> cf{rows, S[0]};
-                l1m::mid_class<0>(a0, a1, unB, cf, S, M6);
                 uself[0] = unB[1][3]; uself[1] = unB[1][4]; uself[2] = unB[1][5];
+                auto cf = l0_coef<true, 4>(rows, S[0], [&] {
+                    window(highoff, shc, shs, std::integral_constant<int, OFC>{}, std::integral_constant<int, OFS>{}, unA);
+                });
+                l1m::mid_class<0>(a0, a1, unB, cf, S, M6);
             }
             __builtin_amdgcn_sched_barrier(0);
             {
-                L0Coef<false, 8> cf{rows, S[0]};
+                auto cf = l0_coef<false, 8>(rows, S[0], [] {});
                 l1m::side_class<1, 0>(a1, unA, cf, S);
             }
             __builtin_amdgcn_sched_barrier(0);
