@@ -12,7 +12,7 @@ echo "== bench under rocprofv3 --kernel-trace --stats"
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_bench_prof -- python3 $R/bench.py > $O/${TAG}_bench_profiled.json 2> $O/${TAG}_bench_profiled.err )
 f=$(find $O/${TAG}_bench_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_bench_kernel_stats.csv
 echo "== apply traffic (PMC)"; bash tools/fetch_size.sh $O/${TAG}_apply_pmc k_apply_dma python3 tools/apply_only.py 512 6
-echo "== marching sweep traffic (PMC)"; bash tools/fetch_size.sh $O/${TAG}_gsm_pmc k_gs_march python3 tools/gs_march_only.py 512
+echo "== marching sweep traffic (PMC)"; bash tools/fetch_size.sh $O/${TAG}_gsm_pmc k_gs_march python3 tools/gs_march_only.py 512 2
 echo "== level-1 sweep traffic (PMC)"; bash tools/fetch_size.sh $O/${TAG}_l1m_pmc k_l1_merged python3 tools/l1_sweep_only.py 512 1 4
 for n in 512 256; do
   lv=6; [ $n = 256 ] && lv=5
