@@ -99,24 +99,30 @@ def test_region_parser_matches_reference_semantics(tmp_path):
         _parse_regions(str(bad))
 
 
-def test_pipelined_scalar_loads_are_hazard_free(tmp_path):
-    """k_apply_q2_march leaves scalar loads in flight across compiler-generated code (sload12_issue / sload12_wait); that is
-    only safe while no instruction touches the destination SGPRs before the wait.  Compile the kernel to ISA (cross-compile,
-    no GPU needed) and scan it."""
+@pytest.mark.parametrize("source,kernels,windows", [
+    ("kernels_q2.hip", ["k_apply_q2_marchILi0"], 84),
+    ("kernels_l1_merged.hip", ["k_l1_mergedILi0E", "k_l1_mergedILi1E", "k_l1_mergedILi2E"], None),
+    ("kernels_gs_march.hip", ["k_gs_march_mf0ILi1ELi1ELi0ELi2E", "k_gs_march_mf0ILi0ELi0ELi1ELi2E"], None)])
+def test_pipelined_scalar_loads_are_hazard_free(tmp_path, source, kernels, windows):
+    """k_apply_q2_march (sload12_issue / sload12_wait), the level-1 per-class kernels and the node-per-lane marching sweep (coef_rows.h:
+    srow_issue / srow_wait) leave scalar loads in flight across compiler-generated code; that is only safe while no instruction
+    touches the destination SGPRs before the wait.  Compile the kernels to ISA (cross-compile, no GPU needed) and scan them."""
     import shutil
     import subprocess
     import sys
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    src = os.path.join(ROOT, "ndr_amd", "csrc", "kernels_q2.hip")
-    asm = str(tmp_path / "q2.s")
+    src = os.path.join(ROOT, "ndr_amd", "csrc", source)
+    asm = str(tmp_path / "k.s")
     subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=on", "-S", "--cuda-device-only",
                            src, "-o", asm], stderr=subprocess.DEVNULL)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_sload_pipeline.py"), asm, "k_apply_q2_marchILi0"],
-                         capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout
-    assert " 0 violations" in out.stdout and "84 request..wait windows" in out.stdout, out.stdout
+    for k in kernels:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_sload_pipeline.py"), asm, k], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout
+        assert " 0 violations" in out.stdout and " 0 request..wait windows" not in out.stdout, out.stdout
+        if windows is not None:
+            assert "%d request..wait windows" % windows in out.stdout, out.stdout
 
 
 def test_host_helpers_of_getk_constant_strain_load_read_densities(tmp_path):
