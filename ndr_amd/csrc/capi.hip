@@ -254,20 +254,22 @@ static bool gs_march_wanted(const MgLevel &L, const Tuning &t) {
     return t.gs_march == 2 || (t.gs_march == 1 && L.d.nn >= 12000000);
 }
 
-// level 0: solve data of the marching sweeps, recomputed when the moduli (or the material / Dirichlet mask: both bump the version) changed
-static void gs_solve_data(vfem_mg *mg, hipStream_t s) {
-    MgLevel &L = mg->lv[0];
-    const vfem_sim *sim = mg->fine;
-    if (L.gs_sd.p && L.gs_sd_version == sim->operator_version) return;
-    L.gs_sd.reserve((size_t) L.d.nn * 6);
-    launch_gs_solve_data(L.d, sim->dK0.p, level_E(mg, 0), L.maskp, L.gs_sd.p, s);
-    L.gs_sd_version = sim->operator_version;
-}
-
 // the marching sweep's form: one node per lane (the neighbour-kind table of K0) when K0 has the mirror symmetry it needs, else
 // (or by VFEM_OPT_GS_MARCH_FORM = 1) the mirrored half waves
 static const double *march_form2_table(const vfem_sim *sim) {
     return (sim->tune.gs_march_form == 2 && sim->k0_mirror_ok) ? sim->dGsTab.p + GS_TABLE_DOUBLES + 84 : nullptr;
+}
+
+// level 0: solve data of the marching sweeps, recomputed when the moduli (or the material / Dirichlet mask: both bump the version) changed
+static void gs_solve_data(vfem_mg *mg, hipStream_t s) {
+    MgLevel &L = mg->lv[0];
+    const vfem_sim *sim = mg->fine;
+    const int per = march_form2_table(sim) ? 3 : 6;
+    if (L.gs_sd.p && L.gs_sd_version == sim->operator_version && L.gs_sd_per == per) return;
+    L.gs_sd.reserve((size_t) L.d.nn * 6);
+    launch_gs_solve_data(L.d, sim->dK0.p, level_E(mg, 0), L.maskp, L.gs_sd.p, s, per);
+    L.gs_sd_version = sim->operator_version;
+    L.gs_sd_per = per;
 }
 
 // n consecutive sweeps of level l in one direction.  Level 0 runs them as marching half sweeps (kernels_gs_march.hip) when

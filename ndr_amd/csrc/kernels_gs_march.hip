@@ -64,7 +64,8 @@ struct GsMarchArgs {
     const char *uR_first, *uR_last, *uO_first, *uO_last;
     double *dst;                   // receives the relaxed planes (other planes untouched)
     const double *b;
-    const double *sd;              // solve data per node (k_gs_solve_data): inverse diagonal (mask folded in), strict lower part of the diagonal block
+    const double *sd;              // solve data per node (k_gs_solve_data): inverse diagonal (mask folded in) [+ strict lower part of the diagonal block:
+                                   // 6 doubles per node in form 1, 3 in form 2]
     int cxl;                       // local x parity of the relaxed planes
     int forward;                   // component order of the 3x3 solve (MG.hh:254-264)
     int steps_per_chunk;           // relaxed planes per block
@@ -73,6 +74,9 @@ struct GsMarchArgs {
 };
 
 typedef double d2a_t __attribute__((ext_vector_type(2), aligned(16)));
+typedef unsigned int u4q_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u2q_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double mkd(unsigned lo, unsigned hi) { return __longlong_as_double(((unsigned long long) hi << 32) | lo); }
 
 
 __device__ __forceinline__ void gsm_glds16(const void *g, void *l) {
@@ -295,16 +299,19 @@ __global__ void __launch_bounds__(64 * (gsm::compute_waves(FORM) + 1)) k_gs_marc
             const int czn = 1 + k + 2 * ce;
             const int z = zl + czn;
             const bool mine = rw < nrows && cl < ncols && y >= 0 && y < d.NY && z >= 0 && z < d.NZ;
-            // right-hand side and solve data of the node: requested now, used after the ~400 operations below (clamped node for the lanes
-            // that relax nothing: no branch, the values are not used)
-            double B[3], D[6];
+            // right-hand side and inverse diagonal of the node (the rest of the diagonal block is formed below): requested now, used after
+            // the ~400 operations of the colour.  Buffer loads on the relaxed plane: lanes that relax nothing (tile halo, shadow rows) get an
+            // out-of-range offset and move no data -- the sweep is close enough to the HBM rate (14 GB per half sweep at 512^3 in 3.7 ms,
+            // block lives of 180 us for ten 9.5 us steps of arithmetic) for 72 bytes per idle lane to matter
+            double B[3], D[3];
             {
-                const int yc = min(max(y, 0), d.NY - 1), zc = min(max(z, 0), d.NZ - 1);
-                const long long n = ((long long) x * d.NY + yc) * d.NZ + zc;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) B[q] = A.b[3 * n + q];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) D[q] = A.sd[6 * n + q];
+                const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(A.b + 3LL * x * plane), 0, (int) (24 * plane), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(A.sd + 3LL * x * plane), 0, (int) (24 * plane), 0x00020000);
+                const unsigned off = mine ? (unsigned) (y * d.NZ + z) * 24u : 0x7ffffff0u;
+                const u4q_t vb = __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, 0), vd = __builtin_amdgcn_raw_buffer_load_b128(rd, off, 0, 0);
+                const u2q_t wb = __builtin_amdgcn_raw_buffer_load_b64(rb, off + 16, 0, 0), wd = __builtin_amdgcn_raw_buffer_load_b64(rd, off + 16, 0, 0);
+                B[0] = mkd(vb.x, vb.y); B[1] = mkd(vb.z, vb.w); B[2] = mkd(wb.x, wb.y);
+                D[0] = mkd(vd.x, vd.y); D[1] = mkd(vd.z, vd.w); D[2] = mkd(wd.x, wd.y);
             }
             int ni = czn - 1 - cshift;
             ni = max(ni, ni & 1);
@@ -371,7 +378,7 @@ __global__ void __launch_bounds__(64 * (gsm::compute_waves(FORM) + 1)) k_gs_marc
             __builtin_amdgcn_sched_barrier(0);
             {
                 // residual form of m_smoothNode (MG.hh:199-264): S also takes the node's own block; component-sequential solve with the
-                // stored inverse diagonal (0 for a fixed component) and the stored strict lower part (D: i00 i11 i22 m10 m20 m21)
+                // stored inverse diagonal (0 for a fixed component) and the strict lower part of the block just formed (M6: xx xy xz yy yz zz)
                 const double s0 = S[0] + (M6[0] * uself[0] + M6[1] * uself[1] + M6[2] * uself[2]);
                 const double s1 = S[1] + (M6[1] * uself[0] + M6[3] * uself[1] + M6[4] * uself[2]);
                 const double s2 = S[2] + (M6[2] * uself[0] + M6[4] * uself[1] + M6[5] * uself[2]);
@@ -379,12 +386,12 @@ __global__ void __launch_bounds__(64 * (gsm::compute_waves(FORM) + 1)) k_gs_marc
                 double ud0, ud1, ud2;
                 if (A.forward) {
                     ud0 = b0 * D[0];
-                    ud1 = (b1 - D[3] * ud0) * D[1];
-                    ud2 = (b2 - (D[4] * ud0 + D[5] * ud1)) * D[2];
+                    ud1 = (b1 - M6[1] * ud0) * D[1];
+                    ud2 = (b2 - (M6[2] * ud0 + M6[4] * ud1)) * D[2];
                 } else {
                     ud2 = b2 * D[2];
-                    ud1 = (b1 - D[5] * ud2) * D[1];
-                    ud0 = (b0 - (D[3] * ud1 + D[4] * ud2)) * D[0];
+                    ud1 = (b1 - M6[4] * ud2) * D[1];
+                    ud0 = (b0 - (M6[1] * ud1 + M6[2] * ud2)) * D[0];
                 }
                 if (mine) {
                     const int iself = midoff + ry * ROW_D + 3 * (czn - cshift) + mhc;
@@ -603,8 +610,9 @@ __global__ void __launch_bounds__(64 * (gsm::compute_waves(FORM) + 1)) k_gs_marc
 // Solve data of the level-0 sweeps, once per operator update: per node the inverse diagonal of its 3x3 diagonal block
 // M = sum_e E_e K0[n-block] (MG.hh:199-220) with the Dirichlet mask folded in (0 for a fixed component, MG.hh:258-262) and the
 // strict lower part of M (it is symmetric): sd[n] = { 1/M00, 1/M11, 1/M22, M10, M20, M21 }
+// (per = 3: the inverse diagonal only -- form 2 of the marching sweep forms the diagonal block itself)
 __global__ void __launch_bounds__(256) k_gs_solve_data(Dims d, const double *__restrict__ K0, const double *__restrict__ E,
-                                                       const uint8_t *__restrict__ mask, double *__restrict__ sd) {
+                                                       const uint8_t *__restrict__ mask, double *__restrict__ sd, int per) {
     const long long n = (long long) blockIdx.x * 256 + threadIdx.x;
     if (n >= d.nn) return;
     const int k = (int) (n % d.NZ), j = (int) ((n / d.NZ) % d.NY), i = (int) (n / ((long long) d.NZ * d.NY));
@@ -619,13 +627,13 @@ __global__ void __launch_bounds__(256) k_gs_solve_data(Dims d, const double *__r
         M[3] = fma(Ee, blk[24], M[3]); M[4] = fma(Ee, blk[48], M[4]); M[5] = fma(Ee, blk[48 + 1], M[5]);
     }
     const uint8_t mk = mask[n];
-    sd[6 * n + 0] = (mk & 1) ? 0.0 : 1.0 / M[0];
-    sd[6 * n + 1] = (mk & 2) ? 0.0 : 1.0 / M[1];
-    sd[6 * n + 2] = (mk & 4) ? 0.0 : 1.0 / M[2];
-    sd[6 * n + 3] = M[3]; sd[6 * n + 4] = M[4]; sd[6 * n + 5] = M[5];
+    sd[per * n + 0] = (mk & 1) ? 0.0 : 1.0 / M[0];
+    sd[per * n + 1] = (mk & 2) ? 0.0 : 1.0 / M[1];
+    sd[per * n + 2] = (mk & 4) ? 0.0 : 1.0 / M[2];
+    if (per == 6) { sd[6 * n + 3] = M[3]; sd[6 * n + 4] = M[4]; sd[6 * n + 5] = M[5]; }
 }
-void launch_gs_solve_data(const Dims &d, const double *K0, const double *E, const uint8_t *mask, double *sd, hipStream_t s) {
-    k_gs_solve_data<<<dim3((unsigned) ((d.nn + 255) / 256)), 256, 0, s>>>(d, K0, E, mask, sd);
+void launch_gs_solve_data(const Dims &d, const double *K0, const double *E, const uint8_t *mask, double *sd, hipStream_t s, int per) {
+    k_gs_solve_data<<<dim3((unsigned) ((d.nn + 255) / 256)), 256, 0, s>>>(d, K0, E, mask, sd, per);
     VFEM_HIP(hipGetLastError());
 }
 

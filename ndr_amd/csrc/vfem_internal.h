@@ -128,7 +128,7 @@ bool launch_gs_march_mf0(const Dims &d, const double *coef36, const double *E, c
                          int cxl, int forward, int chunks, hipStream_t s, int plane_lo = 0, int plane_hi = -1,
                          const double *tab_form2 = nullptr, int form = 1);     // form 2 needs the neighbour-kind table of K0
 // per node { 1/M00, 1/M11, 1/M22 (0 where the component is fixed), M10, M20, M21 } of the level-0 diagonal blocks M = sum_e E_e K0[n-block]
-void launch_gs_solve_data(const Dims &d, const double *K0, const double *E, const uint8_t *mask, double *sd, hipStream_t s);
+void launch_gs_solve_data(const Dims &d, const double *K0, const double *E, const uint8_t *mask, double *sd, hipStream_t s, int per = 6);
 void launch_copy_planes(const Dims &d, int par, const double *src, double *dst, hipStream_t s, int plane_lo = 0, int plane_hi = -1);
 extern long long *g_gsm_stamps;         // diagnostic stamps of the marching kernel (tools/gs_march_stamps.py), null in production
 // level 1: diagonal 3x3 blocks of the virtual Galerkin operator, [nn][9] (once per operator update)
@@ -284,6 +284,7 @@ struct MgLevel {
     vfem::DevBuf<double> tmp;                   // level 0: second copy of the field for the out-of-place marching half sweeps
     vfem::DevBuf<double> gs_sd;                 // level 0: solve data of the marching sweeps [nn][6] (launch_gs_solve_data)
     long long gs_sd_version = 0;                // fine->operator_version gs_sd was computed for
+    int gs_sd_per = 0;                          // doubles per node in gs_sd: 6 (marching form 1) or 3 (form 2)
 };
 
 struct vfem_mg {
