@@ -65,8 +65,9 @@ enum {
     VFEM_OPT_GS_MARCH_CHUNKS = 20, /* x-chunks of the marching sweep (0 = default) */
     VFEM_OPT_L1_STORED    = 21,  /* level 1 (degree 1): operator evaluated on the fly from the child moduli (0), stored as a 27-point block stencil, 1944 B
                                     per node (1), or stored as half of it using the symmetry, 1008 B per node (2); DESIGN section 3.2 */
-    VFEM_OPT_L1_MERGED    = 22,  /* level 1 (degree 1), operator evaluated on the fly: node rows summed per mirror class of the child matrices by three
-                                    waves per node (1, default) or per incident element (0); the two agree to rounding */
+    VFEM_OPT_L1_MERGED    = 22,  /* level 1 (degree 1), operator evaluated on the fly: node rows summed per incident element (0), per mirror class of the
+                                    child matrices by three waves per node (1), or per class with the two z colours of a row relaxed by one launch (2,
+                                    default: the result of 1 bit for bit, half the moduli traffic); 0 and 1 agree to rounding */
     VFEM_OPT_Q2_GS_IMPL   = 16,  /* vfem_gsim: finest-level degree-2 sweep 0 element by element, 1 neighbour node by neighbour node, 2 the same with
                                     the neighbour rows staged through LDS by coalesced loads (default) */
     VFEM_OPT_TRANSFER_AXIS = 17, /* vfem_gsim: restriction / interpolation of 3-D levels above 100 k nodes axis by axis (1, default) or in one pass (0) */

@@ -242,7 +242,8 @@ static void mg_smooth(vfem_mg *mg, int l, double *u, const double *b, int forwar
     MgLevel &L = mg->lv[l];
     if (level_uses_half_stencil(mg, l)) launch_gs_sweep_stencil_half(L.d, L.Sh.p, u, b, L.maskp, forward, L.xparity, first, count, s);
     else if (level_uses_stencil(mg, l)) launch_gs_sweep_stencil(L.d, L.S.p, u, b, L.maskp, forward, L.xparity, first, count, s, L.Sn.p, mg->fine->tune.stencil_split);
-    else if (level_uses_merged_rows(mg, l)) launch_l1_merged_sweep(L.d, mg->l1mtab.p, level_E(mg, l), u, b, L.maskp, forward, L.xparity, first, count, s);
+    else if (level_uses_merged_rows(mg, l)) launch_l1_merged_sweep(L.d, mg->l1mtab.p, level_E(mg, l), u, b, L.maskp, forward, L.xparity, first, count, s,
+                                                                   mg->fine->tune.l1_merged == 2);
     else launch_gs_sweep_mf(L.d, L.kind, level_K(mg, l), l == 0 ? mg->fine->dGsTab.p : mg->mf1diag.p, level_E(mg, l), u, b, L.maskp,
                             forward, L.xparity, first, count, s, mg->fine->tune, mg->mf1_sym,
                             (l == 1 && mg->fine->tune.l1_diag) ? L.Mdiag.p : nullptr);
@@ -555,7 +556,7 @@ int vfem_sim_set_option(vfem_sim *sim, int key, int value) {
         case VFEM_OPT_GS_MARCH_FORM: if (value != 1 && value != 2) throw Error("marching sweep form 1 or 2"); t.gs_march_form = value; break;
         case VFEM_OPT_GS_MARCH_CHUNKS: if (value < 0) throw Error("negative chunk count"); t.gs_march_chunks = value; break;
         case VFEM_OPT_L1_STORED:     if (value < 0 || value > 2) throw Error("level-1 storage mode 0..2"); t.l1_stored = value; ++sim->operator_version; break;
-        case VFEM_OPT_L1_MERGED:     t.l1_merged = value != 0; break;
+        case VFEM_OPT_L1_MERGED:     if (value < 0 || value > 2) throw Error("level-1 row mode 0..2"); t.l1_merged = value; break;
         case VFEM_OPT_L1_DIAG:       t.l1_diag = value != 0; ++sim->operator_version; break;   // hierarchies (re)build the blocks
         default: throw Error("unknown simulator option " + std::to_string(key));
     }

@@ -92,8 +92,9 @@ struct Tuning {
                                // neighbour (four compute waves; a quarter fewer operations, 4 % faster: DESIGN 3.2)
     int l1_stored = 0;      // level 1: 0 virtual Galerkin operator (sum_f E_f cK0[f] at every visit), 1 stored 27-point block stencil (1944 B per
                             // node, built once per operator update; measured slower), 2 stored HALF stencil (symmetry: 1008 B per node)
-    int l1_merged = 1;      // level 1: node rows evaluated per incident element (k_gs_color_mf1_sym*, k_apply_gather<1>; 0) or per mirror class
-                            // by three waves per node (kernels_l1_merged.hip; 1)
+    int l1_merged = 2;      // level 1: node rows evaluated per incident element (k_gs_color_mf1_sym*, k_apply_gather<1>; 0), per mirror class by
+                            // three waves per node (kernels_l1_merged.hip; 1), the same with the two z colours of a row in one launch (2: the
+                            // second colour finds the moduli in L2; bit for bit the result of 1)
     int l1_diag = 0;        // level 1: diagonal blocks precomputed once per operator update instead of inside every sweep (measured
                             // 3 % SLOWER at 512^3, profiles/r02_gs_experiments.json: the sweep is not bound by its arithmetic)
 };
@@ -143,7 +144,7 @@ constexpr int L1M_TABLE_DOUBLES = 8 * 8 * 12;
 void build_l1_merged_table(const double *cK0_0, double *tab /* L1M_TABLE_DOUBLES */);
 bool l1_merged_usable(const Dims &d);
 void launch_l1_merged_sweep(const Dims &d, const double *tab, const double *E, double *u, const double *b, const uint8_t *mask,
-                            int forward, int xparity, int first, int count, hipStream_t s);
+                            int forward, int xparity, int first, int count, hipStream_t s, int pair = 1);
 void launch_l1_merged_apply(const Dims &d, const double *tab, const double *E, const double *u, const double *b, const uint8_t *mask,
                             int res, double *out, hipStream_t s);
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,

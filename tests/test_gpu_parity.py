@@ -160,10 +160,10 @@ def test_sweep_kernel_choices_agree():
                   torch.randn((mg._nn(l), 3), dtype=torch.float64, device="cuda", generator=g)) for l in (1, 2)}
     ref = {}
     # key 21 (VFEM_OPT_L1_STORED): level 1 evaluated on the fly (0), stored as a 27-point stencil (1), as half of it by symmetry (2)
-    # key 22 (VFEM_OPT_L1_MERGED): level-1 node rows summed per mirror class (1) or per incident element (0); the slot sharing of
-    # key 15 belongs to the per-element kernels
+    # key 22 (VFEM_OPT_L1_MERGED): level-1 node rows summed per incident element (0), per mirror class (1), per class with the two z
+    # colours of a row in one launch (2); the slot sharing of key 15 belongs to the per-element kernels
     _lib.check(lib.vfem_sim_set_option(t._h, 22, 0))
-    for key, values, level in ((15, (1, 2, 4, 8), 1), (22, (0, 1), 1), (21, (0, 1, 2), 1), (18, (0, 1), 2)):
+    for key, values, level in ((15, (1, 2, 4, 8), 1), (22, (0, 1, 2), 1), (21, (0, 1, 2), 1), (18, (0, 1), 2)):
         for v in values:
             _lib.check(lib.vfem_sim_set_option(t._h, key, v))
             if key == 21:
@@ -172,7 +172,7 @@ def test_sweep_kernel_choices_agree():
                 got = mg.smoothing_device(level, fields[level][0], fields[level][1], fwd)
                 r = ref.setdefault((key, fwd), got)
                 assert float((got - r).abs().max()) < 1e-12 * float(r.abs().max()), (key, v, fwd)
-        _lib.check(lib.vfem_sim_set_option(t._h, key, {15: 4, 18: 1, 21: 0, 22: 1}[key]))
+        _lib.check(lib.vfem_sim_set_option(t._h, key, {15: 4, 18: 1, 21: 0, 22: 2}[key]))
     with pytest.raises(RuntimeError):
         _lib.check(lib.vfem_sim_set_option(t._h, 15, 3))
 

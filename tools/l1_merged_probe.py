@@ -14,7 +14,7 @@ args = sys.argv[1:]
 
 def both(tps, mg, u, b, what):
     out = {}
-    for merged in (0, 1):
+    for merged in (0, 1, 2):
         _lib.check(lib.vfem_sim_set_option(tps._h, 22, merged))
         if what == "residual":
             r = torch.empty_like(u)
@@ -43,7 +43,8 @@ if "check" in args:
             o = both(tps, mg, u, b, what)
             err = float((o[0] - o[1]).abs().max() / o[0].abs().max())
             worst = max(worst, err)
-            print("grid %s level-1 %s: relative max difference %.2e" % (ne, what, err), flush=True)
+            assert float((o[1] - o[2]).abs().max()) == 0.0, "the z-pair launch must reproduce the two colour launches bit for bit"
+            print("grid %s level-1 %s: relative max difference %.2e (z pairs = colour by colour bit for bit)" % (ne, what, err), flush=True)
     print("worst %.2e" % worst)
     assert worst < 1e-12
 
@@ -56,7 +57,7 @@ for n in [int(a) for a in args]:
     nn = mg._nn(1)
     u = torch.randn((nn, 3), dtype=torch.float64, device="cuda", generator=g)
     b = torch.randn((nn, 3), dtype=torch.float64, device="cuda", generator=g)
-    for merged in (0, 1):
+    for merged in (0, 1, 2):
         _lib.check(lib.vfem_sim_set_option(tps._h, 22, merged))
         x, r = u.clone(), torch.empty_like(u)
         _lib.check(lib.vfem_mg_smooth(mg._h, 1, _ptr(x), _ptr(b), 1, _stream()))
@@ -73,6 +74,6 @@ for n in [int(a) for a in args]:
             _lib.check(lib.vfem_mg_residual(mg._h, 1, _ptr(u), _ptr(b), _ptr(r), _stream()))
         torch.cuda.synchronize()
         t_res = (time.perf_counter() - t0) / 4
-        print("n %d level 1 (%d nodes) %-11s: sweep %.3f ms, residual %.3f ms" % (n, nn, ("per element", "per class")[merged], best * 1e3, t_res * 1e3), flush=True)
+        print("n %d level 1 (%d nodes) %-11s: sweep %.3f ms, residual %.3f ms" % (n, nn, ("per element", "per class", "per class, z pairs")[merged], best * 1e3, t_res * 1e3), flush=True)
     del tps, mg, u, b
     torch.cuda.empty_cache()
