@@ -1290,9 +1290,89 @@ __global__ void __launch_bounds__(256) k_stencil_build(Dims d, const double *__r
     for (int q = 0; q < 9; ++q) St[sbase + ((long long) nb * 9 + q) * scnt] = A[q];
 }
 
+// The same stencil from stored element matrices, one workgroup per 64-node tile of the colour-major storage.  k_stencil_build<2>
+// gives a thread one (node, neighbour) pair: its nine reads per incident element are 8 bytes out of lines 4.6 KB apart from the next
+// lane's, and the other neighbours of the node -- the rest of those lines -- are visited by launches-worth of other threads much
+// later: 12.6 ms for the 129^3 level (9.7 GB of element matrices, 4.2 GB of stencil).  Here the rows of a node in one incident
+// element are read as what they are, 72 contiguous doubles (K_e[3 ln .. 3 ln + 2][0 .. 23]), by 72 consecutive threads, summed
+// into the tile image in LDS (243 x 64 doubles: the storage layout itself) element by element in the old order -- bit for bit the
+// same stencil -- and the tile leaves as one contiguous 124 KB block.
+struct TileStarts { int v[9]; };
+constexpr int ST_LD = 65;            // LDS row length of the tile image (64 + 1: the 72 entries of a node's chunk would otherwise share a bank)
+__global__ void __launch_bounds__(256) k_stencil_tiles(Dims d, const double *__restrict__ Ke, double *__restrict__ St, TileStarts ts) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double *st = reinterpret_cast<double *>(smem_raw);               // [243][ST_LD]
+    __shared__ int sn[64][4];                                         // i, j, k of the tile's nodes (k < 0: padding beyond the colour)
+    int c = 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) c += (int) blockIdx.x >= ts.v[q];
+    const int t = (int) blockIdx.x - ts.v[c];
+    const int ci = (c >> 2) & 1, cj = (c >> 1) & 1, ck = c & 1;
+    const int cny = cj ? d.NY >> 1 : (d.NY + 1) >> 1, cnz = ck ? d.NZ >> 1 : (d.NZ + 1) >> 1, cnx = ci ? d.NX >> 1 : (d.NX + 1) >> 1;
+    const long long cnt = (long long) cnx * cny * cnz;
+    for (int q = threadIdx.x; q < 243 * ST_LD; q += 256) st[q] = 0.0;
+    if (threadIdx.x < 64) {
+        const long long q = 64LL * t + threadIdx.x;
+        const bool ok = q < cnt;
+        const long long qq = ok ? q : 0;
+        sn[threadIdx.x][0] = 2 * (int) (qq / ((long long) cnz * cny)) + ci;
+        sn[threadIdx.x][1] = 2 * (int) ((qq / cnz) % cny) + cj;
+        sn[threadIdx.x][2] = ok ? 2 * (int) (qq % cnz) + ck : -1000;
+    }
+    __syncthreads();
+    // thread = one of the 72 doubles of a node's chunk (x: row r of the node, column (lm, cc)) for every third node of the tile
+    const int x = threadIdx.x % 72, g = threadIdx.x / 72;
+    const int r = x / 24, col = x - 24 * r, lm = col / 3, cc = col - 3 * lm;
+    const int lmx = (lm >> 2) & 1, lmy = (lm >> 1) & 1, lmz = lm & 1, qe = 3 * r + cc;
+    for (int sel = 0; sel < 8; ++sel) {
+        const int bx = (sel >> 2) & 1, by = (sel >> 1) & 1, bz = sel & 1;
+        const int ln = 4 * (1 - bx) + 2 * (1 - by) + (1 - bz);       // the node's corner in the element i - 1 + bit
+        // neighbour the column belongs to, relative to the node: element origin offset (bit - 1) + corner of the column
+        const int nb = (bx - 1 + lmx + 1) * 9 + (by - 1 + lmy + 1) * 3 + (bz - 1 + lmz + 1);
+        if (g < 3) {
+            // all 22 loads of the element slot in flight before the first is added (one at a time the tile was a chain of 176 round trips)
+            double v[22];
+#pragma unroll
+            for (int it = 0; it < 22; ++it) {
+                const int p = g + 3 * it;
+                v[it] = 0.0;
+                if (p < 64) {
+                    const int ex = sn[p][0] - 1 + bx, ey = sn[p][1] - 1 + by, ez = sn[p][2] - 1 + bz;
+                    if (ex >= 0 && ex < d.nx && ey >= 0 && ey < d.ny && ez >= 0 && ez < d.nz) v[it] = Ke[eidx(d, ex, ey, ez) * 576 + (3 * ln) * 24 + x];
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 22; ++it) {
+                const int p = g + 3 * it;
+                if (p < 64) st[(nb * 9 + qe) * ST_LD + p] += v[it];
+            }
+        }
+        __syncthreads();
+    }
+    long long before = 0;
+    for (int q = 0; q < c; ++q) {
+        const long long qx = ((q >> 2) & 1) ? d.NX >> 1 : (d.NX + 1) >> 1, qy = ((q >> 1) & 1) ? d.NY >> 1 : (d.NY + 1) >> 1, qz = (q & 1) ? d.NZ >> 1 : (d.NZ + 1) >> 1;
+        before += cm_padded(qx * qy * qz);
+    }
+    double *dst = St + 243 * before + (long long) t * (243 * 64);
+    for (int q = threadIdx.x; q < 243 * 64; q += 256) dst[q] = st[(q >> 6) * ST_LD + (q & 63)];
+}
+
 void launch_stencil_from_ke(const Dims &d, const double *Ke, double *S, hipStream_t s) {
-    const long long total = d.nn * 27;
-    k_stencil_build<2><<<dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, s>>>(d, Ke, nullptr, S);
+    TileStarts ts;
+    int total = 0;
+    for (int c = 0; c < 8; ++c) {
+        const long long cx = ((c >> 2) & 1) ? d.NX >> 1 : (d.NX + 1) >> 1, cy = ((c >> 1) & 1) ? d.NY >> 1 : (d.NY + 1) >> 1, cz = (c & 1) ? d.NZ >> 1 : (d.NZ + 1) >> 1;
+        ts.v[c] = total;
+        total += (int) (cm_padded(cx * cy * cz) / 64);
+    }
+    ts.v[8] = total;
+    static bool attr = false;
+    if (!attr) {
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_stencil_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, 243 * ST_LD * 8));
+        attr = true;
+    }
+    if (total > 0) k_stencil_tiles<<<dim3((unsigned) total), dim3(256), 243 * ST_LD * 8, s>>>(d, Ke, S, ts);
     VFEM_HIP(hipGetLastError());
 }
 
