@@ -1149,9 +1149,17 @@ __global__ void __launch_bounds__(576) k_coarsen_ke(Dims c, const double *__rest
     const int ez = (int) (ec % c.nz), ey = (int) ((ec / c.nz) % c.ny), ex = (int) (ec / ((long long) c.nz * c.ny));
     const long long ny1 = 2LL * c.ny, nz1 = 2LL * c.nz;          // child-level element dims
     double acc = 0.0;
+    // stored child matrices: the entry of child g + 1 is requested before child g is multiplied (one after the other the block was a
+    // chain of eight exposed memory round trips)
+    auto child_entry = [&](int g) {
+        const long long cx_ = 2LL * ex + ((g >> 2) & 1), cy_ = 2LL * ey + ((g >> 1) & 1), cz_ = 2LL * ez + (g & 1);
+        return Kef[((cx_ * ny1 + cy_) * nz1 + cz_) * 576 + t];
+    };
+    double kf_cur = MODE != 1 ? child_entry(0) : 0.0;
     for (int g = 0; g < 8; ++g) {
         const int gx = (g >> 2) & 1, gy = (g >> 1) & 1, gz = g & 1;
         const long long cx_ = 2LL * ex + gx, cy_ = 2LL * ey + gy, cz_ = 2LL * ez + gz;   // child element index
+        const double kf_next = (MODE != 1 && g < 7) ? child_entry(g + 1) : 0.0;
         if (MODE == 1) {
             // child matrix = sum_f Efine[f] * cK0[f]; the fine grid is 4x this level
             const long long ny0 = 2 * ny1, nz0 = 2 * nz1;
@@ -1164,7 +1172,8 @@ __global__ void __launch_bounds__(576) k_coarsen_ke(Dims c, const double *__rest
             }
             Kf[t] = v;
         } else {
-            Kf[t] = Kef[((cx_ * ny1 + cy_) * nz1 + cz_) * 576 + t];
+            Kf[t] = kf_cur;
+            kf_cur = kf_next;
         }
         if (t < 64) ph[t] = phi_val(g, t >> 3, t & 7);
         __syncthreads();
