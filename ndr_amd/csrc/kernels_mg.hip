@@ -1198,15 +1198,15 @@ __global__ void __launch_bounds__(576) k_coarsen_ke(Dims c, const double *__rest
 // level-2 element matrices straight from the 64 fine moduli inside the element: Ke = sum_{g,f} E[g,f] * c2K0[g][f] with
 // c2K0[g][f] = I_g^T cK0[f] I_g precomputed on the host (the same sum as MODE 1 of k_coarsen_ke with the two triple products
 // folded into the table: 37 k instead of 250 k multiply-adds per element)
-constexpr int CK2_NB = 8;       // elements per block: every table entry fetched from L2 serves 8 elements
+constexpr int CK2_NB = 16;      // elements per block: every table entry fetched from L2 serves 16 elements (8: the 295 KB table per block made 11 TB/s of L2 traffic)
 __global__ void __launch_bounds__(576) k_coarsen_ke_two_levels(Dims c, const double *__restrict__ c2K0, const double *__restrict__ Ef,
                                                                double *__restrict__ Kec) {
-    __shared__ double Es[CK2_NB][64];
+    __shared__ __align__(16) double Es[64][CK2_NB];        // [grandchild][element]: the eight moduli a table entry multiplies are four 16-byte reads
     const int t = threadIdx.x;
     const long long e0 = (long long) blockIdx.x * CK2_NB;
     const long long ny0 = 4LL * c.ny, nz0 = 4LL * c.nz;          // fine element dims
-    if (t < 64 * CK2_NB) {
-        const int b = t >> 6, q = t & 63, g = q >> 3, f = q & 7;
+    for (int tq = t; tq < 64 * CK2_NB; tq += 576) {
+        const int b = tq >> 6, q = tq & 63, g = q >> 3, f = q & 7;
         const long long ec = e0 + b;
         double v = 0.0;
         if (ec < c.ne) {
@@ -1215,7 +1215,7 @@ __global__ void __launch_bounds__(576) k_coarsen_ke_two_levels(Dims c, const dou
                             fz = 4LL * ez + 2 * (g & 1) + (f & 1);
             v = Ef[(fx * ny0 + fy) * nz0 + fz];
         }
-        Es[b][q] = v;
+        Es[q][b] = v;
     }
     __syncthreads();
     double acc[CK2_NB];
@@ -1224,8 +1224,13 @@ __global__ void __launch_bounds__(576) k_coarsen_ke_two_levels(Dims c, const dou
 #pragma unroll 4
     for (int q = 0; q < 64; ++q) {
         const double k = c2K0[q * 576 + t];
+        typedef double d2v_t __attribute__((ext_vector_type(2), aligned(16)));
 #pragma unroll
-        for (int b = 0; b < CK2_NB; ++b) acc[b] = fma(Es[b][q], k, acc[b]);
+        for (int b = 0; b < CK2_NB; b += 2) {
+            const d2v_t e = *reinterpret_cast<const d2v_t *>(&Es[q][b]);
+            acc[b] = fma(e.x, k, acc[b]);
+            acc[b + 1] = fma(e.y, k, acc[b + 1]);
+        }
     }
 #pragma unroll
     for (int b = 0; b < CK2_NB; ++b)
