@@ -399,16 +399,18 @@ static void update_operators(vfem_mg *mg, hipStream_t s) {
 }
 
 // vcycle, MG.hh:516-553
-static void vcycle(vfem_mg *mg, int l, int nsmooth, bool residual_system, hipStream_t s) {
+// x_is_zero: the level's iterate was just zeroed (by the restriction of the level above), so the Dirichlet values of the residual
+// system (zeros, MG.hh:521-523) hold already
+static void vcycle(vfem_mg *mg, int l, int nsmooth, bool residual_system, hipStream_t s, bool x_is_zero = false) {
     MgLevel &L = mg->lv[l];
     if (l == mg->L) { coarsest_solve(mg, L.b.p, L.x.p, s); return; }
     MgLevel &C = mg->lv[l + 1];
-    launch_enforce_dirichlet(L.d.nn, L.maskp, l == 0 ? mg->fine->dvals.p : nullptr, L.x.p, residual_system ? 1 : 0, s);
+    if (!(x_is_zero && residual_system))
+        launch_enforce_dirichlet(L.d.nn, L.maskp, l == 0 ? mg->fine->dvals.p : nullptr, L.x.p, residual_system ? 1 : 0, s);
     mg_smooth_n(mg, l, L.x.p, L.b.p, 1, nsmooth, s);
     mg_apply(mg, l, L.x.p, L.b.p, 1, L.r.p, s);                       // computeResidual (Dirichlet zeroed)
-    launch_restrict(C.d, L.d.NX, C.xshift, L.r.p, C.b.p, s);
-    C.x.zero(s);
-    vcycle(mg, l + 1, nsmooth, true, s);
+    launch_restrict(C.d, L.d.NX, C.xshift, L.r.p, C.b.p, s, C.x.p);  // ... and the zero initial guess of the coarse level
+    vcycle(mg, l + 1, nsmooth, true, s, true);
     launch_prolong(C.d, L.d.NX, C.xshift, C.x.p, L.x.p, 1, s);
     mg_smooth_n(mg, l, L.x.p, L.b.p, mg->symmetric_gs ? 0 : 1, nsmooth, s);
 }
@@ -1050,7 +1052,7 @@ int vfem_mg_pcg(vfem_mg *mg, double *x, const double *b, int max_iter, double to
         if (mg_smoothing == 0) {
             VFEM_HIP(hipMemcpyAsync(sv, r, bytes, hipMemcpyDeviceToDevice, s));
         } else {
-            mg->lv[0].x.zero(s);
+            if (!fmg) mg->lv[0].x.zero(s);          // full multigrid overwrites the iterate of every level (prolongation, MG.hh:500)
             mg_cycles(mg, mg_iterations, mg_smoothing, true, fmg != 0, s);
         }
         // the vector work between the cycle and the apply, three passes fewer than one kernel per line of MG.hh:713-725 (same

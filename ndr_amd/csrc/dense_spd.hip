@@ -87,21 +87,27 @@ __global__ void __launch_bounds__(256) k_dense_pad(long long n, long long Np, co
 }
 
 // diagonal tile k: L_kk (written back, strict upper part zeroed) and D[k] = L_kk^-1, both by right-looking elimination.
-// The tile and the inverse under construction live in REGISTERS (thread (r0, c) of 4 x 64 owns the rows r0 + 4 q, q < 16, of column
-// c: 32 doubles); a step publishes only column j of A and row j of X through LDS (double-buffered: one workgroup barrier per step)
+// The tile and the inverse under construction live in REGISTERS (thread (r0, c) of CD_RG x 64 owns the rows r0 + CD_RG q of column
+// c); a step publishes only column j of A and row j of X through LDS (double-buffered: one workgroup barrier per step)
 // and every thread scales them itself (the same products a[r][j] * inv, x[j][c] * inv as an in-place scaling, so the result does not
 // depend on the thread layout).  With both matrices in LDS and three barriers per step the tile took 97 us (a chain of dependent
 // LDS round trips per row of the trailing update), as one wave without workgroup barriers 259 us; a 2187-dof coarsest level has 35
 // such tiles in sequence.  info (0 on entry) receives 1 + the global index of the first non-positive pivot.
-__global__ void __launch_bounds__(256) k_chol_diag(long long Np, int k, double *__restrict__ L, double *__restrict__ D, int *__restrict__ info) {
+#ifndef VFEM_CD_THREADS
+#define VFEM_CD_THREADS 1024
+#endif
+constexpr int CD_THREADS = VFEM_CD_THREADS;                    // 16 waves: the 64 steps of a tile are one chain of latencies, four waves per SIMD overlap them
+constexpr int CD_RG = CD_THREADS / 64, CD_Q = 64 / CD_RG;      // thread (r0, c) owns rows r0 + CD_RG q, q < CD_Q, of column c
+__global__ void __launch_bounds__(CD_THREADS) k_chol_diag(long long Np, int k, double *__restrict__ L, double *__restrict__ D, int *__restrict__ info) {
     using namespace dense;
+    static_assert(T == 64, "one lane per column of the tile");
     __shared__ double col[2][T], row[2][T];
     double *tile = L + ((long long) k * T) * Np + (long long) k * T;
     const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
-    double a[16], x[16];
+    double a[CD_Q], x[CD_Q];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int r = r0 + 4 * q;
+    for (int q = 0; q < CD_Q; ++q) {
+        const int r = r0 + CD_RG * q;
         a[q] = tile[(long long) r * Np + c];
         x[q] = r == c ? 1.0 : 0.0;
     }
@@ -110,12 +116,12 @@ __global__ void __launch_bounds__(256) k_chol_diag(long long Np, int k, double *
         // publish column j of A (pivot included) and row j of X as they stand
         if (c == j) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) col[buf][r0 + 4 * q] = a[q];
+            for (int q = 0; q < CD_Q; ++q) col[buf][r0 + CD_RG * q] = a[q];
         }
-        if (r0 == (j & 3)) {
+        if (r0 == (j % CD_RG)) {
             double xv = 0.0;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) xv = (j >> 2) == q ? x[q] : xv;
+            for (int q = 0; q < CD_Q; ++q) xv = (j / CD_RG) == q ? x[q] : xv;
             row[buf][c] = xv;
         }
         __syncthreads();
@@ -131,9 +137,9 @@ __global__ void __launch_bounds__(256) k_chol_diag(long long Np, int k, double *
         const double lcj = col[buf][c] * inv;          // L[c][j] (used where c > j)
         const double xjc = row[buf][c] * inv;          // X[j][c] (used where c <= j)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {                 // (selects, no lane-dependent branches: the conditions differ from lane to lane)
-            if (4 * q + 3 < j) continue;               // all four rows of this slot lie above the pivot row: finished (uniform over the workgroup)
-            const int r = r0 + 4 * q;
+        for (int q = 0; q < CD_Q; ++q) {               // (selects, no lane-dependent branches: the conditions differ from lane to lane)
+            if (CD_RG * q + CD_RG - 1 < j) continue;   // all rows of this slot lie above the pivot row: finished (uniform over the workgroup)
+            const int r = r0 + CD_RG * q;
             const double lrj = col[buf][r] * inv;      // L[r][j]
             const double an = (c > j && c <= r) ? fma(-lrj, lcj, a[q]) : (c == j ? lrj : a[q]);
             const double xn = c <= j ? fma(-lrj, xjc, x[q]) : x[q];
@@ -142,8 +148,8 @@ __global__ void __launch_bounds__(256) k_chol_diag(long long Np, int k, double *
         }
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int r = r0 + 4 * q;
+    for (int q = 0; q < CD_Q; ++q) {
+        const int r = r0 + CD_RG * q;
         tile[(long long) r * Np + c] = c <= r ? a[q] : 0.0;
         D[((long long) k * T + r) * T + c] = c <= r ? x[q] : 0.0;
     }
@@ -245,7 +251,7 @@ void dense_spd_inverse(long long n, double *A, DenseWork &w, hipStream_t s) {
     VFEM_HIP(hipMemsetAsync(w.info.p, 0, sizeof(int), s));
     k_dense_pad<<<gsq, 256, 0, s>>>(n, Np, A, w.L.p);
     for (int k = 0; k < nb; ++k) {
-        k_chol_diag<<<1, 256, 0, s>>>(Np, k, w.L.p, w.D.p, w.info.p);
+        k_chol_diag<<<1, CD_THREADS, 0, s>>>(Np, k, w.L.p, w.D.p, w.info.p);
         const int rest = nb - k - 1;
         if (rest > 0) {
             k_chol_panel<<<rest, 256, 0, s>>>(Np, k, w.L.p, w.D.p);

@@ -14,6 +14,7 @@
 #include "device_utils.h"
 #include "gs_coef.h"
 
+
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
@@ -1008,6 +1009,10 @@ __global__ void __launch_bounds__(256) k_gs_color_stencil_wave(Dims d, const dou
     cm_index(d, i, j, k, sbase, scnt);
     // tile-major base = 243 * 64 * tile + lane-in-tile  ->  padded colour-major number of the node
     const double *row = Sn + ((sbase / (243 * 64)) * 64 + sbase % 64) * 243;
+    // what the solve of lane 0 needs is requested with the row (wave-uniform addresses): a launch of this kernel is one latency
+    // chain, and loads issued after the reduction would add a second memory round trip to it
+    const double bn0 = b[3 * n], bn1 = b[3 * n + 1], bn2 = b[3 * n + 2], un0 = u[3 * n], un1 = u[3 * n + 1], un2 = u[3 * n + 2];
+    const uint8_t fixed = mask[n];
     double p0 = 0.0, p1 = 0.0, p2 = 0.0, centre = 0.0;
 #pragma unroll
     for (int sidx = 0; sidx < 4; ++sidx) {
@@ -1028,10 +1033,9 @@ __global__ void __launch_bounds__(256) k_gs_color_stencil_wave(Dims d, const dou
 #pragma unroll
     for (int qq = 0; qq < 9; ++qq) M[qq] = __shfl(centre, 53 + qq);
     if (lane != 0) return;
-    double bms[3] = {b[3 * n] - p0, b[3 * n + 1] - p1, b[3 * n + 2] - p2}, ud[3];
-    gs_solve(bms, M, mask[n], forward != 0, ud);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) u[3 * n + c] += ud[c];
+    double bms[3] = {bn0 - p0, bn1 - p1, bn2 - p2}, ud[3];
+    gs_solve(bms, M, fixed, forward != 0, ud);
+    u[3 * n] = un0 + ud[0]; u[3 * n + 1] = un1 + ud[1]; u[3 * n + 2] = un2 + ud[2];
 }
 
 void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const double *b, const uint8_t *mask,
@@ -1054,7 +1058,7 @@ void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const do
 // grid transfer (trilinear weights 1, 1/2, 1/4, 1/8; no 1/2^N scaling), gather form
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_restrict(Dims c, int FX, int shift, const double *__restrict__ fine,
-                                                  double *__restrict__ coarse) {
+                                                  double *__restrict__ coarse, double *__restrict__ zeroed) {
     const int q = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x;       // lanes packed over the nodes of an x-plane
     if (q >= c.NY * c.NZ) return;
     const int j = q / c.NZ, k = q - j * c.NZ, i = blockIdx.z;
@@ -1080,11 +1084,12 @@ __global__ void __launch_bounds__(256) k_restrict(Dims c, int FX, int shift, con
     }
     const long long n = nidx(c, i, j, k);
     coarse[3 * n] = a0; coarse[3 * n + 1] = a1; coarse[3 * n + 2] = a2;
+    if (zeroed) { zeroed[3 * n] = 0.0; zeroed[3 * n + 1] = 0.0; zeroed[3 * n + 2] = 0.0; }      // the coarse initial guess of the V-cycle
 }
 
-void launch_restrict(const Dims &c, int fineNX, int shift, const double *fine, double *coarse, hipStream_t s) {
+void launch_restrict(const Dims &c, int fineNX, int shift, const double *fine, double *coarse, hipStream_t s, double *zeroed) {
     dim3 blk(64, 4, 1), grd((c.NY * c.NZ + 255) / 256, 1, c.NX);
-    k_restrict<<<grd, blk, 0, s>>>(c, fineNX, shift, fine, coarse);
+    k_restrict<<<grd, blk, 0, s>>>(c, fineNX, shift, fine, coarse, zeroed);
     VFEM_HIP(hipGetLastError());
 }
 

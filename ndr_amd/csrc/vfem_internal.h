@@ -162,7 +162,8 @@ void launch_stencil_node_major(const Dims &d, const double *St, double *Sn, hipS
 constexpr long long WAVE_SWEEP_MAX_NODES = 40000;
 
 // fine local plane index = 2 * (coarse local plane) + shift + {-1,0,1}; fineNX = fine local node planes
-void launch_restrict(const Dims &coarse, int fineNX, int shift, const double *fine, double *coarse_out, hipStream_t s);
+// zeroed (optional): a second coarse field set to zero by the same launch (the V-cycle's coarse initial guess)
+void launch_restrict(const Dims &coarse, int fineNX, int shift, const double *fine, double *coarse_out, hipStream_t s, double *zeroed = nullptr);
 void launch_prolong(const Dims &coarse, int fineNX, int shift, const double *coarse_in, double *fine, int accumulate, hipStream_t s);
 
 void launch_zero_dirichlet(long long nn, const uint8_t *mask, double *u, hipStream_t s);
