@@ -203,7 +203,7 @@ __device__ __forceinline__ void node_group(const Dims &d, const double *__restri
 template <int MODE>
 __global__ void __launch_bounds__(192, L1M_WAVES) k_l1_merged(Dims d, const double *__restrict__ tab, const double *__restrict__ E,
                                                    const double *u, const double *__restrict__ b, const uint8_t *__restrict__ mask,
-                                                   double *out, int cx, int cy, int cz, int forward, int kq0) {
+                                                   double *out, int cx, int cy, int cz, int forward, int ka, int kskip) {
     __shared__ double part[2][3][64];
     __shared__ double sE[4][16][64];     // (35 KB with the exchange area: four workgroups per CU.  Exactly 32 KB -- exchange area inside it, a
                                          // third barrier -- and five workgroups measured no faster: 2.91 against 2.88 ms per sweep at 257^3)
@@ -211,12 +211,12 @@ __global__ void __launch_bounds__(192, L1M_WAVES) k_l1_merged(Dims d, const doub
     int i, j, k;
     bool live;
     if (MODE == 0) {       // lanes packed over the colour's nodes of an x-plane, row after row (rows have 2^k + 1 nodes)
-        // (kq0: the colour's nodes of a row from that colour index on -- what the row kernel below leaves over)
-        const int cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1 - kq0;
+        // (ka, kskip: the colour's nodes of a row without those of colour index ka .. ka + kskip - 1 -- what the row kernel below leaves over)
+        const int cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1 - kskip;
         const int q = blockIdx.x * 64 + lane;
         live = q < cnty * cntz;
-        const int qq = live ? q : cnty * cntz - 1, jq = qq / cntz;
-        k = 2 * (kq0 + qq - jq * cntz) + cz; j = 2 * jq + cy; i = 2 * blockIdx.z + cx;
+        const int qq = live ? q : cnty * cntz - 1, jq = qq / cntz, r = qq - jq * cntz;
+        k = 2 * (r < ka ? r : r + kskip) + cz; j = 2 * jq + cy; i = 2 * blockIdx.z + cx;
     } else {
         const int q = blockIdx.x * 64 + lane;
         live = q < d.NY * d.NZ;
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(192, L1M_WAVES) k_l1_merged(Dims d, const doub
 // colours), so workgroups are independent and the result is that of two launches, bit for bit.  What it saves is HBM traffic: a
 // colour launch streams ALL fine moduli (their 4^3 neighbourhoods tile the fine grid: 1.07 GB at 257^3 of the 2.06 GB a launch
 // moves); here the B phase finds the moduli and node rows of its segment in L2, where the A phase of the same workgroup left them.
-// nseg whole segments per row; the row ends go to k_l1_merged (A before, B after).
+// nseg whole segments per row; what they leave over of the row goes to k_l1_merged (A nodes before, B nodes after).
 template <int FZ>
 __global__ void __launch_bounds__(192, L1M_WAVES) k_l1_pair_rows(Dims d, const double *__restrict__ tab, const double *__restrict__ E, double *u,
                                                                  const double *__restrict__ b, const uint8_t *__restrict__ mask, int cx, int cy,
@@ -243,7 +243,9 @@ __global__ void __launch_bounds__(192, L1M_WAVES) k_l1_pair_rows(Dims d, const d
     const int i = 2 * blockIdx.z + cx, j = 2 * blockIdx.y + cy;
 #pragma unroll 1
     for (int s = 0; s < 2 * nseg; ++s) {           // even s: the A nodes of segment s / 2, odd s: its B nodes
-        const int k = FZ + 128 * (s >> 1) + 2 * lane - (s & 1);
+        // FZ = 0: the A nodes are the even ones from k = 2 on (k = 0 is left over, relaxed before the launch), so that the B nodes
+        // 1, 3, ... fill their 64 lanes and a row of 2^m + 1 nodes leaves nothing over at its end
+        const int k = (FZ == 0 ? 2 : 1) + 128 * (s >> 1) + 2 * lane - (s & 1);
         const bool live = k >= 0 && k < d.NZ;
         node_group<0>(d, tab, E, u, b, mask, u, i, j, live ? k : FZ, live, role, lane, FZ == 0, part, sE);
         // what was stored is read by the next phase's loads of all three waves (same CU: the vector cache is shared and write-through)
@@ -269,21 +271,23 @@ void launch_l1_merged_sweep(const Dims &d, const double *tab, const double *E, d
         const int cx = ((lni >> 2) & 1) ^ (xparity & 1), cy = (lni >> 1) & 1, cz = lni & 1;
         if (cx > d.NX - 1 || cy > d.NY - 1 || cz > d.NZ - 1) continue;
         const int cntx = (d.NX - 1 - cx) / 2 + 1, cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
-        const int nseg = cntz / 64;
+        // the row kernel walks the A nodes of colour index ka .. ka + 64 nseg - 1 (ka = 1 for even A nodes: see there) and the B nodes
+        // 0 .. 64 nseg - 1
+        const int fz = cz, ka = fz == 0 ? 1 : 0, nseg = (cntz - ka) / 64;
         if (pair && ci % 2 == 0 && ci + 1 < first + count && nseg >= 1) {
-            // colours ci and ci + 1 differ in c_z only (c_z = fz first): whole segments by the row kernel, the nodes left over at the
-            // row end colour by colour: first colour before it, second colour after it
-            const int fz = cz, walked = 64 * nseg, cntb = (d.NZ - 1 - (1 - fz)) / 2 + 1, kq0b = walked - (fz == 0 ? 1 : 0);
+            // colours ci and ci + 1 differ in c_z only (c_z = fz first): whole segments by the row kernel, the nodes it leaves over
+            // colour by colour: first colour before it, second colour after it (a row of 2^m + 1 nodes: one launch of one node per row)
+            const int walked = 64 * nseg, cntb = (d.NZ - 1 - (1 - fz)) / 2 + 1;
             if (cntz > walked)
-                k_l1_merged<0><<<dim3((cnty * (cntz - walked) + 63) / 64, 1, cntx), dim3(64, 3, 1), 0, s>>>(d, tab, E, u, b, mask, u, cx, cy, fz, forward, walked);
+                k_l1_merged<0><<<dim3((cnty * (cntz - walked) + 63) / 64, 1, cntx), dim3(64, 3, 1), 0, s>>>(d, tab, E, u, b, mask, u, cx, cy, fz, forward, ka, walked);
             if (fz == 0) k_l1_pair_rows<0><<<dim3(1, cnty, cntx), dim3(64, 3, 1), 0, s>>>(d, tab, E, u, b, mask, cx, cy, nseg);
             else         k_l1_pair_rows<1><<<dim3(1, cnty, cntx), dim3(64, 3, 1), 0, s>>>(d, tab, E, u, b, mask, cx, cy, nseg);
-            if (cntb > kq0b)
-                k_l1_merged<0><<<dim3((cnty * (cntb - kq0b) + 63) / 64, 1, cntx), dim3(64, 3, 1), 0, s>>>(d, tab, E, u, b, mask, u, cx, cy, 1 - fz, forward, kq0b);
+            if (cntb > walked)
+                k_l1_merged<0><<<dim3((cnty * (cntb - walked) + 63) / 64, 1, cntx), dim3(64, 3, 1), 0, s>>>(d, tab, E, u, b, mask, u, cx, cy, 1 - fz, forward, 0, walked);
             ++ci;
             continue;
         }
-        k_l1_merged<0><<<dim3((cnty * cntz + 63) / 64, 1, cntx), dim3(64, 3, 1), 0, s>>>(d, tab, E, u, b, mask, u, cx, cy, cz, forward, 0);
+        k_l1_merged<0><<<dim3((cnty * cntz + 63) / 64, 1, cntx), dim3(64, 3, 1), 0, s>>>(d, tab, E, u, b, mask, u, cx, cy, cz, forward, 0, 0);
     }
     VFEM_HIP(hipGetLastError());
 }
@@ -291,8 +295,8 @@ void launch_l1_merged_sweep(const Dims &d, const double *tab, const double *E, d
 void launch_l1_merged_apply(const Dims &d, const double *tab, const double *E, const double *u, const double *b, const uint8_t *mask,
                             int res, double *out, hipStream_t s) {
     const dim3 grd((d.NY * d.NZ + 63) / 64, 1, d.NX), blk(64, 3, 1);
-    if (res) k_l1_merged<2><<<grd, blk, 0, s>>>(d, tab, E, u, b, mask, out, 0, 0, 0, 0, 0);
-    else     k_l1_merged<1><<<grd, blk, 0, s>>>(d, tab, E, u, b, mask, out, 0, 0, 0, 0, 0);
+    if (res) k_l1_merged<2><<<grd, blk, 0, s>>>(d, tab, E, u, b, mask, out, 0, 0, 0, 0, 0, 0);
+    else     k_l1_merged<1><<<grd, blk, 0, s>>>(d, tab, E, u, b, mask, out, 0, 0, 0, 0, 0, 0);
     VFEM_HIP(hipGetLastError());
 }
 
