@@ -399,13 +399,13 @@ static void update_operators(vfem_mg *mg, hipStream_t s) {
 }
 
 // vcycle, MG.hh:516-553
-// x_is_zero: the level's iterate was just zeroed (by the restriction of the level above), so the Dirichlet values of the residual
-// system (zeros, MG.hh:521-523) hold already
-static void vcycle(vfem_mg *mg, int l, int nsmooth, bool residual_system, hipStream_t s, bool x_is_zero = false) {
+// dirichlet_zeroed: the level's iterate has zeros at the Dirichlet components already (just zeroed by the restriction of the level
+// above, or interpolated with the mask by full_multigrid), which is all the residual system asks for (MG.hh:521-523)
+static void vcycle(vfem_mg *mg, int l, int nsmooth, bool residual_system, hipStream_t s, bool dirichlet_zeroed = false) {
     MgLevel &L = mg->lv[l];
     if (l == mg->L) { coarsest_solve(mg, L.b.p, L.x.p, s); return; }
     MgLevel &C = mg->lv[l + 1];
-    if (!(x_is_zero && residual_system))
+    if (!(dirichlet_zeroed && residual_system))
         launch_enforce_dirichlet(L.d.nn, L.maskp, l == 0 ? mg->fine->dvals.p : nullptr, L.x.p, residual_system ? 1 : 0, s);
     mg_smooth_n(mg, l, L.x.p, L.b.p, 1, nsmooth, s);
     mg_apply(mg, l, L.x.p, L.b.p, 1, L.r.p, s);                       // computeResidual (Dirichlet zeroed)
@@ -422,8 +422,8 @@ static void full_multigrid(vfem_mg *mg, int l, int nsmooth, bool residual_system
     MgLevel &C = mg->lv[l + 1];
     launch_restrict(C.d, L.d.NX, C.xshift, L.b.p, C.b.p, s);
     full_multigrid(mg, l + 1, nsmooth, residual_system, s);
-    launch_prolong(C.d, L.d.NX, C.xshift, C.x.p, L.x.p, 0, s);
-    vcycle(mg, l, nsmooth, residual_system, s);
+    launch_prolong(C.d, L.d.NX, C.xshift, C.x.p, L.x.p, 0, s, residual_system ? L.maskp : nullptr);
+    vcycle(mg, l, nsmooth, residual_system, s, residual_system);
 }
 
 // MG::solve on the level-0 work vectors (x[0], b[0] already set), MG.hh:457-471

@@ -1093,8 +1093,11 @@ void launch_restrict(const Dims &c, int fineNX, int shift, const double *fine, d
     VFEM_HIP(hipGetLastError());
 }
 
+// fixed (optional, !ACC): Dirichlet mask of the fine level, the interpolated field gets zeros at its components (the residual
+// system's Dirichlet values, MG.hh:521-523, without a pass of their own)
 template <bool ACC>
-__global__ void __launch_bounds__(256) k_prolong(Dims c, int shift, const double *__restrict__ coarse, double *__restrict__ fine) {
+__global__ void __launch_bounds__(256) k_prolong(Dims c, int shift, const double *__restrict__ coarse, double *__restrict__ fine,
+                                                 const uint8_t *__restrict__ fixed) {
     const int FY = 2 * c.ny + 1, FZ = 2 * c.nz + 1;
     const int qq = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x;      // lanes packed over the nodes of an x-plane
     if (qq >= FY * FZ) return;
@@ -1116,14 +1119,18 @@ __global__ void __launch_bounds__(256) k_prolong(Dims c, int shift, const double
     }
     const long long n = ((long long) i * FY + j) * FZ + k;
     if (ACC) { fine[3 * n] += a0; fine[3 * n + 1] += a1; fine[3 * n + 2] += a2; }
-    else     { fine[3 * n] = a0;  fine[3 * n + 1] = a1;  fine[3 * n + 2] = a2; }
+    else {
+        const unsigned f = fixed ? fixed[n] : 0u;
+        fine[3 * n] = (f & 1) ? 0.0 : a0; fine[3 * n + 1] = (f & 2) ? 0.0 : a1; fine[3 * n + 2] = (f & 4) ? 0.0 : a2;
+    }
 }
 
-void launch_prolong(const Dims &c, int fineNX, int shift, const double *coarse, double *fine, int accumulate, hipStream_t s) {
+void launch_prolong(const Dims &c, int fineNX, int shift, const double *coarse, double *fine, int accumulate, hipStream_t s,
+                    const uint8_t *fixed) {
     const int FY = 2 * c.ny + 1, FZ = 2 * c.nz + 1;
     dim3 blk(64, 4, 1), grd((FY * FZ + 255) / 256, 1, fineNX);
-    if (accumulate) k_prolong<true><<<grd, blk, 0, s>>>(c, shift, coarse, fine);
-    else            k_prolong<false><<<grd, blk, 0, s>>>(c, shift, coarse, fine);
+    if (accumulate) k_prolong<true><<<grd, blk, 0, s>>>(c, shift, coarse, fine, nullptr);
+    else            k_prolong<false><<<grd, blk, 0, s>>>(c, shift, coarse, fine, fixed);
     VFEM_HIP(hipGetLastError());
 }
 

@@ -164,7 +164,9 @@ constexpr long long WAVE_SWEEP_MAX_NODES = 40000;
 // fine local plane index = 2 * (coarse local plane) + shift + {-1,0,1}; fineNX = fine local node planes
 // zeroed (optional): a second coarse field set to zero by the same launch (the V-cycle's coarse initial guess)
 void launch_restrict(const Dims &coarse, int fineNX, int shift, const double *fine, double *coarse_out, hipStream_t s, double *zeroed = nullptr);
-void launch_prolong(const Dims &coarse, int fineNX, int shift, const double *coarse_in, double *fine, int accumulate, hipStream_t s);
+// fixed (optional, accumulate == 0): the fine level's Dirichlet mask; its components of the interpolated field are set to zero
+void launch_prolong(const Dims &coarse, int fineNX, int shift, const double *coarse_in, double *fine, int accumulate, hipStream_t s,
+                    const uint8_t *fixed = nullptr);
 
 void launch_zero_dirichlet(long long nn, const uint8_t *mask, double *u, hipStream_t s);
 void launch_enforce_dirichlet(long long nn, const uint8_t *mask, const double *vals, double *u, int zero, hipStream_t s);
