@@ -73,6 +73,14 @@ __device__ __forceinline__ double lane_below(double v) {
 }
 
 
+// value held by the next lane of the wave (lane 63 receives 0): DPP wave shift the other way
+__device__ __forceinline__ double lane_above(double v) {
+    const unsigned long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned) (b & 0xffffffffull), 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned) (b >> 32), 0x130, 0xf, 0xf, true);
+    return __longlong_as_double(((unsigned long long) hi << 32) | lo);
+}
+
 // component-sequential 3x3 solve of m_smoothNode (MG.hh:254-264)
 __device__ __forceinline__ void gs_solve(const double bms[3], const double M[9], uint8_t mask, bool forward,
                                          double ud[3]) {

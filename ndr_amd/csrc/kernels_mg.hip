@@ -1057,44 +1057,54 @@ void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const do
 // ------------------------------------------------------------------------------------------
 // grid transfer (trilinear weights 1, 1/2, 1/4, 1/8; no 1/2^N scaling), gather form
 // ------------------------------------------------------------------------------------------
+// Lanes run along z.  Of the three fine nodes 2k-1, 2k, 2k+1 a coarse node reads in each of its nine fine rows, lane k loads 2k and
+// 2k+1 (48 contiguous bytes: a wave reads 3 KB of the row in one piece) and receives 2k-1 from lane k-1, which loaded it as its own
+// second node (DPP wave shift; the first lane of a wave loads it itself).  Loading all three per lane -- 54 load instructions per
+// coarse node for 24 bytes of result -- ran at the rate of its memory instructions, 2.7 TB/s at 512^3.  The sum runs over the
+// rows and, inside a row, over 2k-1, 2k, 2k+1 as before: same values bit for bit.
 __global__ void __launch_bounds__(256) k_restrict(Dims c, int FX, int shift, const double *__restrict__ fine,
                                                   double *__restrict__ coarse, double *__restrict__ zeroed) {
-    const int q = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x;       // lanes packed over the nodes of an x-plane
-    if (q >= c.NY * c.NZ) return;
-    const int j = q / c.NZ, k = q - j * c.NZ, i = blockIdx.z;
+    const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z;
+    if (j >= c.NY) return;                                                 // (wave-uniform)
     const int FY = 2 * c.ny + 1, FZ = 2 * c.nz + 1;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    for (int di = -1; di <= 1; ++di) {
-        const int fi = 2 * i + shift + di;
-        if (fi < 0 || fi >= FX) continue;
-        for (int dj = -1; dj <= 1; ++dj) {
-            const int fj = 2 * j + dj;
-            if (fj < 0 || fj >= FY) continue;
+    const bool live = k < c.NZ, lo = live && k > 0, hi = live && 2 * k + 1 < FZ, first = threadIdx.x == 0;
+    double a[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-            for (int dk = -1; dk <= 1; ++dk) {
-                const int fk = 2 * k + dk;
-                if (fk < 0 || fk >= FZ) continue;
-                const double w = (di ? 0.5 : 1.0) * (dj ? 0.5 : 1.0) * (dk ? 0.5 : 1.0);
-                const long long m = ((long long) fi * FY + fj) * FZ + fk;
-                a0 = fma(w, fine[3 * m], a0);
-                a1 = fma(w, fine[3 * m + 1], a1);
-                a2 = fma(w, fine[3 * m + 2], a2);
-            }
+    for (int t = 0; t < 9; ++t) {
+        const int di = t / 3 - 1, dj = t % 3 - 1, fi = 2 * i + shift + di, fj = 2 * j + dj;
+        if (fi < 0 || fi >= FX || fj < 0 || fj >= FY) continue;             // (wave-uniform)
+        const double w = (di ? 0.5 : 1.0) * (dj ? 0.5 : 1.0);
+        const double *p = fine + 3 * (((long long) fi * FY + fj) * FZ + (live ? 2 * k : 0));
+        double f0[3], f1[3], fm[3];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            f0[cc] = p[cc];
+            f1[cc] = hi ? p[3 + cc] : 0.0;
+        }
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            fm[cc] = lane_below(f1[cc]);
+            if (first && lo) fm[cc] = p[cc - 3];
+        }
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            if (lo) a[cc] = fma(0.5 * w, fm[cc], a[cc]);
+            a[cc] = fma(w, f0[cc], a[cc]);
+            if (hi) a[cc] = fma(0.5 * w, f1[cc], a[cc]);
         }
     }
+    if (!live) return;
     const long long n = nidx(c, i, j, k);
-    coarse[3 * n] = a0; coarse[3 * n + 1] = a1; coarse[3 * n + 2] = a2;
+    coarse[3 * n] = a[0]; coarse[3 * n + 1] = a[1]; coarse[3 * n + 2] = a[2];
     if (zeroed) { zeroed[3 * n] = 0.0; zeroed[3 * n + 1] = 0.0; zeroed[3 * n + 2] = 0.0; }      // the coarse initial guess of the V-cycle
 }
 
 void launch_restrict(const Dims &c, int fineNX, int shift, const double *fine, double *coarse, hipStream_t s, double *zeroed) {
-    dim3 blk(64, 4, 1), grd((c.NY * c.NZ + 255) / 256, 1, c.NX);
+    dim3 blk(64, 4, 1), grd((c.NZ + 63) / 64, (c.NY + 3) / 4, c.NX);
     k_restrict<<<grd, blk, 0, s>>>(c, fineNX, shift, fine, coarse, zeroed);
     VFEM_HIP(hipGetLastError());
 }
 
-// fixed (optional, !ACC): Dirichlet mask of the fine level, the interpolated field gets zeros at its components (the residual
-// system's Dirichlet values, MG.hh:521-523, without a pass of their own)
 template <bool ACC>
 __global__ void __launch_bounds__(256) k_prolong(Dims c, int shift, const double *__restrict__ coarse, double *__restrict__ fine,
                                                  const uint8_t *__restrict__ fixed) {
@@ -1125,12 +1135,82 @@ __global__ void __launch_bounds__(256) k_prolong(Dims c, int shift, const double
     }
 }
 
+// The same interpolation row by row with whole-line stores.  A wave owns 128 consecutive nodes of a fine row (i, j): lane l loads
+// coarse node k0 = 64 chunk + l of the (up to) four coarse rows the fine row depends on (24 bytes each; k0 + 1 comes from the next
+// lane by a DPP wave shift), forms fine nodes 2 k0 and 2 k0 + 1, and the 3 KB of results go through LDS so that every store
+// instruction writes 1 KB of consecutive bytes.  The node-per-lane kernel above issues 16 loads and 2 strided stores per fine node
+// (2.8 TB/s of useful bytes at 512^3, bound by the rate of its memory instructions); this one 6 loads and 3 stores per 128.
+// Every fine node is summed in the same order: same values bit for bit.
+template <bool ACC>
+__global__ void __launch_bounds__(256) k_prolong_rows(Dims c, int shift, const double *__restrict__ coarse, double *__restrict__ fine,
+                                                      const uint8_t *__restrict__ fixed) {
+    __shared__ __align__(16) double sh[4][384];
+    const int FY = 2 * c.ny + 1, FZ = 2 * c.nz + 1;
+    const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int j = blockIdx.y * 4 + wv, i = blockIdx.z, chunk = blockIdx.x;
+    if (j >= FY) return;                                                    // (wave-uniform)
+    const int ig = i - shift;                                               // >= 0: shift is 0 or -1
+    const int i0 = ig >> 1, j0 = j >> 1, oi = ig & 1, oj = j & 1;
+    const int k0 = 64 * chunk + lane;
+    const bool live = k0 < c.NZ, up = k0 + 1 < c.NZ;
+    const double w0 = (oi ? 0.5 : 1.0) * (oj ? 0.5 : 1.0), w1 = 0.5 * w0;
+    double v0[3] = {0.0, 0.0, 0.0}, v1[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int qi = t >> 1, qj = t & 1;
+        if ((qi && !oi) || (qj && !oj) || i0 + qi > c.NX - 1) continue;     // (wave-uniform; beyond the local slab: ghost planes only)
+        const double *p = coarse + 3 * nidx(c, i0 + qi, j0 + qj, live ? k0 : 0);
+        double c0[3], c1[3];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) c0[cc] = p[cc];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            c1[cc] = lane_above(c0[cc]);
+            if (lane == 63 && up) c1[cc] = p[3 + cc];
+        }
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            v0[cc] = fma(w0, c0[cc], v0[cc]);
+            v1[cc] = fma(w1, c0[cc], v1[cc]);
+            v1[cc] = fma(w1, c1[cc], v1[cc]);
+        }
+    }
+    const long long row = ((long long) i * FY + j) * FZ;
+    if (!ACC && fixed != nullptr && live) {
+        const unsigned f0 = fixed[row + 2 * k0], f1 = up ? fixed[row + 2 * k0 + 1] : 0u;
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            if ((f0 >> cc) & 1) v0[cc] = 0.0;
+            if ((f1 >> cc) & 1) v1[cc] = 0.0;
+        }
+    }
+    double *s = sh[wv];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) { s[6 * lane + cc] = v0[cc]; s[6 * lane + 3 + cc] = v1[cc]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nd = 3 * min(128, FZ - 128 * chunk);                           // doubles of this wave's piece of the fine row
+    double *out = fine + 3 * row + 384 * chunk;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int d = 2 * (lane + 64 * r);
+        if (d + 1 < nd) {
+            double2 x = *reinterpret_cast<const double2 *>(s + d);
+            if (ACC) { x.x += out[d]; x.y += out[d + 1]; out[d] = x.x; out[d + 1] = x.y; }
+            else { __builtin_nontemporal_store(x.x, out + d); __builtin_nontemporal_store(x.y, out + d + 1); }
+        } else if (d < nd) {
+            out[d] = ACC ? out[d] + s[d] : s[d];
+        }
+    }
+}
+
 void launch_prolong(const Dims &c, int fineNX, int shift, const double *coarse, double *fine, int accumulate, hipStream_t s,
                     const uint8_t *fixed) {
-    const int FY = 2 * c.ny + 1, FZ = 2 * c.nz + 1;
-    dim3 blk(64, 4, 1), grd((FY * FZ + 255) / 256, 1, fineNX);
-    if (accumulate) k_prolong<true><<<grd, blk, 0, s>>>(c, shift, coarse, fine, nullptr);
-    else            k_prolong<false><<<grd, blk, 0, s>>>(c, shift, coarse, fine, fixed);
+    const int FY = 2 * c.ny + 1;
+    dim3 blk(64, 4, 1), grd((c.NZ + 63) / 64, (FY + 3) / 4, fineNX);
+    if (accumulate) k_prolong_rows<true><<<grd, blk, 0, s>>>(c, shift, coarse, fine, nullptr);
+    else            k_prolong_rows<false><<<grd, blk, 0, s>>>(c, shift, coarse, fine, fixed);
     VFEM_HIP(hipGetLastError());
 }
 
