@@ -92,12 +92,34 @@ __device__ __forceinline__ double block_sum_256(double v, double *sh) {
 
 constexpr int DOT_BLOCKS = 1024;
 
+// The element loops of the PCG vector kernels take two consecutive doubles per thread and step -- one 16-byte access where the
+// arrays are 16-byte aligned (VEC; otherwise two 8-byte accesses to the same elements, so the partition and the order of a sum do
+// not depend on the alignment); an odd last element goes to the first thread of the grid after its pairs.
+template <bool VEC>
+__device__ __forceinline__ void load2(const double *p, long long i, double &x0, double &x1) {
+    if (VEC) { const double2 v = *reinterpret_cast<const double2 *>(p + i); x0 = v.x; x1 = v.y; }
+    else { x0 = p[i]; x1 = p[i + 1]; }
+}
+template <bool VEC>
+__device__ __forceinline__ void store2(double *p, long long i, double x0, double x1) {
+    if (VEC) *reinterpret_cast<double2 *>(p + i) = make_double2(x0, x1);
+    else { p[i] = x0; p[i + 1] = x1; }
+}
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <bool VEC>
 __global__ void __launch_bounds__(256) k_dot_partial(long long n, const double *__restrict__ a, const double *__restrict__ b,
                                                      double *__restrict__ partial) {
     __shared__ double sh[4];
     double acc = 0.0;
-    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
-        acc = fma(a[i], b[i], acc);
+    const long long t0 = (long long) blockIdx.x * blockDim.x + threadIdx.x, nt = (long long) gridDim.x * blockDim.x;
+    for (long long i = 2 * t0; i + 1 < n; i += 2 * nt) {
+        double a0, a1, b0, b1;
+        load2<VEC>(a, i, a0, a1); load2<VEC>(b, i, b0, b1);
+        acc = fma(a0, b0, acc);
+        acc = fma(a1, b1, acc);
+    }
+    if ((n & 1) && t0 == 0) acc = fma(a[n - 1], b[n - 1], acc);
     const double t = block_sum_256(acc, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
@@ -112,34 +134,55 @@ __global__ void __launch_bounds__(256) k_dot_final(int nparts, const double *__r
 
 // zeroDirichlet(bm) and a . bm in one pass over both (bm is written only where a component is constrained); same partition and
 // order of the sum as k_dot_partial, so the value equals launch_zero_dirichlet + launch_dot bit for bit
+template <bool VEC>
 __global__ void __launch_bounds__(256) k_dot_masked_partial(long long n, const double *__restrict__ a, double *__restrict__ bm,
                                                             const uint8_t *__restrict__ mask, double *__restrict__ partial) {
     __shared__ double sh[4];
     double acc = 0.0;
-    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
-        double v = bm[i];
+    const long long t0 = (long long) blockIdx.x * blockDim.x + threadIdx.x, nt = (long long) gridDim.x * blockDim.x;
+    auto masked = [&](long long i, double v) {
         const long long node = i / 3;
         if ((mask[node] >> (int) (i - 3 * node)) & 1) { v = 0.0; bm[i] = 0.0; }
-        acc = fma(a[i], v, acc);
+        return v;
+    };
+    for (long long i = 2 * t0; i + 1 < n; i += 2 * nt) {
+        double a0, a1, v0, v1;
+        load2<VEC>(a, i, a0, a1); load2<VEC>(bm, i, v0, v1);
+        acc = fma(a0, masked(i, v0), acc);
+        acc = fma(a1, masked(i + 1, v1), acc);
     }
+    if ((n & 1) && t0 == 0) acc = fma(a[n - 1], masked(n - 1, bm[n - 1]), acc);
     const double t = block_sum_256(acc, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 void launch_dot_zero_dirichlet(long long n, const double *a, double *bm, const uint8_t *mask, double *scratch, double *out, hipStream_t s) {
-    k_dot_masked_partial<<<DOT_BLOCKS, 256, 0, s>>>(n, a, bm, mask, scratch);
+    if (aligned16(a) && aligned16(bm)) k_dot_masked_partial<true><<<DOT_BLOCKS, 256, 0, s>>>(n, a, bm, mask, scratch);
+    else k_dot_masked_partial<false><<<DOT_BLOCKS, 256, 0, s>>>(n, a, bm, mask, scratch);
     k_dot_final<<<1, 256, 0, s>>>(DOT_BLOCKS, scratch, out);
     VFEM_HIP(hipGetLastError());
 }
 
 // x += alpha d, r -= alpha Ad and ||r||^2 of the new residual in one pass (alpha = sc[0] / sc[2]); the sum is partitioned and
 // ordered as k_dot_partial's
+template <bool VEC>
 __global__ void __launch_bounds__(256) k_pcg_step_dot(long long n, double *__restrict__ x, double *__restrict__ r,
                                                       const double *__restrict__ dv, const double *__restrict__ Ad,
                                                       const double *__restrict__ sc, double *__restrict__ partial) {
     __shared__ double sh[4];
     const double alpha = sc[0] / sc[2];
     double acc = 0.0;
-    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+    const long long t0 = (long long) blockIdx.x * blockDim.x + threadIdx.x, nt = (long long) gridDim.x * blockDim.x;
+    for (long long i = 2 * t0; i + 1 < n; i += 2 * nt) {
+        double x0, x1, d0, d1, r0, r1, q0, q1;
+        load2<VEC>(x, i, x0, x1); load2<VEC>(dv, i, d0, d1); load2<VEC>(r, i, r0, r1); load2<VEC>(Ad, i, q0, q1);
+        store2<VEC>(x, i, fma(alpha, d0, x0), fma(alpha, d1, x1));
+        const double n0 = fma(-alpha, q0, r0), n1 = fma(-alpha, q1, r1);
+        store2<VEC>(r, i, n0, n1);
+        acc = fma(n0, n0, acc);
+        acc = fma(n1, n1, acc);
+    }
+    if ((n & 1) && t0 == 0) {
+        const long long i = n - 1;
         x[i] = fma(alpha, dv[i], x[i]);
         const double rn = fma(-alpha, Ad[i], r[i]);
         r[i] = rn;
@@ -150,26 +193,37 @@ __global__ void __launch_bounds__(256) k_pcg_step_dot(long long n, double *__res
 }
 void launch_pcg_step_dot(long long n, double *x, double *r, const double *dv, const double *Ad, const double *sc, double *scratch,
                          double *rr_out, hipStream_t s) {
-    k_pcg_step_dot<<<DOT_BLOCKS, 256, 0, s>>>(n, x, r, dv, Ad, sc, scratch);
+    if (aligned16(x) && aligned16(r) && aligned16(dv) && aligned16(Ad)) k_pcg_step_dot<true><<<DOT_BLOCKS, 256, 0, s>>>(n, x, r, dv, Ad, sc, scratch);
+    else k_pcg_step_dot<false><<<DOT_BLOCKS, 256, 0, s>>>(n, x, r, dv, Ad, sc, scratch);
     k_dot_final<<<1, 256, 0, s>>>(DOT_BLOCKS, scratch, rr_out);
     VFEM_HIP(hipGetLastError());
 }
 
 void launch_dot(long long n, const double *a, const double *b, double *scratch, double *out, hipStream_t s) {
-    k_dot_partial<<<DOT_BLOCKS, 256, 0, s>>>(n, a, b, scratch);
+    if (aligned16(a) && aligned16(b)) k_dot_partial<true><<<DOT_BLOCKS, 256, 0, s>>>(n, a, b, scratch);
+    else k_dot_partial<false><<<DOT_BLOCKS, 256, 0, s>>>(n, a, b, scratch);
     k_dot_final<<<1, 256, 0, s>>>(DOT_BLOCKS, scratch, out);
     VFEM_HIP(hipGetLastError());
 }
 
 // d = s + (rMr / rMr_old) d   (MG.hh:717-718); scalars live in HBM so the host never stalls on them
+template <bool VEC>
 __global__ void __launch_bounds__(256) k_pcg_direction(long long n, const double *__restrict__ sv, double *__restrict__ dv,
                                                        const double *__restrict__ sc, int first) {
     const double beta = first ? 0.0 : sc[0] / sc[1];
-    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
-        dv[i] = first ? sv[i] : fma(beta, dv[i], sv[i]);
+    const long long t0 = (long long) blockIdx.x * blockDim.x + threadIdx.x, nt = (long long) gridDim.x * blockDim.x;
+    for (long long i = 2 * t0; i + 1 < n; i += 2 * nt) {
+        double s0, s1, d0 = 0.0, d1 = 0.0;
+        load2<VEC>(sv, i, s0, s1);
+        if (!first) load2<VEC>(dv, i, d0, d1);
+        store2<VEC>(dv, i, first ? s0 : fma(beta, d0, s0), first ? s1 : fma(beta, d1, s1));
+    }
+    if ((n & 1) && t0 == 0) dv[n - 1] = first ? sv[n - 1] : fma(beta, dv[n - 1], sv[n - 1]);
 }
 void launch_pcg_direction(long long n, const double *sv, double *dv, const double *sc, int first, hipStream_t s) {
-    k_pcg_direction<<<grid_for(n, 256), 256, 0, s>>>(n, sv, dv, sc, first);
+    const unsigned grid = (unsigned) std::min<long long>((n / 2 + 255) / 256 + 1, 1 << 20);
+    if (aligned16(sv) && aligned16(dv)) k_pcg_direction<true><<<grid, 256, 0, s>>>(n, sv, dv, sc, first);
+    else k_pcg_direction<false><<<grid, 256, 0, s>>>(n, sv, dv, sc, first);
     VFEM_HIP(hipGetLastError());
 }
 
