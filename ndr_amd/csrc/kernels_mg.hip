@@ -796,6 +796,16 @@ __device__ __forceinline__ void cm_index(const Dims &d, int i, int j, int k, lon
     base = 243 * before + (q >> 6) * (243 * 64) + (q & 63);
     stride = 64;
 }
+// padded number of nodes of the colours before (ci, cj, ck): cm_index's `before`
+__device__ __forceinline__ long long cm_colour_start(const Dims &d, int ci, int cj, int ck) {
+    const long long nx[2] = {(d.NX + 1) >> 1, d.NX >> 1}, ny[2] = {(d.NY + 1) >> 1, d.NY >> 1}, nz[2] = {(d.NZ + 1) >> 1, d.NZ >> 1};
+    long long before = 0;
+    const int c = ci * 4 + cj * 2 + ck;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (q < c) before += cm_padded(nx[(q >> 2) & 1] * ny[(q >> 1) & 1] * nz[q & 1]);
+    return before;
+}
 long long stencil_storage_doubles(const Dims &d) {
     const long long nx[2] = {(d.NX + 1) >> 1, d.NX >> 1}, ny[2] = {(d.NY + 1) >> 1, d.NY >> 1}, nz[2] = {(d.NZ + 1) >> 1, d.NZ >> 1};
     long long total = 0;
@@ -947,10 +957,12 @@ __global__ void __launch_bounds__(192) k_gs_color_stencil_split(Dims d, const do
     __shared__ double part[2][3][64];
     const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int cntx = (d.NX - 1 - cx) / 2 + 1, cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
-    const long long q0 = (long long) blockIdx.x * 64 + lane, total = (long long) cntx * cnty * cntz;
+    // (32-bit index arithmetic: the launcher checks that a colour has fewer than 2^31 nodes; the 64-bit divisions were ~200 of the
+    // kernel's ~600 instructions per lane)
+    const unsigned q0 = blockIdx.x * 64u + (unsigned) lane, total = (unsigned) cntx * (unsigned) cnty * (unsigned) cntz;
     const bool live = q0 < total;
-    const long long q = live ? q0 : total - 1;
-    const int iq = (int) (q / ((long long) cnty * cntz)), rem = (int) (q - (long long) iq * cnty * cntz), jq = rem / cntz;
+    const unsigned q = live ? q0 : total - 1u, pc = (unsigned) cnty * (unsigned) cntz;
+    const int iq = (int) (q / pc), rem = (int) (q - (unsigned) iq * pc), jq = rem / cntz;
     const int i = 2 * iq + cx, j = 2 * jq + cy, k = 2 * (rem - jq * cntz) + cz;
     const long long n = nidx(d, i, j, k);
     long long sbase, scnt;
@@ -998,17 +1010,16 @@ void launch_stencil_node_major(const Dims &d, const double *St, double *Sn, hipS
 __global__ void __launch_bounds__(256) k_gs_color_stencil_wave(Dims d, const double *__restrict__ Sn, double *__restrict__ u,
                                                                const double *__restrict__ b, const uint8_t *__restrict__ mask,
                                                                int cx, int cy, int cz, int forward) {
-    const int cntx = (d.NX - 1 - cx) / 2 + 1, cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
-    const long long q = (long long) blockIdx.x * 4 + threadIdx.y;              // colour-local node index of this wave
-    if (q >= (long long) cntx * cnty * cntz) return;
+    // the grid is (groups of four nodes along z, rows, planes) of the colour: no division on the way to the node -- a launch of
+    // this kernel is one latency chain, and the 64-bit divisions of a flat node number were a microsecond of it
+    const int cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
+    const int kq = blockIdx.x * 4 + threadIdx.y, jq = blockIdx.y, iq = blockIdx.z;
+    if (kq >= cntz) return;
     const int lane = threadIdx.x;
-    const int iq = (int) (q / ((long long) cnty * cntz)), rem = (int) (q - (long long) iq * cnty * cntz), jq = rem / cntz;
-    const int i = 2 * iq + cx, j = 2 * jq + cy, k = 2 * (rem - jq * cntz) + cz;
+    const int i = 2 * iq + cx, j = 2 * jq + cy, k = 2 * kq + cz;
     const long long n = nidx(d, i, j, k);
-    long long sbase, scnt;
-    cm_index(d, i, j, k, sbase, scnt);
-    // tile-major base = 243 * 64 * tile + lane-in-tile  ->  padded colour-major number of the node
-    const double *row = Sn + ((sbase / (243 * 64)) * 64 + sbase % 64) * 243;
+    // padded colour-major number of the node (cm_index: the 64-node tiles of the earlier colours, then its place in its own)
+    const double *row = Sn + (cm_colour_start(d, cx, cy, cz) + ((long long) iq * cnty + jq) * cntz + kq) * 243;
     // what the solve of lane 0 needs is requested with the row (wave-uniform addresses): a launch of this kernel is one latency
     // chain, and loads issued after the reduction would add a second memory round trip to it
     const double bn0 = b[3 * n], bn1 = b[3 * n + 1], bn2 = b[3 * n + 2], un0 = u[3 * n], un1 = u[3 * n + 1], un2 = u[3 * n + 2];
@@ -1047,8 +1058,8 @@ void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const do
         const int cntx = (d.NX - 1 - cx) / 2 + 1, cnty = (d.NY - 1 - cy) / 2 + 1, cntz = (d.NZ - 1 - cz) / 2 + 1;
         const long long cnt = (long long) cntx * cnty * cntz;
         dim3 blk(64, 4, 1), grd((unsigned) ((cnt + 255) / 256), 1, 1);
-        if (Sn) k_gs_color_stencil_wave<<<dim3((unsigned) ((cnt + 3) / 4)), blk, 0, s>>>(d, Sn, u, b, mask, cx, cy, cz, forward);
-        else if (stencil_split) k_gs_color_stencil_split<<<dim3((unsigned) ((cnt + 63) / 64)), dim3(64, 3, 1), 0, s>>>(d, S, u, b, mask, cx, cy, cz, forward);
+        if (Sn) k_gs_color_stencil_wave<<<dim3((unsigned) ((cntz + 3) / 4), (unsigned) cnty, (unsigned) cntx), blk, 0, s>>>(d, Sn, u, b, mask, cx, cy, cz, forward);
+        else if (stencil_split && cnt < (1LL << 31)) k_gs_color_stencil_split<<<dim3((unsigned) ((cnt + 63) / 64)), dim3(64, 3, 1), 0, s>>>(d, S, u, b, mask, cx, cy, cz, forward);
         else k_gs_color_stencil<<<grd, blk, 0, s>>>(d, S, u, b, mask, cx, cy, cz, forward);
     }
     VFEM_HIP(hipGetLastError());
