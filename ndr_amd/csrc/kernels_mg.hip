@@ -1116,42 +1116,14 @@ void launch_restrict(const Dims &c, int fineNX, int shift, const double *fine, d
     VFEM_HIP(hipGetLastError());
 }
 
-template <bool ACC>
-__global__ void __launch_bounds__(256) k_prolong(Dims c, int shift, const double *__restrict__ coarse, double *__restrict__ fine,
-                                                 const uint8_t *__restrict__ fixed) {
-    const int FY = 2 * c.ny + 1, FZ = 2 * c.nz + 1;
-    const int qq = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x;      // lanes packed over the nodes of an x-plane
-    if (qq >= FY * FZ) return;
-    const int j = qq / FZ, k = qq - j * FZ, i = blockIdx.z;
-    const int ig = i - shift;                     // >= 0: shift is 0 or -1
-    const int i0 = ig >> 1, j0 = j >> 1, k0 = k >> 1;
-    const int oi = ig & 1, oj = j & 1, ok = k & 1;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int qi = (q >> 2) & 1, qj = (q >> 1) & 1, qk = q & 1;
-        if ((qi && !oi) || (qj && !oj) || (qk && !ok)) continue;
-        if (i0 + qi > c.NX - 1) continue;         // beyond the local slab (only for ghost planes, refreshed by the exchange)
-        const double w = (oi ? 0.5 : 1.0) * (oj ? 0.5 : 1.0) * (ok ? 0.5 : 1.0);
-        const long long m = nidx(c, i0 + qi, j0 + qj, k0 + qk);
-        a0 = fma(w, coarse[3 * m], a0);
-        a1 = fma(w, coarse[3 * m + 1], a1);
-        a2 = fma(w, coarse[3 * m + 2], a2);
-    }
-    const long long n = ((long long) i * FY + j) * FZ + k;
-    if (ACC) { fine[3 * n] += a0; fine[3 * n + 1] += a1; fine[3 * n + 2] += a2; }
-    else {
-        const unsigned f = fixed ? fixed[n] : 0u;
-        fine[3 * n] = (f & 1) ? 0.0 : a0; fine[3 * n + 1] = (f & 2) ? 0.0 : a1; fine[3 * n + 2] = (f & 4) ? 0.0 : a2;
-    }
-}
-
-// The same interpolation row by row with whole-line stores.  A wave owns 128 consecutive nodes of a fine row (i, j): lane l loads
+// Interpolation (MG.hh:116-142) row by row with whole-line stores.  fixed (optional, !ACC): Dirichlet mask of the fine level, the
+// interpolated field gets zeros at its components (the residual system's Dirichlet values, MG.hh:521-523, without a pass of their
+// own).  A wave owns 128 consecutive nodes of a fine row (i, j): lane l loads
 // coarse node k0 = 64 chunk + l of the (up to) four coarse rows the fine row depends on (24 bytes each; k0 + 1 comes from the next
 // lane by a DPP wave shift), forms fine nodes 2 k0 and 2 k0 + 1, and the 3 KB of results go through LDS so that every store
-// instruction writes 1 KB of consecutive bytes.  The node-per-lane kernel above issues 16 loads and 2 strided stores per fine node
-// (2.8 TB/s of useful bytes at 512^3, bound by the rate of its memory instructions); this one 6 loads and 3 stores per 128.
-// Every fine node is summed in the same order: same values bit for bit.
+// instruction writes 1 KB of consecutive bytes.  The node-per-lane kernel of rounds 1-2 issued 16 loads and 2 strided stores per
+// fine node (2.8 TB/s of useful bytes at 512^3, bound by the rate of its memory instructions); this one 6 loads and 3 stores per
+// 128.  Every fine node is summed in that kernel's order (coarse neighbours lexicographic in (x, y, z)): same values bit for bit.
 template <bool ACC>
 __global__ void __launch_bounds__(256) k_prolong_rows(Dims c, int shift, const double *__restrict__ coarse, double *__restrict__ fine,
                                                       const uint8_t *__restrict__ fixed) {
