@@ -1075,43 +1075,68 @@ void launch_gs_sweep_stencil(const Dims &d, const double *S, double *u, const do
 // rows and, inside a row, over 2k-1, 2k, 2k+1 as before: same values bit for bit.
 __global__ void __launch_bounds__(256) k_restrict(Dims c, int FX, int shift, const double *__restrict__ fine,
                                                   double *__restrict__ coarse, double *__restrict__ zeroed) {
-    const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z;
+    // a wave = 64 coarse nodes along z of the rows (i, j) and (i + 1, j), i = 2 blockIdx.z: the fine plane between the two coarse
+    // planes is loaded once for both (the x-neighbours of a launch lie a plane apart: what one wave does not share comes back
+    // through the fabric, profiles/r03_transfers_pmc.json)
+    const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, i = 2 * blockIdx.z;
     if (j >= c.NY) return;                                                 // (wave-uniform)
     const int FY = 2 * c.ny + 1, FZ = 2 * c.nz + 1;
     const bool live = k < c.NZ, lo = live && k > 0, hi = live && 2 * k + 1 < FZ, first = threadIdx.x == 0;
-    double a[3] = {0.0, 0.0, 0.0};
+    const bool second = i + 1 < c.NX;                                       // (wave-uniform)
+    double a[3] = {0.0, 0.0, 0.0}, a2[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int di = t / 3 - 1, dj = t % 3 - 1, fi = 2 * i + shift + di, fj = 2 * j + dj;
-        if (fi < 0 || fi >= FX || fj < 0 || fj >= FY) continue;             // (wave-uniform)
-        const double w = (di ? 0.5 : 1.0) * (dj ? 0.5 : 1.0);
-        const double *p = fine + 3 * (((long long) fi * FY + fj) * FZ + (live ? 2 * k : 0));
-        double f0[3], f1[3], fm[3];
+    for (int pl = 0; pl < 5; ++pl) {                                        // fine planes 2 i + shift - 1 ... + 3
+        const int fi = 2 * i + shift - 1 + pl;
+        if (fi < 0 || fi >= FX || (pl > 2 && !second)) continue;            // (wave-uniform)
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-            f0[cc] = p[cc];
-            f1[cc] = hi ? p[3 + cc] : 0.0;
-        }
+        for (int dj = -1; dj <= 1; ++dj) {
+            const int fj = 2 * j + dj;
+            if (fj < 0 || fj >= FY) continue;                               // (wave-uniform)
+            const double *p = fine + 3 * (((long long) fi * FY + fj) * FZ + (live ? 2 * k : 0));
+            double f0[3], f1[3], fm[3];
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-            fm[cc] = lane_below(f1[cc]);
-            if (first && lo) fm[cc] = p[cc - 3];
-        }
+            for (int cc = 0; cc < 3; ++cc) {
+                f0[cc] = p[cc];
+                f1[cc] = hi ? p[3 + cc] : 0.0;
+            }
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-            if (lo) a[cc] = fma(0.5 * w, fm[cc], a[cc]);
-            a[cc] = fma(w, f0[cc], a[cc]);
-            if (hi) a[cc] = fma(0.5 * w, f1[cc], a[cc]);
+            for (int cc = 0; cc < 3; ++cc) {
+                fm[cc] = lane_below(f1[cc]);
+                if (first && lo) fm[cc] = p[cc - 3];
+            }
+            if (pl <= 2) {                                                  // di = pl - 1 for coarse plane i
+                const double w = (pl != 1 ? 0.5 : 1.0) * (dj ? 0.5 : 1.0);
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    if (lo) a[cc] = fma(0.5 * w, fm[cc], a[cc]);
+                    a[cc] = fma(w, f0[cc], a[cc]);
+                    if (hi) a[cc] = fma(0.5 * w, f1[cc], a[cc]);
+                }
+            }
+            if (pl >= 2 && second) {                                        // di = pl - 3 for coarse plane i + 1
+                const double w = (pl != 3 ? 0.5 : 1.0) * (dj ? 0.5 : 1.0);
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    if (lo) a2[cc] = fma(0.5 * w, fm[cc], a2[cc]);
+                    a2[cc] = fma(w, f0[cc], a2[cc]);
+                    if (hi) a2[cc] = fma(0.5 * w, f1[cc], a2[cc]);
+                }
+            }
         }
     }
     if (!live) return;
     const long long n = nidx(c, i, j, k);
     coarse[3 * n] = a[0]; coarse[3 * n + 1] = a[1]; coarse[3 * n + 2] = a[2];
     if (zeroed) { zeroed[3 * n] = 0.0; zeroed[3 * n + 1] = 0.0; zeroed[3 * n + 2] = 0.0; }      // the coarse initial guess of the V-cycle
+    if (second) {
+        const long long n2 = nidx(c, i + 1, j, k);
+        coarse[3 * n2] = a2[0]; coarse[3 * n2 + 1] = a2[1]; coarse[3 * n2 + 2] = a2[2];
+        if (zeroed) { zeroed[3 * n2] = 0.0; zeroed[3 * n2 + 1] = 0.0; zeroed[3 * n2 + 2] = 0.0; }
+    }
 }
 
 void launch_restrict(const Dims &c, int fineNX, int shift, const double *fine, double *coarse, hipStream_t s, double *zeroed) {
-    dim3 blk(64, 4, 1), grd((c.NZ + 63) / 64, (c.NY + 3) / 4, c.NX);
+    dim3 blk(64, 4, 1), grd((c.NZ + 63) / 64, (c.NY + 3) / 4, (c.NX + 1) / 2);
     k_restrict<<<grd, blk, 0, s>>>(c, fineNX, shift, fine, coarse, zeroed);
     VFEM_HIP(hipGetLastError());
 }
