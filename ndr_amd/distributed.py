@@ -72,9 +72,10 @@ class SlabPartition:
 class HaloExchanger:
     """Refreshes the ghost node planes of a nodal field [n_planes * plane, 3] from the neighbours."""
 
-    def __init__(self, part, group=None):
+    def __init__(self, part, group=None, proxy=False):
         self.p = part
         self.group = group
+        self.proxy = proxy      # rank proxy (tools/rank_proxy.py): no peers exist; a message becomes a device copy of the same bytes
 
     def start(self, field, left=True, right=True):
         """Begin the exchange of the two interface planes with each neighbour (`left` / `right`: only that side) and return a
@@ -87,9 +88,18 @@ class HaloExchanger:
         if p.world == 1:
             return None
         v = field.view(p.n_planes, -1)
+        w = getattr(p, "halo_width", 1)        # ghost node planes per side (degree-2 slabs: 4), contiguous in memory
+        if self.proxy:
+            # what a neighbour would have sent is replaced by this rank's own planes: the same number of bytes moves, on the device
+            n = 0
+            if p.gl and left:
+                v[p.first_owned - w:p.first_owned].copy_(v[p.first_owned + 1:p.first_owned + 1 + w]); n += 1
+            if p.gr and right:
+                v[p.last_owned + 1:p.last_owned + 1 + w].copy_(v[p.last_owned - w:p.last_owned]); n += 1
+            self.messages = getattr(self, "messages", 0) + n
+            return None
         staged = field.is_cuda and dist.get_backend(self.group) == "gloo"
         ops, recvs = [], []
-        w = getattr(p, "halo_width", 1)        # ghost node planes per side (degree-2 slabs: 4), contiguous in memory
 
         def add(send_first, recv_first, peer):
             send, recv = slice(send_first, send_first + w), slice(recv_first, recv_first + w)
@@ -129,7 +139,7 @@ class HaloExchanger:
         av = a.view(p.n_planes, -1)[lo:hi]
         bv = b.view(p.n_planes, -1)[lo:hi]
         s = (av * bv).sum().reshape(1)
-        if p.world > 1:
+        if p.world > 1 and not self.proxy:
             if s.is_cuda and dist.get_backend(self.group) == "gloo":
                 h = s.cpu()
                 dist.all_reduce(h, group=self.group)
@@ -420,15 +430,23 @@ class DistributedMGSolver:
     """Slab-decomposed multigrid PCG on the HIP kernels (one instance per rank)."""
 
     def __init__(self, ne, bbmin, bbmax, bc_path, material_path, num_levels, dist_levels=None, E0=1.0, Emin=1e-4,
-                 gamma=3.0, group=None):
+                 gamma=3.0, group=None, proxy=None):
+        """proxy = (world, rank): build the slab of ONE rank of `world` in a single process (8-rank readiness measured on one
+        GPU, tools/rank_proxy.py): every message becomes a device copy of the same size out of this rank's own planes and the
+        all-reduces are skipped, so the VALUES are meaningless -- only the work, the launches and the host-side cost of one
+        rank's iteration are those of the real run."""
         import ctypes
         from . import _lib
         from . import pyVoxelFEM as pv
         self._ct, self._lib_mod, self._pv = ctypes, _lib, pv
         self.lib = _lib.load()
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.proxy = proxy is not None
+        if self.proxy:
+            self.world, self.rank = int(proxy[0]), int(proxy[1])
+        else:
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+            self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.ne = tuple(int(v) for v in ne)
         self.L = int(num_levels)
         if dist_levels is None:
@@ -486,7 +504,7 @@ class DistributedMGSolver:
         h2 = ctypes.c_void_p()
         _lib.check(self.lib.vfem_mg_create_slab(ctypes.byref(h2), self.lsim._h, len(self.geom), arr, mptrs))
         self.lmg = h2
-        self.halos = [HaloExchanger(g, group) for g in self.geom]
+        self.halos = [HaloExchanger(g, group, self.proxy) for g in self.geom]
         for hx, g in zip(self.halos, self.geom):
             hx.p.world, hx.p.rank = self.world, self.rank
         z = lambda g: torch.zeros((g.n_planes * g.plane, 3), dtype=torch.float64, device=self.dev)
@@ -529,7 +547,7 @@ class DistributedMGSolver:
         self._lib_mod.check(status)
 
     def _allreduce(self, t):
-        if self.world > 1:
+        if self.world > 1 and not self.proxy:
             if t.is_cuda and dist.get_backend(self.group) == "gloo":
                 h = t.cpu()
                 dist.all_reduce(h, group=self.group)
@@ -564,10 +582,13 @@ class DistributedMGSolver:
             raise RuntimeError("slab thinner than the padding of the local hierarchy")
         local = torch.empty((lo_need + own.shape[0] + hi_need, layer), dtype=torch.float64, device=own.device)
         local[lo_need:lo_need + own.shape[0]] = own
-        staged = own.is_cuda and self.world > 1 and dist.get_backend(self.group) == "gloo"
+        staged = own.is_cuda and self.world > 1 and not self.proxy and dist.get_backend(self.group) == "gloo"
         ops, recvs = [], []
 
         def add(send, recv_slice, peer):
+            if self.proxy:
+                local[recv_slice].copy_(send)
+                return
             sb = send.contiguous().cpu() if staged else send.contiguous()
             rb = torch.empty_like(sb) if staged else torch.empty_like(local[recv_slice])
             ops.append(dist.P2POp(dist.isend, sb, peer, self.group))
@@ -597,6 +618,9 @@ class DistributedMGSolver:
         self._chk(self._mg("export_level_ke")(self.lmg, self.T, child.gl + child.extra_lo, count, self._p(mine), self._s()))
         if self.world == 1:
             whole = mine
+        elif self.proxy:
+            counts = [(self.part.starts[r + 1] - self.part.starts[r]) >> self.T for r in range(self.world)]
+            whole = torch.cat([mine[:c * nyz * KE] if c <= count else mine.repeat(2)[:c * nyz * KE] for c in counts])
         else:
             counts = [(self.part.starts[r + 1] - self.part.starts[r]) >> self.T for r in range(self.world)]
             staged = dist.get_backend(self.group) == "gloo"

@@ -27,13 +27,19 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
-def build_lib(force=False):
-    """Compile voxel_ref.c -> oracle/_build/libvoxel_ref.so (gcc, OpenMP)."""
+def build_lib(force=False, native=False):
+    """Compile voxel_ref.c -> oracle/_build/libvoxel_ref.so (gcc -O2, OpenMP): the checker the tests use.
+    native=True: a second copy with the reference's own optimisation flags (VoxelFEM/CMakeLists.txt:43: -O3 -march=native
+    -ffast-math ...), always rebuilt on the host it will run on -- only bench.py's cpu_baseline leg times that one."""
     out_dir = os.path.join(_HERE, "_build")
-    so = os.path.join(out_dir, "libvoxel_ref.so")
     src = os.path.join(_HERE, "voxel_ref.c")
+    os.makedirs(out_dir, exist_ok=True)
+    if native:
+        so = os.path.join(out_dir, "libvoxel_ref_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-ffast-math", "-funroll-loops", "-fopenmp", "-fPIC", "-shared", "-o", so, src, "-lm"])
+        return so
+    so = os.path.join(out_dir, "libvoxel_ref.so")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        os.makedirs(out_dir, exist_ok=True)
         subprocess.check_call(["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", "-o", so, src, "-lm"])
     return so
 
@@ -44,6 +50,14 @@ def lib():
         _LIB = ctypes.CDLL(build_lib())
         _LIB.ref_max_threads.restype = ctypes.c_int
     return _LIB
+
+
+def use_native_build(on=True):
+    """bench.py only: route the C loops through the -O3 -march=native -ffast-math copy (on) or back through the -O2 checker (off)."""
+    global _LIB
+    _LIB = ctypes.CDLL(build_lib(native=True)) if on else None
+    if _LIB is not None:
+        _LIB.ref_max_threads.restype = ctypes.c_int
 
 
 def _p(a):

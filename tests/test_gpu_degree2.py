@@ -56,6 +56,42 @@ def test_q2_operator_properties_at_size():
     assert float(t.applyK_device(ones).abs().max()) < 1e-10 * float(Ku.abs().max())
 
 
+def test_q2_apply_at_config5_size_512_cubed():
+    """BASELINE config 5's own grid (512^3 elements of degree 2 = 1025^3 nodes, 3.2 G dofs) on one GPU: the marching apply against
+    the dense-matrix gather kernel (which shares no code with it) on the whole field, symmetry, rigid-body null space, positivity"""
+    import torch
+    from ndr_amd import _lib, pyVoxelFEM as pv
+    lib = _lib.load()
+    ne = (512, 512, 512)
+    t = pv.TensorProductSimulator([2, 2, 2], ([0, 0, 0], [1.0, 1.0, 1.0]), ne)
+    t.readMaterial(MATERIAL)
+    g = torch.Generator(device="cuda").manual_seed(17)
+    t.setElementDensities(torch.rand(t.numElements(), dtype=torch.float64, device="cuda", generator=g))
+    u = torch.randn((t.numNodes(), 3), dtype=torch.float64, device="cuda", generator=g)
+    Ku = t.applyK_device(u)
+    _lib.check(lib.vfem_gsim_set_option(t._h, 6, 1))              # VFEM_OPT_Q2_IMPL = dense gather
+    Kg = t.applyK_device(u)
+    _lib.check(lib.vfem_gsim_set_option(t._h, 6, 0))
+    scale = float(Kg.abs().max())
+    Kg -= Ku
+    assert float(Kg.abs().max()) < 1e-12 * scale
+    del Kg
+    v = torch.randn((t.numNodes(), 3), dtype=torch.float64, device="cuda", generator=g)
+    Kv = t.applyK_device(v)
+    a, b = float((v * Ku).sum()), float((u * Kv).sum())
+    assert abs(a - b) < 1e-11 * float(Ku.norm() * v.norm())
+    assert float((u * Ku).sum()) > 0
+    del Kv, v
+    assert float(t.applyK_device(torch.ones_like(u)).abs().max()) < 1e-10 * scale
+    # rigid rotation about z: u = (-y, x, 0)
+    n1 = 2 * ne[0] + 1
+    ax = torch.arange(n1, dtype=torch.float64, device="cuda") / (n1 - 1)
+    rot = torch.zeros_like(u).reshape(n1, n1, n1, 3)
+    rot[..., 0] = -ax[None, :, None]
+    rot[..., 1] = ax[:, None, None]
+    assert float(t.applyK_device(rot.reshape(-1, 3)).abs().max()) < 1e-10 * scale
+
+
 @pytest.mark.parametrize("ne", [(17, 6, 63), (16, 5, 130), (33, 9, 70), (70, 3, 3)])
 def test_q2_apply_kernels_agree_across_chunk_seams(ne):
     """the marching kernel (x-chunks with a lead-in element, z-chunks of 63 elements, two y colours), the pencil kernel and the
