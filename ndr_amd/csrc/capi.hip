@@ -1136,19 +1136,21 @@ int vfem_mlp_load_weights(vfem_mlp *m, const float *B, const float *W1, const fl
     up(m->W1f, W1, (size_t) m->nn * 2 * m->es);
     up(m->Whf, Wh, (size_t) nh * m->nn * m->nn);
     m->W1.alloc((size_t) m->nn * 2 * m->es);
-    launch_f32_to_f16((long long) m->nn * 2 * m->es, m->W1f.p, m->W1.p, nullptr);
+    launch_f32_to_f16_frag(m->nn, 2 * m->es, 0, m->W1f.p, m->W1.p, nullptr);
     m->W1h.alloc((size_t) m->nn * 2 * m->es);
     m->W1l.alloc((size_t) m->nn * 2 * m->es);
-    launch_split_f32((long long) m->nn * 2 * m->es, m->W1f.p, m->W1h.p, m->W1l.p, nullptr);
+    launch_split_f32_frag(m->nn, 2 * m->es, m->W1f.p, m->W1h.p, m->W1l.p, nullptr);
     m->Whh.alloc((size_t) nh * m->nn * m->nn);
     m->Whl.alloc((size_t) nh * m->nn * m->nn);
-    if (nh) launch_split_f32((long long) nh * m->nn * m->nn, m->Whf.p, m->Whh.p, m->Whl.p, nullptr);
+    for (int l = 0; l < nh; ++l)
+        launch_split_f32_frag(m->nn, m->nn, m->Whf.p + (size_t) l * m->nn * m->nn, m->Whh.p + (size_t) l * m->nn * m->nn, m->Whl.p + (size_t) l * m->nn * m->nn, nullptr);
     m->Wh.alloc((size_t) nh * m->nn * m->nn);
     m->WhT.alloc((size_t) nh * m->nn * m->nn);
     if (nh) {
-        launch_f32_to_f16((long long) nh * m->nn * m->nn, m->Whf.p, m->Wh.p, nullptr);
-        for (int l = 0; l < nh; ++l)
-            launch_transpose_f32_to_f16(m->nn, m->nn, m->Whf.p + (size_t) l * m->nn * m->nn, m->WhT.p + (size_t) l * m->nn * m->nn, nullptr);
+        for (int l = 0; l < nh; ++l) {
+            launch_f32_to_f16_frag(m->nn, m->nn, 0, m->Whf.p + (size_t) l * m->nn * m->nn, m->Wh.p + (size_t) l * m->nn * m->nn, nullptr);
+            launch_f32_to_f16_frag(m->nn, m->nn, 1, m->Whf.p + (size_t) l * m->nn * m->nn, m->WhT.p + (size_t) l * m->nn * m->nn, nullptr);
+        }
     }
     up(m->bias, biases, (size_t) (nh + 1) * m->nn);
     up(m->wout, wout, (size_t) m->nn);

@@ -59,16 +59,15 @@ struct APipe {
     __device__ __forceinline__ void load(int slot, int ks) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-            if (FULL || on[t]) ring[slot][t] = *reinterpret_cast<const h8_t *>(row[t] + ks * 16);
+            if (FULL || on[t]) ring[slot][t] = *reinterpret_cast<const h8_t *>(row[t] + ks * 512);
     }
     __device__ __forceinline__ void init(const _Float16 *W, int ldw, int wave, int ntiles, int lane, int total_ksteps) {
-        const int r = lane & 31, h = lane >> 5;
         total = total_ksteps;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int tile = wave + 8 * t;
             on[t] = FULL || tile < ntiles;
-            row[t] = W + (long long) ((on[t] ? tile : 0) * 32 + r) * ldw + 8 * h;
+            row[t] = W + ((long long) (on[t] ? tile : 0) * (ldw >> 4) * 64 + lane) * 8;       // fragment order [row tile][k-step][lane][8] (k_f32_to_f16_frag)
         }
 #pragma unroll
         for (int p = 0; p < MLP_PD; ++p)
@@ -532,6 +531,24 @@ __global__ void __launch_bounds__(256) k_adam(long long n, float *__restrict__ p
 void launch_adam(long long n, float *p, const float *g, float *m, float *v, float lr, float b1, float b2, float eps, int step, hipStream_t s) {
     const float bc1 = 1.f - powf(b1, (float) step), bc2 = 1.f - powf(b2, (float) step);
     k_adam<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s>>>(n, p, g, m, v, lr, b1, b2, eps, bc1, bc2);
+    VFEM_HIP(hipGetLastError());
+}
+
+// fp32 [N][K] (or, transposed = 1, the transpose of an fp32 [K][N]) -> fp16 in MFMA-fragment order [N / 32][K / 16][lane][8]: the A
+// operand of a (row tile, k-step) is one contiguous KB instead of 32 pieces of 32 bytes (kernels_mlp_x3.hip: k_split_f32_frag)
+__global__ void k_f32_to_f16_frag(int N, int K, int transposed, const float *__restrict__ in, _Float16 *__restrict__ out) {
+    const long long n = (long long) N * K;
+    const int nks = K / 16;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+        const int row = (int) (i / K), k = (int) (i - (long long) row * K);
+        const long long o = ((((long long) (row >> 5) * nks + (k >> 4)) * 64) + (row & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
+        out[o] = (_Float16) (transposed ? in[(long long) k * N + row] : in[i]);
+    }
+}
+void launch_f32_to_f16_frag(int N, int K, int transposed, const float *in, void *out, hipStream_t s) {
+    if (N % 32 || K % 16) throw Error("fragment-order weights need N % 32 == 0 and K % 16 == 0");
+    long long g = ((long long) N * K + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1;
+    k_f32_to_f16_frag<<<dim3((unsigned) g), dim3(256), 0, s>>>(N, K, transposed, in, (_Float16 *) out);
     VFEM_HIP(hipGetLastError());
 }
 

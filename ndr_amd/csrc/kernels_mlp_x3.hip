@@ -55,6 +55,27 @@ struct MlpX3Weights { const _Float16 *W1h, *W1l, *Whh, *Whl; };
 __global__ void __launch_bounds__(256) k_split_f32(long long n, const float *__restrict__ in, _Float16 *__restrict__ hi, _Float16 *__restrict__ lo) {
     for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) x3::split(in[i], hi[i], lo[i]);
 }
+// The same halves in MFMA-FRAGMENT order: the A operand of v_mfma_f32_32x32x16_f16 for the row tile T (32 rows) and k-step S is, per
+// lane (r = lane & 31, h = lane >> 5), the eight halves W[32 T + r][16 S + 8 h .. + 7].  Row-major, the 64 lanes of that load touch 32
+// rows = 32 separate 32-byte pieces: the forward kernel then sits on the L2's REQUEST rate (profiles/r04_mlp_x3_pmc.json: 99 % L2 hits,
+// 0.74 requests per clock and channel, waves 63 % of their time in s_waitcnt).  Stored as [T][S][lane][8] the load is one contiguous KB
+// = eight whole 128-byte lines, and successive k-steps of a tile follow each other in memory.
+__global__ void __launch_bounds__(256) k_split_f32_frag(int N, int K, const float *__restrict__ in, _Float16 *__restrict__ hi, _Float16 *__restrict__ lo) {
+    const long long n = (long long) N * K;
+    const int nks = K / 16;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+        const int row = (int) (i / K), k = (int) (i - (long long) row * K);
+        const long long o = ((((long long) (row >> 5) * nks + (k >> 4)) * 64) + (row & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
+        x3::split(in[i], hi[o], lo[o]);
+    }
+}
+void launch_split_f32_frag(int N, int K, const float *in, void *hi, void *lo, hipStream_t s) {
+    if (N % 32 || K % 16) throw Error("fragment-order weights need N % 32 == 0 and K % 16 == 0");
+    long long g = ((long long) N * K + 255) / 256;
+    if (g > 4096) g = 4096;
+    k_split_f32_frag<<<dim3((unsigned) (g < 1 ? 1 : g)), 256, 0, s>>>(N, K, in, (_Float16 *) hi, (_Float16 *) lo);
+    VFEM_HIP(hipGetLastError());
+}
 void launch_split_f32(long long n, const float *in, void *hi, void *lo, hipStream_t s) {
     long long g = (n + 255) / 256;
     if (g > 4096) g = 4096;
@@ -114,13 +135,14 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
             }
         }
     };
-    // weight fragments of k-step ks of a layer (row-major [N][K] halves): 8 consecutive k of one output row = one 16-byte load
+    // weight fragments of k-step ks of a layer (fragment order [row tile][k-step][lane][8 halves], k_split_f32_frag): one 16-byte load
+    // per lane, one contiguous KB per wave
     auto load_a = [&](const _Float16 *Wh_, const _Float16 *Wl_, int ldw, int ks, h8_t (&ah)[2], h8_t (&al)[2]) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const long long row = (long long) ((on[t] ? wave + 8 * t : 0) * 32 + r) * ldw + ks * 16 + 8 * h;
-            ah[t] = *reinterpret_cast<const h8_t *>(Wh_ + row);
-            al[t] = *reinterpret_cast<const h8_t *>(Wl_ + row);
+            const long long off = (((long long) (on[t] ? wave + 8 * t : 0) * (ldw >> 4) + ks) * 64 + lane) * 8;
+            ah[t] = *reinterpret_cast<const h8_t *>(Wh_ + off);
+            al[t] = *reinterpret_cast<const h8_t *>(Wl_ + off);
         }
     };
 
