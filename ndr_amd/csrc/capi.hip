@@ -1139,11 +1139,11 @@ int vfem_mlp_load_weights(vfem_mlp *m, const float *B, const float *W1, const fl
     launch_f32_to_f16_frag(m->nn, 2 * m->es, 0, m->W1f.p, m->W1.p, nullptr);
     m->W1h.alloc((size_t) m->nn * 2 * m->es);
     m->W1l.alloc((size_t) m->nn * 2 * m->es);
-    launch_split_f32_frag(m->nn, 2 * m->es, m->W1f.p, m->W1h.p, m->W1l.p, nullptr);
+    launch_split_f32_frag(m->nn, 2 * m->es, m->W1f.p, m->W1h.p, m->W1l.p, nullptr, m->es);
     m->Whh.alloc((size_t) nh * m->nn * m->nn);
     m->Whl.alloc((size_t) nh * m->nn * m->nn);
     for (int l = 0; l < nh; ++l)
-        launch_split_f32_frag(m->nn, m->nn, m->Whf.p + (size_t) l * m->nn * m->nn, m->Whh.p + (size_t) l * m->nn * m->nn, m->Whl.p + (size_t) l * m->nn * m->nn, nullptr);
+        launch_split_f32_frag(m->nn, m->nn, m->Whf.p + (size_t) l * m->nn * m->nn, m->Whh.p + (size_t) l * m->nn * m->nn, m->Whl.p + (size_t) l * m->nn * m->nn, nullptr, 0);
     m->Wh.alloc((size_t) nh * m->nn * m->nn);
     m->WhT.alloc((size_t) nh * m->nn * m->nn);
     if (nh) {

@@ -39,6 +39,27 @@ __device__ __forceinline__ void split(float x, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16) x;
     lo = (_Float16) ((x - (float) hi) * LO_SCALE);
 }
+// sin and cos of an fp32 argument together, to fp32 rounding (max error 9.2e-8 for |t| <= 1000, tools/ numpy check in DESIGN 3.5; numpy's own
+// fp32 sin: 7e-8): one Cody-Waite reduction by pi/2 in three fma steps (pi/2 = c1 + c2 + c3), the cephes single-precision minimax
+// polynomials on [-pi/4, pi/4], quadrant by the low bits of n.  ~25 instructions for the pair; two library calls (sinf, cosf) were ~90
+// and made feature generation 27 % of the SIMD time of the forward kernel (profiles/r04_mlp_x3_pmc.json: 1686 vector instructions per voxel).
+__device__ __forceinline__ void sincos_f32(float t, float &sn, float &cs) {
+    const float n = __builtin_rintf(t * 0.636619772367581343f);
+    float y = fmaf(-n, 1.5707963705062866f, t);
+    y = fmaf(-n, -4.371138828673793e-08f, y);
+    y = fmaf(-n, -1.7763568394002505e-15f, y);
+    const float z = y * y;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    const float s = fmaf(ps * z, y, y);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    const float c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+    const int q = (int) n;
+    const float a = (q & 1) ? c : s, b = (q & 1) ? s : c;
+    sn = (q & 2) ? -a : a;
+    cs = ((q + 1) & 2) ? -b : b;
+}
 __device__ __forceinline__ void voxel_xyz(const MlpArgs &a, long long v, float x[3]) {
     if (a.coords) { x[0] = a.coords[3 * v]; x[1] = a.coords[3 * v + 1]; x[2] = a.coords[3 * v + 2]; return; }
     v += a.v_offset;
@@ -60,20 +81,25 @@ __global__ void __launch_bounds__(256) k_split_f32(long long n, const float *__r
 // rows = 32 separate 32-byte pieces: the forward kernel then sits on the L2's REQUEST rate (profiles/r04_mlp_x3_pmc.json: 99 % L2 hits,
 // 0.74 requests per clock and channel, waves 63 % of their time in s_waitcnt).  Stored as [T][S][lane][8] the load is one contiguous KB
 // = eight whole 128-byte lines, and successive k-steps of a tile follow each other in memory.
-__global__ void __launch_bounds__(256) k_split_f32_frag(int N, int K, const float *__restrict__ in, _Float16 *__restrict__ hi, _Float16 *__restrict__ lo) {
+// pair_es > 0 (first layer): the K order is permuted so that a 64-wide chunk holds the sines of 32 rows of B followed by the cosines of
+// the same rows (the forward kernel forms both from one argument): logical feature f < es -> 64 (f / 32) + f % 32, f >= es -> the same + 32
+__global__ void __launch_bounds__(256) k_split_f32_frag(int N, int K, int pair_es, const float *__restrict__ in, _Float16 *__restrict__ hi, _Float16 *__restrict__ lo) {
     const long long n = (long long) N * K;
     const int nks = K / 16;
     for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
-        const int row = (int) (i / K), k = (int) (i - (long long) row * K);
+        const int row = (int) (i / K);
+        int k = (int) (i - (long long) row * K);
+        if (pair_es > 0) { const int f = k < pair_es ? k : k - pair_es; k = 64 * (f >> 5) + (f & 31) + (k < pair_es ? 0 : 32); }
         const long long o = ((((long long) (row >> 5) * nks + (k >> 4)) * 64) + (row & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
         x3::split(in[i], hi[o], lo[o]);
     }
 }
-void launch_split_f32_frag(int N, int K, const float *in, void *hi, void *lo, hipStream_t s) {
+void launch_split_f32_frag(int N, int K, const float *in, void *hi, void *lo, hipStream_t s, int pair_es) {
     if (N % 32 || K % 16) throw Error("fragment-order weights need N % 32 == 0 and K % 16 == 0");
+    if (pair_es > 0 && (K != 2 * pair_es || pair_es % 32)) throw Error("sine / cosine pairing needs K = 2 es and es % 32 == 0");
     long long g = ((long long) N * K + 255) / 256;
     if (g > 4096) g = 4096;
-    k_split_f32_frag<<<dim3((unsigned) (g < 1 ? 1 : g)), 256, 0, s>>>(N, K, in, (_Float16 *) hi, (_Float16 *) lo);
+    k_split_f32_frag<<<dim3((unsigned) (g < 1 ? 1 : g)), 256, 0, s>>>(N, K, pair_es, in, (_Float16 *) hi, (_Float16 *) lo);
     VFEM_HIP(hipGetLastError());
 }
 void launch_split_f32(long long n, const float *in, void *hi, void *lo, hipStream_t s) {
@@ -148,31 +174,41 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
 
     // ---- layer 1: K = 2 es, features generated chunk by chunk ------------------------------------------------------------
     const int K1 = 2 * a.es, nchunks = K1 / KC;
-    // 64 voxels x 64 features per chunk: thread -> voxel tid & 63, features 8 (tid >> 6) .. + 7 (all sines or all cosines: es % 32 == 0)
+    // a chunk = the sines and the cosines of 32 rows of B (the K order of W1 is permuted to match, k_split_f32_frag): 64 voxels x 32
+    // arguments, thread -> voxel tid & 63, rows 4 (tid >> 6) .. + 3, one sincos per argument
     auto make_features = [&](int chunk, int buf) {
         _Float16 *Fh = F + (2 * buf) * (TM * FS), *Fl = Fh + TM * FS;
         const int v = tid & 63, fq = __builtin_amdgcn_readfirstlane(tid >> 6);
         const float c0 = xc[3 * v], c1 = xc[3 * v + 1], c2 = xc[3 * v + 2];
-        const int f0 = chunk * KC + fq * 8;
-        const bool is_cos = f0 >= a.es;
-        const float *Bp = a.B + 3 * (is_cos ? f0 - a.es : f0);
-        h8_t oh, ol;
+        const float *Bp = a.B + 3 * (chunk * 32 + fq * 4);
+        h4_t sh, sl, ch, cl;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
             const float arg = fmaf(c2, Bp[3 * j + 2], fmaf(c1, Bp[3 * j + 1], c0 * Bp[3 * j]));
-            const float f = is_cos ? cosf(arg) : sinf(arg);
+            float sn, cs;
+            sincos_f32(arg, sn, cs);
             _Float16 fh, fl;
-            split(f, fh, fl);
-            oh[j] = fh; ol[j] = fl;
+            split(sn, fh, fl);
+            sh[j] = fh; sl[j] = fl;
+            split(cs, fh, fl);
+            ch[j] = fh; cl[j] = fl;
         }
-        *reinterpret_cast<h8_t *>(Fh + v * FS + fq * 8) = oh;
-        *reinterpret_cast<h8_t *>(Fl + v * FS + fq * 8) = ol;
+        *reinterpret_cast<h4_t *>(Fh + v * FS + fq * 4) = sh;
+        *reinterpret_cast<h4_t *>(Fl + v * FS + fq * 4) = sl;
+        *reinterpret_cast<h4_t *>(Fh + v * FS + 32 + fq * 4) = ch;
+        *reinterpret_cast<h4_t *>(Fl + v * FS + 32 + fq * 4) = cl;
     };
     make_features(0, 0);
     __syncthreads();
+    // weight fragments run PD k-steps ahead of their use in a register ring (an L2 hit is ~700 cycles away, a k-step of this wave 384
+    // MFMA cycles, twice that with the other wave of the SIMD in between: one k-step of lookahead left the matrix pipe waiting)
+    constexpr int PD = KC / 16;
+    h8_t ah[PD][2], al[PD][2];
     {
-        h8_t ah[2][2], al[2][2];           // [parity of the k-step][row tile]: fragments of the next k-step load while this one multiplies
-        load_a(w.W1h, w.W1l, K1, 0, ah[0], al[0]);
+        const int nks1 = K1 / 16;
+#pragma unroll
+        for (int p = 0; p < PD; ++p)
+            if (p < nks1) load_a(w.W1h, w.W1l, K1, p, ah[p], al[p]);
         for (int ch = 0; ch < nchunks; ++ch) {
             const int cur = ch & 1;
             const _Float16 *Fh = F + (2 * cur) * (TM * FS), *Fl = Fh + TM * FS;
@@ -180,10 +216,10 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
             // the matrix pipe at different times
             if (wave < 4 && ch + 1 < nchunks) make_features(ch + 1, 1 - cur);
 #pragma unroll
-            for (int q = 0; q < KC / 16; ++q) {
-                const int ks = ch * (KC / 16) + q;
-                if (ks + 1 < K1 / 16) load_a(w.W1h, w.W1l, K1, ks + 1, ah[(q + 1) & 1], al[(q + 1) & 1]);
-                kstep(ah[q & 1], al[q & 1], Fh, Fl, FS, q * 16);
+            for (int q = 0; q < PD; ++q) {
+                const int ks = ch * PD + q;
+                kstep(ah[q], al[q], Fh, Fl, FS, q * 16);
+                if (ks + PD < nks1) load_a(w.W1h, w.W1l, K1, ks + PD, ah[q], al[q]);
             }
             if (wave >= 4 && ch + 1 < nchunks) make_features(ch + 1, 1 - cur);
             __syncthreads();
@@ -222,15 +258,18 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
     // ---- hidden layers ------------------------------------------------------------------------------------------------------
     for (int l = 0; l < a.n_hidden; ++l) {
         const _Float16 *Wlh = w.Whh + (long long) l * a.nn * a.nn, *Wll = w.Whl + (long long) l * a.nn * a.nn;
-        h8_t ah[2][2], al[2][2];
-        load_a(Wlh, Wll, a.nn, 0, ah[0], al[0]);
         const int nks = a.nn / 16;
-        for (int ks = 0; ks < nks; ks += 2) {
-            if (ks + 1 < nks) load_a(Wlh, Wll, a.nn, ks + 1, ah[1], al[1]);
-            kstep(ah[0], al[0], Hh, Hl, HS, ks * 16);
-            if (ks + 1 < nks) {
-                if (ks + 2 < nks) load_a(Wlh, Wll, a.nn, ks + 2, ah[0], al[0]);
-                kstep(ah[1], al[1], Hh, Hl, HS, (ks + 1) * 16);
+#pragma unroll
+        for (int p = 0; p < PD; ++p)
+            if (p < nks) load_a(Wlh, Wll, a.nn, p, ah[p], al[p]);
+        for (int ks0 = 0; ks0 < nks; ks0 += PD) {
+#pragma unroll
+            for (int q = 0; q < PD; ++q) {
+                const int ks = ks0 + q;
+                if (ks < nks) {
+                    kstep(ah[q], al[q], Hh, Hl, HS, ks * 16);
+                    if (ks + PD < nks) load_a(Wlh, Wll, a.nn, ks + PD, ah[q], al[q]);
+                }
             }
         }
         __syncthreads();          // every wave finished reading the images

@@ -231,7 +231,7 @@ void launch_mlp_backward(const MlpBwdArgs &a, long long rows, hipStream_t s);
 void launch_mlp_features(const MlpArgs &a, long long rows, void *out, hipStream_t s);
 // reference-precision fused forward (kernels_mlp_x3.hip): split fp16 operands (hi + lo 2^-11), three MFMA products per product
 void launch_f32_to_f16_frag(int N, int K, int transposed, const float *in, void *out, hipStream_t s);
-void launch_split_f32_frag(int N, int K, const float *in, void *hi, void *lo, hipStream_t s);
+void launch_split_f32_frag(int N, int K, const float *in, void *hi, void *lo, hipStream_t s, int pair_es);
 void launch_mlp_forward_x3(const MlpArgs &a, const void *W1h, const void *W1l, const void *Whh, const void *Whl, hipStream_t s);
 void launch_split_f32(long long n, const float *in, void *hi, void *lo, hipStream_t s);
 void launch_colsum_f16(long long rows, int ncols, const void *X, const float *w, float *partial, hipStream_t s);
