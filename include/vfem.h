@@ -295,6 +295,10 @@ int vfem_mean(int64_t n, const double *x, double *mean_host, void *stream);
  * Requirements of the MFMA tiling: es % 32 == 0, nn % 32 == 0, nn <= 512. */
 int vfem_mlp_create(vfem_mlp **out, int embedding_size, int n_neurons, int n_layers, int sigmoid_output);
 int vfem_mlp_destroy(vfem_mlp *mlp);
+/* options of one network: VFEM_MLP_OPT_BWD_TERMS = 3 (default; every product of the backward pass is hi hi + hi lo + lo hi of split
+ * fp16 operands: the reference's fp32 autograd to rounding) or 1 (hi hi only in the weight-gradient GEMMs, three times fewer MFMAs) */
+#define VFEM_MLP_OPT_BWD_TERMS 1
+int vfem_mlp_set_option(vfem_mlp *mlp, int key, int value);
 int vfem_mlp_load_weights(vfem_mlp *mlp, const float *B, const float *W_first, const float *W_hidden, const float *biases,
                           const float *w_out, float b_out);
 /* forward on an explicit coordinate list [nvox][3] fp32 (device); either output pointer may be NULL */
@@ -315,8 +319,10 @@ int vfem_mlp_forward_grid_range_f32(vfem_mlp *mlp, const int64_t n_host[3], cons
                                     int64_t first_voxel, int64_t num_voxels, float *out_f32, double *out_f64, void *stream);
 /* Training (what torch.autograd does for networks.MLP in train_xdg.py:282-329): gradients of a scalar loss wrt the
  * parameters given g_out[v] = dL/d(out[v]) (device, fp32).  Outputs are overwritten, fp32, same layouts as vfem_mlp_load_weights:
- * dW1 [nn][2 es], dWh [n_layers-2][nn][nn], dbias [n_layers-1][nn], dwout [nn], dbout [1].  fp16 operands / fp32 accumulation;
- * `loss_scale` multiplies g_out before it enters fp16 and is divided out of the results (power of two recommended). */
+ * dW1 [nn][2 es], dWh [n_layers-2][nn][nn], dbias [n_layers-1][nn], dwout [nn], dbout [1].  Split fp16 operands (hi + lo) on the
+ * matrix pipe with fp32 accumulation = the reference's fp32 autograd to rounding; no library GEMM, the first layer's Fourier
+ * features are regenerated inside the weight-gradient kernel.  `loss_scale` multiplies g_out before it enters fp16 and is
+ * divided out of the results (power of two recommended). */
 int vfem_mlp_backward(vfem_mlp *mlp, const float *coords, int64_t nvox, const float *g_out, float loss_scale, float *dW1,
                       float *dWh, float *dbias, float *dwout, float *dbout, void *stream);
 int vfem_mlp_backward_grid(vfem_mlp *mlp, const int64_t n_host[3], const double lo_host[3], const double hi_host[3],

@@ -135,6 +135,7 @@ SIGNATURES = {
     "vfem_mean": (c_int, [c_int64, c_void_p, POINTER(c_double), c_void_p]),
     "vfem_mlp_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int]),
     "vfem_mlp_destroy": (c_int, [c_void_p]),
+    "vfem_mlp_set_option": (c_int, [c_void_p, c_int, c_int]),
     "vfem_mlp_load_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float]),
     "vfem_mlp_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "vfem_mlp_forward_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),

@@ -8,7 +8,6 @@
 #include "vfem_internal.h"
 #include "gs_coef.h"
 
-#include <rocblas/rocblas.h>
 
 #include <chrono>
 #include <cmath>
@@ -1118,8 +1117,15 @@ int vfem_mlp_create(vfem_mlp **out, int es, int nn, int n_layers, int sigmoid) {
 }
 int vfem_mlp_destroy(vfem_mlp *mlp) {
     VFEM_TRY
-    if (mlp && mlp->rocblas) rocblas_destroy_handle((rocblas_handle) mlp->rocblas);
     delete mlp;
+    VFEM_CATCH
+}
+int vfem_mlp_set_option(vfem_mlp *m, int key, int value) {
+    VFEM_TRY
+    if (key == VFEM_MLP_OPT_BWD_TERMS) {
+        if (value != 1 && value != 3) throw Error("VFEM_MLP_OPT_BWD_TERMS: 3 (hi hi + hi lo + lo hi, reference precision) or 1 (hi hi)");
+        m->bwd_terms = value;
+    } else throw Error("unknown MLP option");
     VFEM_CATCH
 }
 int vfem_mlp_load_weights(vfem_mlp *m, const float *B, const float *W1, const float *Wh, const float *biases,
@@ -1145,11 +1151,13 @@ int vfem_mlp_load_weights(vfem_mlp *m, const float *B, const float *W1, const fl
     for (int l = 0; l < nh; ++l)
         launch_split_f32_frag(m->nn, m->nn, m->Whf.p + (size_t) l * m->nn * m->nn, m->Whh.p + (size_t) l * m->nn * m->nn, m->Whl.p + (size_t) l * m->nn * m->nn, nullptr, 0);
     m->Wh.alloc((size_t) nh * m->nn * m->nn);
-    m->WhT.alloc((size_t) nh * m->nn * m->nn);
+    m->WhTh.alloc((size_t) nh * m->nn * m->nn);
+    m->WhTl.alloc((size_t) nh * m->nn * m->nn);
     if (nh) {
         for (int l = 0; l < nh; ++l) {
-            launch_f32_to_f16_frag(m->nn, m->nn, 0, m->Whf.p + (size_t) l * m->nn * m->nn, m->Wh.p + (size_t) l * m->nn * m->nn, nullptr);
-            launch_f32_to_f16_frag(m->nn, m->nn, 1, m->Whf.p + (size_t) l * m->nn * m->nn, m->WhT.p + (size_t) l * m->nn * m->nn, nullptr);
+            const size_t o = (size_t) l * m->nn * m->nn;
+            launch_f32_to_f16_frag(m->nn, m->nn, 0, m->Whf.p + o, m->Wh.p + o, nullptr);
+            launch_split_f32_frag(m->nn, m->nn, m->Whf.p + o, m->WhTh.p + o, m->WhTl.p + o, nullptr, 0, 1);
         }
     }
     up(m->bias, biases, (size_t) (nh + 1) * m->nn);
@@ -1240,9 +1248,10 @@ int vfem_mlp_forward_grid_range_f32(vfem_mlp *m, const int64_t n[3], const doubl
 }
 }  // extern "C"
 // Gradients of a scalar loss wrt the MLP parameters given dL/d(out) per voxel (what torch.autograd computes for
-// networks.MLP in the reference, train_xdg.py:282-329).  Voxels are processed in chunks: forward pass with saved fp16
-// activations, fused backward data pass (k_mlp_backward), then the weight gradients as split-V batched GEMMs
-// (rocBLAS, fp16 operands, fp32 accumulation/outputs) and column sums for the biases.
+// networks.MLP in the reference, train_xdg.py:282-329), at the reference's precision and with no library GEMM
+// (kernels_mlp_bwd.hip).  Voxels are processed in chunks: reference-precision forward with saved split activations, fused backward
+// data pass, the weight gradients as voxel-reduction GEMMs of our own (first layer: Fourier features regenerated in the kernel),
+// column sums for the biases and the output layer.
 static void mlp_backward_impl(vfem_mlp *m, vfem::MlpArgs base, const float *coords, const float *g_out, float scale,
                               float *dW1, float *dWh, float *dbias, float *dwout, float *dbout, hipStream_t s) {
     if (!m->loaded) throw Error("vfem_mlp_load_weights has not been called");
@@ -1250,66 +1259,62 @@ static void mlp_backward_impl(vfem_mlp *m, vfem::MlpArgs base, const float *coor
     const long long V = base.nvox;
     const int nn = m->nn, K1 = 2 * m->es, nh = m->n_layers - 2, nact = nh + 1;
     if (V <= 0) throw Error("empty voxel set");
-    const long long Vc = std::min<long long>((V + 127) / 128 * 128, 1LL << 20);
-    auto plan = [](long long n_c, int &nb, long long &Vb) {
-        nb = (int) std::min<long long>(32, (n_c + 127) / 128);
-        Vb = ((n_c + nb - 1) / nb + 127) / 128 * 128;
+    // a chunk: at most 2^20 voxels; its voxel slices (one block of the weight-gradient kernel per slice and output tile): enough
+    // blocks to fill the chip -- the first layer has 16 output tiles at the run.md sizes, a hidden layer 4 -- of at least 128 voxels each
+    auto plan = [](long long n_c, int &s1, int &sh, long long &rows) {
+        s1 = 8; sh = 8;
+        while (s1 < 32 && n_c >= (long long) 2 * s1 * 128) s1 *= 2;
+        while (sh < 128 && n_c >= (long long) 2 * sh * 128) sh *= 2;
+        const long long q = 32LL * std::max(s1, sh);
+        rows = (n_c + q - 1) / q * q;
     };
-    int nb; long long Vb;
-    plan(std::min(Vc, V), nb, Vb);
-    const long long rows_max = (long long) nb * Vb;
+    const long long Vc = std::min<long long>(V, 1LL << 20);
+    int s1, sh; long long rows_max;
+    plan(Vc, s1, sh, rows_max);
     m->acts.alloc((size_t) nact * rows_max * nn);
+    m->acts_lo.alloc((size_t) nact * rows_max * nn);
     m->dz.alloc((size_t) nact * rows_max * nn);
-    m->feats.alloc((size_t) rows_max * K1);
+    m->dz_lo.alloc((size_t) nact * rows_max * nn);
     m->gs.alloc((size_t) rows_max);
     m->out_chunk.alloc((size_t) rows_max);
     const size_t colblocks = (size_t) ((rows_max + 511) / 512);
-    m->partial.alloc(std::max((size_t) 32 * nn * K1, colblocks * (size_t) nn));
-    if (!m->rocblas) {
-        rocblas_handle hnd;
-        if (rocblas_create_handle(&hnd) != rocblas_status_success) throw Error("rocblas_create_handle failed");
-        m->rocblas = hnd;
-    }
-    rocblas_handle hnd = (rocblas_handle) m->rocblas;
-    rocblas_set_stream(hnd, s);
-    rocblas_set_pointer_mode(hnd, rocblas_pointer_mode_host);
-    const float inv = 1.f / scale, one = 1.f, zero = 0.f;
-    // C[n][k] (row-major, ld = kdim) = sum_v X[v][n] Y[v][k] over nbatch sub-ranges of Vb rows -> partial[b][n][k]
-    auto wgrad = [&](const uint16_t *Y, int kdim, const uint16_t *X, int nb_, long long Vb_, float beta, float *out) {
-        rocblas_status st = rocblas_gemm_strided_batched_ex(
-            hnd, rocblas_operation_none, rocblas_operation_transpose, kdim, nn, (rocblas_int) Vb_, &one,
-            Y, rocblas_datatype_f16_r, kdim, (rocblas_stride) Vb_ * kdim, X, rocblas_datatype_f16_r, nn, (rocblas_stride) Vb_ * nn, &zero,
-            m->partial.p, rocblas_datatype_f32_r, kdim, (rocblas_stride) nn * kdim,
-            m->partial.p, rocblas_datatype_f32_r, kdim, (rocblas_stride) nn * kdim, nb_, rocblas_datatype_f32_r,
-            rocblas_gemm_algo_standard, 0, 0);
-        if (st != rocblas_status_success) throw Error("rocblas_gemm_strided_batched_ex failed (status " + std::to_string((int) st) + ")");
-        launch_reduce_partials(nb_, (long long) nn * kdim, m->partial.p, inv, beta, out, s);
-    };
+    m->partial.alloc(std::max(std::max((size_t) s1 * nn * K1, (size_t) sh * nn * nn), colblocks * (size_t) nn));
+    const float inv = 1.f / scale;
     for (long long c0 = 0; c0 < V; c0 += Vc) {
         const long long n_c = std::min(Vc, V - c0);
-        plan(n_c, nb, Vb);
-        const long long rows = (long long) nb * Vb;
+        long long rows;
+        plan(n_c, s1, sh, rows);
         const float beta = c0 == 0 ? 0.f : 1.f;
-        if (rows != n_c) { m->acts.zero(s); m->feats.zero(s); }       // padded rows must be finite (they meet dz = 0)
+        if (rows != n_c) { m->acts.zero(s); m->acts_lo.zero(s); }      // padded rows must be finite (they meet dz = 0)
         vfem::MlpArgs a = base;
         a.nvox = n_c; a.v_offset = base.v_offset + c0; a.coords = coords ? coords + 3 * c0 : nullptr;
-        a.out32 = m->out_chunk.p; a.out64 = nullptr; a.save_act = m->acts.p; a.act_rows = rows;
-        launch_mlp_forward(a, s);
+        a.out32 = m->out_chunk.p; a.out64 = nullptr; a.save_act = m->acts.p; a.save_act_lo = m->acts_lo.p; a.act_rows = rows;
+        launch_mlp_forward_x3(a, m->W1h.p, m->W1l.p, m->Whh.p, m->Whl.p, s);
         vfem::MlpBwdArgs b{};
-        b.nn = nn; b.n_hidden = nh; b.sigmoid = m->sigmoid; b.WhT = m->WhT.p; b.wout = m->wout.p; b.g = g_out + c0;
-        b.out32 = m->out_chunk.p; b.scale = scale; b.act = m->acts.p; b.dz = m->dz.p; b.gs = m->gs.p; b.act_rows = rows; b.nvox = n_c;
-        launch_mlp_backward(b, rows, s);
-        a.save_act = nullptr;
-        launch_mlp_features(a, rows, m->feats.p, s);
-        wgrad(m->feats.p, K1, m->dz.p, nb, Vb, beta, dW1);
-        for (int l = 0; l < nh; ++l)
-            wgrad(m->acts.p + (size_t) l * rows * nn, nn, m->dz.p + (size_t) (l + 1) * rows * nn, nb, Vb, beta, dWh + (size_t) l * nn * nn);
+        b.nn = nn; b.n_hidden = nh; b.sigmoid = m->sigmoid; b.WhTh = m->WhTh.p; b.WhTl = m->WhTl.p; b.wout = m->wout.p; b.g = g_out + c0;
+        b.out32 = m->out_chunk.p; b.scale = scale; b.act_hi = m->acts.p; b.act_lo = m->acts_lo.p; b.dz_hi = m->dz.p; b.dz_lo = m->dz_lo.p;
+        b.gs = m->gs.p; b.act_rows = rows; b.nvox = n_c;
+        launch_mlp_backward_x3(b, rows, s);
+        a.save_act = nullptr; a.save_act_lo = nullptr;
+        vfem::MlpDwArgs w{};
+        w.nn = nn; w.rows = rows; w.terms = m->bwd_terms; w.partial = m->partial.p; w.grid = a;
+        // first layer: against the Fourier features of the chunk's voxels, regenerated in the kernel
+        w.K = K1; w.dz_hi = m->dz.p; w.dz_lo = m->dz_lo.p; w.h_hi = nullptr; w.h_lo = nullptr; w.slices = s1;
+        launch_mlp_dw(w, s);
+        launch_reduce_partials(s1, (long long) nn * K1, m->partial.p, inv, beta, dW1, s);
+        for (int l = 0; l < nh; ++l) {
+            w.K = nn; w.slices = sh;
+            w.dz_hi = m->dz.p + (size_t) (l + 1) * rows * nn; w.dz_lo = m->dz_lo.p + (size_t) (l + 1) * rows * nn;
+            w.h_hi = m->acts.p + (size_t) l * rows * nn; w.h_lo = m->acts_lo.p + (size_t) l * rows * nn;
+            launch_mlp_dw(w, s);
+            launch_reduce_partials(sh, (long long) nn * nn, m->partial.p, inv, beta, dWh + (size_t) l * nn * nn, s);
+        }
         const int cb = (int) ((rows + 511) / 512);
         for (int j = 0; j < nact; ++j) {
-            launch_colsum_f16(rows, nn, m->dz.p + (size_t) j * rows * nn, nullptr, m->partial.p, s);
+            launch_colsum_split(rows, nn, m->dz.p + (size_t) j * rows * nn, m->dz_lo.p + (size_t) j * rows * nn, nullptr, m->partial.p, s);
             launch_reduce_partials(cb, nn, m->partial.p, inv, beta, dbias + (size_t) j * nn, s);
         }
-        launch_colsum_f16(rows, nn, m->acts.p + (size_t) nh * rows * nn, m->gs.p, m->partial.p, s);
+        launch_colsum_split(rows, nn, m->acts.p + (size_t) nh * rows * nn, m->acts_lo.p + (size_t) nh * rows * nn, m->gs.p, m->partial.p, s);
         launch_reduce_partials(cb, nn, m->partial.p, inv, beta, dwout, s);
         launch_sum_f32(rows, m->gs.p, inv, beta, dbout, m->partial.p, s);
     }

@@ -294,151 +294,6 @@ void launch_mlp_forward(const MlpArgs &a, hipStream_t s) {
 }
 
 
-// ------------------------------------------------------------------------------------------------------
-// backward pass, data path: from dL/d(out) per voxel to the gradients wrt the pre-activations of every layer
-// (dz[j], fp16, scaled by the loss scale), for the weight-gradient GEMMs.  Same tiling as the forward kernel:
-//   dz_top[v][n] = gs[v] wout[n] 1[h_top > 0],   dh_l[v][k] = sum_n Wh_l[n][k] dz_{l+1}[v][n]  (MFMA, W^T as the A operand)
-// ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512) k_mlp_backward(MlpBwdArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    _Float16 *H = reinterpret_cast<_Float16 *>(smem);
-    float *gsl = reinterpret_cast<float *>(smem + (size_t) MLP_TM * MLP_HSTRIDE * 2);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long v0 = (long long) blockIdx.x * MLP_TM;
-    const int ntiles = a.nn / 32, ppr = a.nn / 8, top = a.n_hidden;
-    const _Float16 *act = reinterpret_cast<const _Float16 *>(a.act);
-    _Float16 *dz = reinterpret_cast<_Float16 *>(a.dz);
-
-    if (tid < MLP_TM) {
-        float g = 0.f;
-        if (v0 + tid < a.nvox) {
-            g = a.g[v0 + tid] * a.scale;
-            if (a.sigmoid) { const float o = a.out32[v0 + tid]; g *= o * (1.f - o); }
-        }
-        gsl[tid] = g;
-        a.gs[v0 + tid] = g;
-    }
-    __syncthreads();
-    // top layer: no GEMM
-    for (int q = tid; q < MLP_TM * ppr; q += 512) {
-        const int v = q / ppr, c = q - v * ppr;
-        h8_t o;
-        if (v0 + v < a.nvox) {
-            const h8_t hv = *reinterpret_cast<const h8_t *>(act + ((long long) top * a.act_rows + v0 + v) * a.nn + 8 * c);
-            const float g = gsl[v];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (float) hv[j] > 0.f ? (_Float16) (g * a.wout[8 * c + j]) : (_Float16) 0.f;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (_Float16) 0.f;
-        }
-        *reinterpret_cast<h8_t *>(H + v * MLP_HSTRIDE + 8 * c) = o;
-        *reinterpret_cast<h8_t *>(dz + ((long long) top * a.act_rows + v0 + v) * a.nn + 8 * c) = o;
-    }
-    __syncthreads();
-
-    f16_t acc[2][4];
-    for (int l = a.n_hidden - 1; l >= 0; --l) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[t][c][q] = 0.f;
-        gemm_layer<MLP_HSTRIDE, false>(acc, (const _Float16 *) a.WhT + (long long) l * a.nn * a.nn, a.nn, a.nn, H, wave, ntiles, lane);
-        __syncthreads();
-        {   // raw dh -> H (fp16)
-            const int col = lane & 31, h = lane >> 5;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int tile = wave + 8 * t;
-                if (tile >= ntiles) continue;
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = tile * 32 + 8 * g + 4 * h;
-                        h4_t o;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) o[q] = (_Float16) acc[t][c][4 * g + q];
-                        *reinterpret_cast<h4_t *>(H + (c * 32 + col) * MLP_HSTRIDE + n) = o;
-                    }
-            }
-        }
-        __syncthreads();
-        // ReLU mask from the saved activations, coalesced; result to LDS (next layer's operand) and to HBM
-        for (int q = tid; q < MLP_TM * ppr; q += 512) {
-            const int v = q / ppr, c = q - v * ppr;
-            h8_t o = *reinterpret_cast<const h8_t *>(H + v * MLP_HSTRIDE + 8 * c);
-            if (v0 + v < a.nvox) {
-                const h8_t hv = *reinterpret_cast<const h8_t *>(act + ((long long) l * a.act_rows + v0 + v) * a.nn + 8 * c);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) if (!((float) hv[j] > 0.f)) o[j] = (_Float16) 0.f;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (_Float16) 0.f;
-            }
-            *reinterpret_cast<h8_t *>(H + v * MLP_HSTRIDE + 8 * c) = o;
-            *reinterpret_cast<h8_t *>(dz + ((long long) l * a.act_rows + v0 + v) * a.nn + 8 * c) = o;
-        }
-        __syncthreads();
-    }
-}
-
-void launch_mlp_backward(const MlpBwdArgs &a, long long rows, hipStream_t s) {
-    const size_t lds = (size_t) MLP_TM * MLP_HSTRIDE * 2 + MLP_TM * 3 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_backward, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-        attr_set = true;
-    }
-    k_mlp_backward<<<dim3((unsigned) (rows / MLP_TM)), dim3(512), lds, s>>>(a);
-    VFEM_HIP(hipGetLastError());
-}
-
-// Fourier features of a voxel chunk, fp16 [rows][2 es] (operand of the first layer's weight-gradient GEMM)
-__global__ void __launch_bounds__(256) k_mlp_features(MlpArgs a, long long rows, _Float16 *__restrict__ out) {
-    const int ppr = 2 * a.es / 8;
-    const long long q = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= rows * ppr) return;
-    const long long v = q / ppr;
-    const int c = (int) (q - v * ppr);
-    h8_t o;
-    if (v < a.nvox) {
-        float x[3];
-        voxel_coord(a, v, x);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int f = 8 * c + j;
-            const bool is_cos = f >= a.es;
-            const int fi = is_cos ? f - a.es : f;
-            const float t = fmaf(x[0], a.B[3 * fi], fmaf(x[1], a.B[3 * fi + 1], x[2] * a.B[3 * fi + 2]));
-            const float fr = t - floorf(t);
-            o[j] = (_Float16) (is_cos ? __builtin_amdgcn_cosf(fr) : __builtin_amdgcn_sinf(fr));
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (_Float16) 0.f;
-    }
-    *reinterpret_cast<h8_t *>(out + v * 2 * a.es + 8 * c) = o;
-}
-void launch_mlp_features(const MlpArgs &a, long long rows, void *out, hipStream_t s) {
-    const long long total = rows * (2 * a.es / 8);
-    k_mlp_features<<<dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, s>>>(a, rows, (_Float16 *) out);
-    VFEM_HIP(hipGetLastError());
-}
-
-// column sums of an fp16 [rows][ncols] matrix, optionally weighted per row: partial[blk][col], 512 rows per block
-__global__ void __launch_bounds__(512) k_colsum_f16(long long rows, int ncols, const _Float16 *__restrict__ X,
-                                                    const float *__restrict__ w, float *__restrict__ partial) {
-    const long long r0 = (long long) blockIdx.x * 512;
-    for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
-        float acc = 0.f;
-        const long long r1 = r0 + 512 < rows ? r0 + 512 : rows;
-        for (long long r = r0; r < r1; ++r) acc += (w ? w[r] : 1.f) * (float) X[r * ncols + c];
-        partial[(long long) blockIdx.x * ncols + c] = acc;
-    }
-}
 // out[i] = beta * out[i] + alpha * sum_b partial[b][i]; four consecutive outputs per thread (16-byte loads), the loop over
 // the partials unrolled so that many loads are in flight
 __global__ void __launch_bounds__(256) k_reduce_partials(int nb, long long n, const float *__restrict__ partial, float alpha,
@@ -463,10 +318,6 @@ __global__ void __launch_bounds__(256) k_reduce_partials(int nb, long long n, co
         for (int b = 0; b < nb; ++b) acc += partial[(long long) b * n + i];
         out[i] = (beta == 0.f ? 0.f : beta * out[i]) + alpha * acc;
     }
-}
-void launch_colsum_f16(long long rows, int ncols, const void *X, const float *w, float *partial, hipStream_t s) {
-    k_colsum_f16<<<dim3((unsigned) ((rows + 511) / 512)), dim3(512), 0, s>>>(rows, ncols, (const _Float16 *) X, w, partial);
-    VFEM_HIP(hipGetLastError());
 }
 void launch_reduce_partials(int nb, long long n, const float *partial, float alpha, float beta, float *out, hipStream_t s) {
     k_reduce_partials<<<dim3((unsigned) (((n + 3) / 4 + 255) / 256)), dim3(256), 0, s>>>(nb, n, partial, alpha, beta, out);
@@ -501,18 +352,6 @@ void launch_sum_f32(long long n, const float *x, float alpha, float beta, float 
     const long long nblk = (n + 4095) / 4096;                      // scratch holds >= nblk floats
     k_sum_f32_partial<<<dim3((unsigned) nblk), dim3(256), 0, s>>>(n, x, scratch);
     k_sum_f32<<<dim3(1), dim3(256), 0, s>>>(nblk, scratch, alpha, beta, out);
-    VFEM_HIP(hipGetLastError());
-}
-
-// fp32 [rows][cols] -> fp16 transposed [cols][rows] (hidden weights for the backward GEMMs; tiny)
-__global__ void k_transpose_f32_to_f16(int rows, int cols, const float *__restrict__ in, _Float16 *__restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * cols) return;
-    const int r = i / cols, c = i % cols;
-    out[(long long) c * rows + r] = (_Float16) in[i];
-}
-void launch_transpose_f32_to_f16(int rows, int cols, const float *in, void *out, hipStream_t s) {
-    k_transpose_f32_to_f16<<<dim3((unsigned) ((rows * cols + 255) / 256)), dim3(256), 0, s>>>(rows, cols, in, (_Float16 *) out);
     VFEM_HIP(hipGetLastError());
 }
 

@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(256) k_split_f32(long long n, const float *__r
 // = eight whole 128-byte lines, and successive k-steps of a tile follow each other in memory.
 // pair_es > 0 (first layer): the K order is permuted so that a 64-wide chunk holds the sines of 32 rows of B followed by the cosines of
 // the same rows (the forward kernel forms both from one argument): logical feature f < es -> 64 (f / 32) + f % 32, f >= es -> the same + 32
-__global__ void __launch_bounds__(256) k_split_f32_frag(int N, int K, int pair_es, const float *__restrict__ in, _Float16 *__restrict__ hi, _Float16 *__restrict__ lo) {
+// transposed: `in` is the fp32 [K][N] matrix whose transpose is packed (hidden weights for the backward data pass)
+__global__ void __launch_bounds__(256) k_split_f32_frag(int N, int K, int pair_es, int transposed, const float *__restrict__ in, _Float16 *__restrict__ hi, _Float16 *__restrict__ lo) {
     const long long n = (long long) N * K;
     const int nks = K / 16;
     for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
@@ -91,15 +92,15 @@ __global__ void __launch_bounds__(256) k_split_f32_frag(int N, int K, int pair_e
         int k = (int) (i - (long long) row * K);
         if (pair_es > 0) { const int f = k < pair_es ? k : k - pair_es; k = 64 * (f >> 5) + (f & 31) + (k < pair_es ? 0 : 32); }
         const long long o = ((((long long) (row >> 5) * nks + (k >> 4)) * 64) + (row & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
-        x3::split(in[i], hi[o], lo[o]);
+        x3::split(transposed ? in[(long long) (int) (i - (long long) row * K) * N + row] : in[i], hi[o], lo[o]);
     }
 }
-void launch_split_f32_frag(int N, int K, const float *in, void *hi, void *lo, hipStream_t s, int pair_es) {
+void launch_split_f32_frag(int N, int K, const float *in, void *hi, void *lo, hipStream_t s, int pair_es, int transposed) {
     if (N % 32 || K % 16) throw Error("fragment-order weights need N % 32 == 0 and K % 16 == 0");
     if (pair_es > 0 && (K != 2 * pair_es || pair_es % 32)) throw Error("sine / cosine pairing needs K = 2 es and es % 32 == 0");
     long long g = ((long long) N * K + 255) / 256;
     if (g > 4096) g = 4096;
-    k_split_f32_frag<<<dim3((unsigned) (g < 1 ? 1 : g)), 256, 0, s>>>(N, K, pair_es, in, (_Float16 *) hi, (_Float16 *) lo);
+    k_split_f32_frag<<<dim3((unsigned) (g < 1 ? 1 : g)), 256, 0, s>>>(N, K, pair_es, transposed, in, (_Float16 *) hi, (_Float16 *) lo);
     VFEM_HIP(hipGetLastError());
 }
 void launch_split_f32(long long n, const float *in, void *hi, void *lo, hipStream_t s) {
@@ -252,8 +253,26 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
         }
         zero_acc();
     };
+    // training: the finished layer's two [voxel][k] images to HBM in 16-byte pieces, the low halves unscaled (h = hi + lo)
+    auto save_layer = [&](int layer) {
+        if (!a.save_act) return;
+        _Float16 *dh = reinterpret_cast<_Float16 *>(a.save_act) + ((long long) layer * a.act_rows + v0) * a.nn;
+        _Float16 *dl = reinterpret_cast<_Float16 *>(a.save_act_lo) + ((long long) layer * a.act_rows + v0) * a.nn;
+        const int ppr = a.nn / 8;
+        for (int q = tid; q < TM * ppr; q += 512) {
+            const int v = q / ppr, c = q - v * ppr;
+            if (v0 + v < a.nvox) {
+                *reinterpret_cast<h8_t *>(dh + (long long) v * a.nn + 8 * c) = *reinterpret_cast<const h8_t *>(Hh + v * HS + 8 * c);
+                h8_t l = *reinterpret_cast<const h8_t *>(Hl + v * HS + 8 * c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) l[j] = (_Float16) ((float) l[j] * LO_INV);
+                *reinterpret_cast<h8_t *>(dl + (long long) v * a.nn + 8 * c) = l;
+            }
+        }
+    };
     store_layer(a.bias);          // all waves passed the last barrier of the chunk loop: the feature buffers are dead
     __syncthreads();
+    save_layer(0);
 
     // ---- hidden layers ------------------------------------------------------------------------------------------------------
     for (int l = 0; l < a.n_hidden; ++l) {
@@ -275,6 +294,7 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
         __syncthreads();          // every wave finished reading the images
         store_layer(a.bias + (l + 1) * a.nn);
         __syncthreads();
+        save_layer(l + 1);
     }
 
     // ---- output layer: one scalar per voxel, 8 threads per voxel -----------------------------------------------------------

@@ -21,22 +21,37 @@ struct MlpArgs {
     // post-ReLU activations of every hidden layer, fp16 [1 + n_hidden][act_rows][nn], for the backward pass
     long long v_offset;
     void *save_act;
+    void *save_act_lo;                      // reference-precision forward only: the low halves, UNSCALED (h = hi + lo), same layout
     long long act_rows;
     int ablate;                             // timing ablations (wrong results): 1 no feature generation, 2 no hidden layers, 3 no layer-1 MFMAs
 };
 
-// backward pass of one voxel chunk (networks.MLP under torch.autograd in the reference, train_xdg.py:282-329)
+// backward pass of one voxel chunk (networks.MLP under torch.autograd in the reference, train_xdg.py:282-329), split operands:
+// every saved quantity q is a pair of fp16 arrays (hi, lo) with q = hi + lo (lo unscaled), [layer][act_rows][nn]
 struct MlpBwdArgs {
     int nn, n_hidden, sigmoid;
-    const void *WhT;                        // [n_hidden][nn (k)][nn (n)] fp16: transposed hidden weights
+    const void *WhTh, *WhTl;                // transposed hidden weights, split, MFMA-fragment order (lo scaled by 2^11 as the forward's)
     const float *wout;                      // [nn]
     const float *g;                         // [nvox] dL/d(out)
     const float *out32;                     // [nvox] forward outputs (sigmoid derivative)
-    float scale;                            // loss scale applied to g before it enters fp16
-    const void *act;                        // [1 + n_hidden][act_rows][nn] fp16
-    void *dz;                               // [1 + n_hidden][act_rows][nn] fp16: scaled gradients wrt the pre-activations
+    float scale;                            // loss scale applied to g
+    const void *act_hi, *act_lo;            // [1 + n_hidden][act_rows][nn]: post-ReLU activations saved by the forward kernel
+    void *dz_hi, *dz_lo;                    // [1 + n_hidden][act_rows][nn]: scaled gradients wrt the pre-activations
     float *gs;                              // [act_rows] scaled dL/d(pre-sigmoid out), zero beyond nvox
     long long act_rows, nvox;
+};
+
+// weight gradient of one layer over one voxel chunk: dW[n][k] = sum_v dz[v][n] h[v][k]   (h: saved activations, or -- first layer -- the
+// Fourier features, regenerated from the coordinates)
+struct MlpDwArgs {
+    int nn, K;                              // output rows (hidden width), columns (nn, or 2 es for the first layer)
+    const void *dz_hi, *dz_lo;              // [rows][nn]
+    const void *h_hi, *h_lo;                // [rows][K], null for the first layer
+    MlpArgs grid;                           // first layer: coordinates / grid of the chunk and B (es, B, coords, gn, glo, gstep, v_offset, nvox)
+    long long rows;                         // voxels of the chunk, padded to a multiple of 32 x slices (rows beyond nvox hold dz = 0)
+    int slices;                             // voxel slices: one block per (slice, output tile), partial sums [slice][nn][K]
+    int terms;                              // 3: hi hi + hi lo + lo hi (reference precision);  1: hi hi only
+    float *partial;
 };
 
 }  // namespace vfem

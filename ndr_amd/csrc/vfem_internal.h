@@ -227,17 +227,17 @@ struct MlpArgs;
 void launch_mlp_forward(const MlpArgs &a, hipStream_t s);
 void launch_f32_to_f16(long long n, const float *in, void *out, hipStream_t s);
 struct MlpBwdArgs;
-void launch_mlp_backward(const MlpBwdArgs &a, long long rows, hipStream_t s);
-void launch_mlp_features(const MlpArgs &a, long long rows, void *out, hipStream_t s);
+struct MlpDwArgs;
+void launch_mlp_backward_x3(const MlpBwdArgs &a, long long rows, hipStream_t s);
+void launch_mlp_dw(const MlpDwArgs &a, hipStream_t s);
+void launch_colsum_split(long long rows, int ncols, const void *Xh, const void *Xl, const float *w, float *partial, hipStream_t s);
 // reference-precision fused forward (kernels_mlp_x3.hip): split fp16 operands (hi + lo 2^-11), three MFMA products per product
 void launch_f32_to_f16_frag(int N, int K, int transposed, const float *in, void *out, hipStream_t s);
-void launch_split_f32_frag(int N, int K, const float *in, void *hi, void *lo, hipStream_t s, int pair_es);
+void launch_split_f32_frag(int N, int K, const float *in, void *hi, void *lo, hipStream_t s, int pair_es, int transposed = 0);
 void launch_mlp_forward_x3(const MlpArgs &a, const void *W1h, const void *W1l, const void *Whh, const void *Whl, hipStream_t s);
 void launch_split_f32(long long n, const float *in, void *hi, void *lo, hipStream_t s);
-void launch_colsum_f16(long long rows, int ncols, const void *X, const float *w, float *partial, hipStream_t s);
 void launch_reduce_partials(int nb, long long n, const float *partial, float alpha, float beta, float *out, hipStream_t s);
 void launch_sum_f32(long long n, const float *x, float alpha, float beta, float *out, float *scratch, hipStream_t s);
-void launch_transpose_f32_to_f16(int rows, int cols, const float *in, void *out, hipStream_t s);
 void launch_adam(long long n, float *p, const float *g, float *m, float *v, float lr, float b1, float b2, float eps, int step, hipStream_t s);
 
 }  // namespace vfem
@@ -323,7 +323,8 @@ struct vfem_mlp {
     float bout = 0.f;
     bool loaded = false;
     // training workspace (vfem_mlp_backward*): transposed hidden weights, per-chunk activations / gradients / features
-    vfem::DevBuf<uint16_t> WhT, acts, dz, feats;
+    vfem::DevBuf<uint16_t> WhTh, WhTl;           // transposed hidden weights, split, fragment order (backward data pass)
+    vfem::DevBuf<uint16_t> acts, acts_lo, dz, dz_lo;   // per chunk: saved activations / gradients wrt pre-activations as (hi, lo) pairs
     vfem::DevBuf<float> gs, partial, out_chunk;
-    void *rocblas = nullptr;
+    int bwd_terms = 3;                           // VFEM_MLP_OPT_BWD_TERMS
 };

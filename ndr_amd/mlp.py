@@ -31,13 +31,18 @@ class MLP:
         self.embedding_size, self.n_neurons, self.n_layers, self.scale = embedding_size, n_neurons, n_layers, scale
         # "fp32" (default): the reference's precision -- the fused kernel with split fp16 operands (hi + lo 2^-11, three MFMA
         # products per product, fp32 accumulation; kernels_mlp_x3.hip), outputs within fp32 rounding of networks.MLP.forward.
-        # "fp16": plain fp16 operands, three times the throughput, ~4e-4 on the logits.  The backward pass uses fp16 operands in
-        # both modes.
+        # "fp16": plain fp16 operands, three times the throughput, ~4e-4 on the logits.  The backward pass runs at the reference's
+        # precision in both modes (split operands in every product; `set_backward_terms(1)` keeps only the hi x hi product in the
+        # weight-gradient GEMMs).
         self.precision = "fp32"
         h = ctypes.c_void_p()
         _lib.check(self._lib.vfem_mlp_create(ctypes.byref(h), int(embedding_size), int(n_neurons), int(n_layers),
                                              int(name == "Sigmoid")))
         self._h = h
+
+    def set_backward_terms(self, terms):
+        """3 (default): hi hi + hi lo + lo hi in the weight-gradient products; 1: hi hi only (VFEM_MLP_OPT_BWD_TERMS)"""
+        _lib.check(self._lib.vfem_mlp_set_option(self._h, 1, int(terms)))
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -112,7 +117,8 @@ class MLP:
 
     @staticmethod
     def _auto_scale(g):
-        """power-of-two loss scale that brings max |g| to about 64 (fp16 operands in the backward GEMMs)"""
+        """power-of-two loss scale that brings max |g| to about 64 (the split fp16 operands of the backward products then sit well
+        inside fp16's normal range)"""
         m = float(g.abs().max().item())
         return 1.0 if not (m > 0) else float(2.0 ** int(np.round(np.log2(64.0 / m))))
 
