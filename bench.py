@@ -273,7 +273,7 @@ def mlp_rate(side=(512, 256, 256), es=1024, nn_=512, nl=4, sigma=4.0, reps=3):
     d16 = timed("fp16")
     res["fp16_option"] = {"seconds": d16, "voxels_per_s": nv / d16, "tflops": flop / d16 / 1e12, "mfma_frac_of_2.5PF": flop / d16 / 2.5e15,
                           "operands": "f16, f32 accumulate"}
-    # parameter gradients of the whole grid (recomputed forward with saved activations + data path + weight-gradient GEMMs)
+    # parameter gradients of the whole grid (recomputed forward with saved activations + data path + weight-gradient kernels)
     g = torch.randn(nv, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
     m.backward_grid(side, g)
     torch.cuda.synchronize()
@@ -283,7 +283,9 @@ def mlp_rate(side=(512, 256, 256), es=1024, nn_=512, nl=4, sigma=4.0, reps=3):
     db = time.perf_counter() - t0
     macs = (3 * es + 2 * es * nn_ + (nl - 2) * nn_ * nn_ + nn_) + (nl - 2) * nn_ * nn_ + (2 * es * nn_ + (nl - 2) * nn_ * nn_ + nn_)
     res["backward"] = {"seconds": db, "voxels_per_s": nv / db, "tflops": 2.0 * macs * nv / db / 1e12,
-                       "note": "forward recompute + dX + dW GEMMs (rocBLAS f16->f32 for dW)"}
+                       "note": "reference precision throughout: forward recompute with saved split activations (kernels_mlp_x3.hip) + data pass + own "
+                               "weight-gradient kernels with in-kernel Fourier features (kernels_mlp_bwd.hip); no library GEMM; tflops counts the "
+                               "network's multiply-adds once, the matrix pipe executes three times that"}
     return res
 
 
@@ -309,7 +311,7 @@ def degree2_rate(ne=(512, 512, 512), reps=3):
     return {"grid": "%dx%dx%d" % tuple(ne), "nodes": t.numNodes(), "seconds": dt, "gvoxel_per_s": nvox / dt / 1e9,
             "algorithmic_GBs": ab / dt / 1e9, "frac_of_8TBs": ab / dt / 1e9 / HBM_PEAK_GBS,
             "algorithmic_bytes_per_voxel": ab / nvox,
-            "note": "marching kernel: reflection-mode blocks (855 of 6561 multiply-adds), x-march with in-block y hand-off, 2 colour launches; 527 B/voxel moved by the counters (profiles/r01_q2march512_pmc.json)"}
+            "note": "marching kernel: reflection-mode blocks (855 of 6561 multiply-adds), x-march with in-block y hand-off, 2 colour launches; 527 B/voxel moved by the counters (profiles/r04_q2march512_pmc.json: re-measured on the current kernel, 2 x FETCH_SIZE + WRITE_SIZE)"}
 
 
 def degree2_pcg_rate(n=128, levels=5):

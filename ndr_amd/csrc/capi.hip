@@ -1279,6 +1279,7 @@ static void mlp_backward_impl(vfem_mlp *m, vfem::MlpArgs base, const float *coor
     m->out_chunk.alloc((size_t) rows_max);
     const size_t colblocks = (size_t) ((rows_max + 511) / 512);
     m->partial.alloc(std::max(std::max((size_t) s1 * nn * K1, (size_t) sh * nn * nn), colblocks * (size_t) nn));
+    m->partial_b.alloc((size_t) 128 * nn);
     const float inv = 1.f / scale;
     for (long long c0 = 0; c0 < V; c0 += Vc) {
         const long long n_c = std::min(Vc, V - c0);
@@ -1300,20 +1301,19 @@ static void mlp_backward_impl(vfem_mlp *m, vfem::MlpArgs base, const float *coor
         w.nn = nn; w.rows = rows; w.terms = m->bwd_terms; w.partial = m->partial.p; w.grid = a;
         // first layer: against the Fourier features of the chunk's voxels, regenerated in the kernel
         w.K = K1; w.dz_hi = m->dz.p; w.dz_lo = m->dz_lo.p; w.h_hi = nullptr; w.h_lo = nullptr; w.slices = s1;
+        w.colsum_partial = m->partial_b.p;                              // the layer's bias gradient: column sums of its dz, formed by the same kernel
         launch_mlp_dw(w, s);
         launch_reduce_partials(s1, (long long) nn * K1, m->partial.p, inv, beta, dW1, s);
+        launch_reduce_partials(s1, nn, m->partial_b.p, inv, beta, dbias, s);
         for (int l = 0; l < nh; ++l) {
             w.K = nn; w.slices = sh;
             w.dz_hi = m->dz.p + (size_t) (l + 1) * rows * nn; w.dz_lo = m->dz_lo.p + (size_t) (l + 1) * rows * nn;
             w.h_hi = m->acts.p + (size_t) l * rows * nn; w.h_lo = m->acts_lo.p + (size_t) l * rows * nn;
             launch_mlp_dw(w, s);
             launch_reduce_partials(sh, (long long) nn * nn, m->partial.p, inv, beta, dWh + (size_t) l * nn * nn, s);
+            launch_reduce_partials(sh, nn, m->partial_b.p, inv, beta, dbias + (size_t) (l + 1) * nn, s);
         }
         const int cb = (int) ((rows + 511) / 512);
-        for (int j = 0; j < nact; ++j) {
-            launch_colsum_split(rows, nn, m->dz.p + (size_t) j * rows * nn, m->dz_lo.p + (size_t) j * rows * nn, nullptr, m->partial.p, s);
-            launch_reduce_partials(cb, nn, m->partial.p, inv, beta, dbias + (size_t) j * nn, s);
-        }
         launch_colsum_split(rows, nn, m->acts.p + (size_t) nh * rows * nn, m->acts_lo.p + (size_t) nh * rows * nn, m->gs.p, m->partial.p, s);
         launch_reduce_partials(cb, nn, m->partial.p, inv, beta, dwout, s);
         launch_sum_f32(rows, m->gs.p, inv, beta, dbout, m->partial.p, s);

@@ -72,6 +72,7 @@ __device__ __forceinline__ void voxel_xyz(const MlpArgs &a, long long v, float x
 // data path: 64 voxels per 512-thread block, the tiling and the k-step of k_mlp_forward_x3 (A = transposed-weight fragments in
 // fragment order, B = the two images of dz in LDS)
 // ---------------------------------------------------------------------------------------------------------------------------
+template <bool FULL>                // FULL: hidden width 512 (see k_mlp_forward_x3)
 __global__ void __launch_bounds__(512) k_mlp_backward_x3(MlpBwdArgs a) {
     using namespace bw;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -82,7 +83,7 @@ __global__ void __launch_bounds__(512) k_mlp_backward_x3(MlpBwdArgs a) {
     const int r = lane & 31, h = lane >> 5;
     const long long v0 = (long long) blockIdx.x * TM;
     const int ntiles = a.nn / 32, ppr = a.nn / 8, top = a.n_hidden;
-    const bool on[2] = {wave < ntiles, wave + 8 < ntiles};
+    const bool on[2] = {FULL || wave < ntiles, FULL || wave + 8 < ntiles};
     const _Float16 *acth = reinterpret_cast<const _Float16 *>(a.act_hi), *actl = reinterpret_cast<const _Float16 *>(a.act_lo);
     _Float16 *dzh = reinterpret_cast<_Float16 *>(a.dz_hi), *dzl = reinterpret_cast<_Float16 *>(a.dz_lo);
 
@@ -148,7 +149,7 @@ __global__ void __launch_bounds__(512) k_mlp_backward_x3(MlpBwdArgs a) {
         auto load_a = [&](int ks, h8_t (&fh)[2], h8_t (&fl)[2]) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const long long off = (((long long) (on[t] ? wave + 8 * t : 0) * nks + ks) * 64 + lane) * 8;
+                const long long off = (((long long) ((FULL || on[t]) ? wave + 8 * t : 0) * nks + ks) * 64 + lane) * 8;
                 fh[t] = *reinterpret_cast<const h8_t *>(Wh_ + off);
                 fl[t] = *reinterpret_cast<const h8_t *>(Wl_ + off);
             }
@@ -168,15 +169,17 @@ __global__ void __launch_bounds__(512) k_mlp_backward_x3(MlpBwdArgs a) {
                         bl[c] = *reinterpret_cast<const h8_t *>(Hl + (c * 32 + r) * HS + ks * 16 + 8 * h);
                     }
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        if (!on[t]) continue;
+                    for (int term = 0; term < 3; ++term)
 #pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            acch[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q][t], bh[c], acch[t][c], 0, 0, 0);
-                            accx[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q][t], bl[c], accx[t][c], 0, 0, 0);
-                            accx[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[q][t], bh[c], accx[t][c], 0, 0, 0);
+                        for (int t = 0; t < 2; ++t) {
+                            if (!FULL && !on[t]) continue;
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) {
+                                if (term == 0) acch[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q][t], bh[c], acch[t][c], 0, 0, 0);
+                                if (term == 1) accx[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q][t], bl[c], accx[t][c], 0, 0, 0);
+                                if (term == 2) accx[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[q][t], bh[c], accx[t][c], 0, 0, 0);
+                            }
                         }
-                    }
                     if (ks + PD < nks) load_a(ks + PD, ah[q], al[q]);
                 }
             }
@@ -184,7 +187,7 @@ __global__ void __launch_bounds__(512) k_mlp_backward_x3(MlpBwdArgs a) {
         __syncthreads();          // every wave finished reading the images
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            if (!on[t]) continue;
+            if (!FULL && !on[t]) continue;
             const int tile = wave + 8 * t;
 #pragma unroll
             for (int c = 0; c < 2; ++c)
@@ -215,10 +218,12 @@ void launch_mlp_backward_x3(const MlpBwdArgs &a, long long rows, hipStream_t s) 
     const size_t lds = (size_t) 2 * TM * HS * 2 + TM * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_backward_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_backward_x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_backward_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         attr_set = true;
     }
-    k_mlp_backward_x3<<<dim3((unsigned) (rows / TM)), dim3(512), lds, s>>>(a);
+    if (a.nn == MAXN) k_mlp_backward_x3<true><<<dim3((unsigned) (rows / TM)), dim3(512), lds, s>>>(a);
+    else              k_mlp_backward_x3<false><<<dim3((unsigned) (rows / TM)), dim3(512), lds, s>>>(a);
     VFEM_HIP(hipGetLastError());
 }
 
@@ -326,6 +331,17 @@ __global__ void __launch_bounds__(512) k_mlp_dw(MlpDwArgs a) {
         }
     };
 
+    // bias gradient of the layer = column sums of dz, the A operand: the blocks of the first column tile add up the pieces they stage
+    // anyway (eight columns x two rows per thread and stage), no pass of its own over dz
+    const bool colsum = a.colsum_partial != nullptr && k0 == 0;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto add_colsum = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cs[j] += (float) ra[0][i][j] + (TERMS == 3 ? (float) ra[1][i][j] : 0.f);
+    };
+
     f16_t acc[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -351,6 +367,7 @@ __global__ void __launch_bounds__(512) k_mlp_dw(MlpDwArgs a) {
     if (nstages > 0) {
         fetch(0);
         commit(0);
+        if (colsum) add_colsum();
         if (FEATURES) features(0, 0);
     }
     __syncthreads();
@@ -374,20 +391,33 @@ __global__ void __launch_bounds__(512) k_mlp_dw(MlpDwArgs a) {
                 fb[c] = frag(base + 2 * IMG, wk * 64 + 32 * c, ks);
                 if (TERMS == 3) fbl[c] = frag(base + 3 * IMG, wk * 64 + 32 * c, ks);
             }
+            // term by term over the eight tiles: products into the same accumulator are eight MFMAs apart, not back to back
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int term = 0; term < TERMS; ++term)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t], fb[c], acc[t][c], 0, 0, 0);
-                    if (TERMS == 3) {
-                        acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t], fbl[c], acc[t][c], 0, 0, 0);
-                        acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[t], fb[c], acc[t][c], 0, 0, 0);
-                    }
-                }
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? fal[t] : fa[t], term == 1 ? fbl[c] : fb[c], acc[t][c], 0, 0, 0);
         }
         if (FEATURES && wave >= 4 && st + 1 < nstages) features(st + 1, 1 - buf);
-        if (st + 1 < nstages) commit(1 - buf);
+        if (st + 1 < nstages) {
+            commit(1 - buf);
+            if (colsum) add_colsum();
+        }
         __syncthreads();
+    }
+    if (colsum) {
+        // the 16 threads that share a column piece (rows tid >> 5) meet in LDS (the staging buffers are dead), fixed order
+        float *red = reinterpret_cast<float *>(smem);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[(prow * 32 + pcol) * 8 + j] = cs[j];
+        __syncthreads();
+        if (tid < 256) {
+            float sum = 0.f;
+            for (int q = 0; q < 16; ++q) sum += red[q * 256 + tid];
+            if (n0 + tid < a.nn) a.colsum_partial[(long long) slice * a.nn + n0 + tid] = sum;
+        }
     }
 
     // partial[slice][n][k]: column (lane & 31) of a tile, rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); first layer: back from the
@@ -436,19 +466,36 @@ void launch_mlp_dw(const MlpDwArgs &a, hipStream_t s) {
     VFEM_HIP(hipGetLastError());
 }
 
-// column sums of a split fp16 [rows][ncols] matrix (hi + lo), optionally weighted per row: partial[blk][col], 512 rows per block
-__global__ void __launch_bounds__(512) k_colsum_split(long long rows, int ncols, const _Float16 *__restrict__ Xh, const _Float16 *__restrict__ Xl,
+// column sums of a split fp16 [rows][ncols] matrix (hi + lo), optionally weighted per row: partial[blk][col], 512 rows per block.
+// 256 threads: a thread owns eight consecutive columns (16-byte loads) and every (256 / (ncols / 8))-th row of the block's rows
+__global__ void __launch_bounds__(256) k_colsum_split(long long rows, int ncols, const _Float16 *__restrict__ Xh, const _Float16 *__restrict__ Xl,
                                                       const float *__restrict__ w, float *__restrict__ partial) {
-    const long long r0 = (long long) blockIdx.x * 512;
-    for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
-        float acc = 0.f;
-        const long long r1 = r0 + 512 < rows ? r0 + 512 : rows;
-        for (long long r = r0; r < r1; ++r) acc += (w ? w[r] : 1.f) * ((float) Xh[r * ncols + c] + (float) Xl[r * ncols + c]);
-        partial[(long long) blockIdx.x * ncols + c] = acc;
+    using namespace bw;
+    __shared__ float red[256 * 8];
+    const int groups = ncols / 8;                       // column groups (<= 64)
+    const int lanes = 256 / groups;                     // row lanes per group
+    const int cg = threadIdx.x % groups, rl = threadIdx.x / groups;
+    const long long r0 = (long long) blockIdx.x * 512, r1 = r0 + 512 < rows ? r0 + 512 : rows;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (rl < lanes)
+        for (long long r = r0 + rl; r < r1; r += lanes) {
+            const h8_t h = *reinterpret_cast<const h8_t *>(Xh + r * ncols + 8 * cg), l = *reinterpret_cast<const h8_t *>(Xl + r * ncols + 8 * cg);
+            const float wr = w ? w[r] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(wr, (float) h[j] + (float) l[j], acc[j]);
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = acc[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < ncols; c += 256) {
+        float sum = 0.f;
+        for (int q = 0; q < lanes; ++q) sum += red[(q * groups + (c >> 3)) * 8 + (c & 7)];
+        partial[(long long) blockIdx.x * ncols + c] = sum;
     }
 }
 void launch_colsum_split(long long rows, int ncols, const void *Xh, const void *Xl, const float *w, float *partial, hipStream_t s) {
-    k_colsum_split<<<dim3((unsigned) ((rows + 511) / 512)), dim3(512), 0, s>>>(rows, ncols, (const _Float16 *) Xh, (const _Float16 *) Xl, w, partial);
+    if (ncols % 8 || ncols > 512) throw Error("column sums: width must be a multiple of 8, at most 512");
+    k_colsum_split<<<dim3((unsigned) ((rows + 511) / 512)), dim3(256), 0, s>>>(rows, ncols, (const _Float16 *) Xh, (const _Float16 *) Xl, w, partial);
     VFEM_HIP(hipGetLastError());
 }
 

@@ -110,6 +110,7 @@ void launch_split_f32(long long n, const float *in, void *hi, void *lo, hipStrea
     VFEM_HIP(hipGetLastError());
 }
 
+template <bool FULL>                // FULL: hidden width 512 = 16 row tiles, both tiles of every wave live: the branches on tile validity fold away
 __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights w) {
     using namespace x3;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -122,7 +123,7 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
     const int r = lane & 31, h = lane >> 5;
     const long long v0 = (long long) blockIdx.x * TM;
     const int ntiles = a.nn / 32;
-    const bool on[2] = {wave < ntiles, wave + 8 < ntiles};
+    const bool on[2] = {FULL || wave < ntiles, FULL || wave + 8 < ntiles};
 
     if (tid < TM) {
         float x[3] = {0.f, 0.f, 0.f};
@@ -151,23 +152,26 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
             bh[c] = *reinterpret_cast<const h8_t *>(xh + (c * 32 + r) * stride + klocal + 8 * h);
             bl[c] = *reinterpret_cast<const h8_t *>(xl + (c * 32 + r) * stride + klocal + 8 * h);
         }
+        // term by term over the four tiles: two products into the same accumulator are then four MFMAs apart, not back to back
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (!on[t]) continue;
+        for (int term = 0; term < 3; ++term)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                acch[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[c], acch[t][c], 0, 0, 0);
-                accx[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[c], accx[t][c], 0, 0, 0);
-                accx[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[c], accx[t][c], 0, 0, 0);
+            for (int t = 0; t < 2; ++t) {
+                if (!FULL && !on[t]) continue;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (term == 0) acch[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[c], acch[t][c], 0, 0, 0);
+                    if (term == 1) accx[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[c], accx[t][c], 0, 0, 0);
+                    if (term == 2) accx[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[c], accx[t][c], 0, 0, 0);
+                }
             }
-        }
     };
     // weight fragments of k-step ks of a layer (fragment order [row tile][k-step][lane][8 halves], k_split_f32_frag): one 16-byte load
     // per lane, one contiguous KB per wave
     auto load_a = [&](const _Float16 *Wh_, const _Float16 *Wl_, int ldw, int ks, h8_t (&ah)[2], h8_t (&al)[2]) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const long long off = (((long long) (on[t] ? wave + 8 * t : 0) * (ldw >> 4) + ks) * 64 + lane) * 8;
+            const long long off = (((long long) ((FULL || on[t]) ? wave + 8 * t : 0) * (ldw >> 4) + ks) * 64 + lane) * 8;
             ah[t] = *reinterpret_cast<const h8_t *>(Wh_ + off);
             al[t] = *reinterpret_cast<const h8_t *>(Wl_ + off);
         }
@@ -231,7 +235,7 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
     auto store_layer = [&](const float *bias) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            if (!on[t]) continue;
+            if (!FULL && !on[t]) continue;
             const int tile = wave + 8 * t;
 #pragma unroll
             for (int c = 0; c < 2; ++c)
@@ -322,12 +326,14 @@ void launch_mlp_forward_x3(const MlpArgs &a, const void *W1h, const void *W1l, c
     const size_t lds = (size_t) 2 * TM * HS * 2 + TM * 3 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_forward_x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_forward_x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_forward_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         attr_set = true;
     }
     MlpX3Weights w{(const _Float16 *) W1h, (const _Float16 *) W1l, (const _Float16 *) Whh, (const _Float16 *) Whl};
     const long long blocks = (a.nvox + TM - 1) / TM;
-    k_mlp_forward_x3<<<dim3((unsigned) blocks), dim3(512), lds, s>>>(a, w);
+    if (a.nn == MAXN) k_mlp_forward_x3<true><<<dim3((unsigned) blocks), dim3(512), lds, s>>>(a, w);
+    else              k_mlp_forward_x3<false><<<dim3((unsigned) blocks), dim3(512), lds, s>>>(a, w);
     VFEM_HIP(hipGetLastError());
 }
 

@@ -52,6 +52,7 @@ struct MlpDwArgs {
     int slices;                             // voxel slices: one block per (slice, output tile), partial sums [slice][nn][K]
     int terms;                              // 3: hi hi + hi lo + lo hi (reference precision);  1: hi hi only
     float *partial;
+    float *colsum_partial;                  // [slice][nn] column sums of dz (the layer's bias gradient), or null
 };
 
 }  // namespace vfem

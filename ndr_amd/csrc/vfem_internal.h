@@ -325,6 +325,6 @@ struct vfem_mlp {
     // training workspace (vfem_mlp_backward*): transposed hidden weights, per-chunk activations / gradients / features
     vfem::DevBuf<uint16_t> WhTh, WhTl;           // transposed hidden weights, split, fragment order (backward data pass)
     vfem::DevBuf<uint16_t> acts, acts_lo, dz, dz_lo;   // per chunk: saved activations / gradients wrt pre-activations as (hi, lo) pairs
-    vfem::DevBuf<float> gs, partial, out_chunk;
+    vfem::DevBuf<float> gs, partial, partial_b, out_chunk;
     int bwd_terms = 3;                           // VFEM_MLP_OPT_BWD_TERMS
 };

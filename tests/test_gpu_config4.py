@@ -95,7 +95,7 @@ def test_config4_closure_fp16_kernel_vs_fp32_network():
     # north_star's 1e-5 bar is for the FEM path given a density; this number says what the MLP's fp16 operands add on top of
     # it on a field with O(1) logit spread: measured 1.06e-5 (profiles/r02_parity_deltas.json), i.e. AT the bar, not below it
     assert d_c < 2e-5, (k["compliance"], r["compliance"], d_c)
-    assert max(gerr) < 2e-2, gerr
+    assert max(gerr) < 2e-3, gerr
 
 
 def test_config4_closure_default_precision_meets_the_parity_bar():
@@ -123,7 +123,7 @@ def test_config4_closure_default_precision_meets_the_parity_bar():
                                                         "relative_compliance_delta": d_c, "param_grad_rel_l2": gerr})
     assert d_logit < 5e-5 and d_rho < 2e-5, (d_logit, d_rho)
     assert d_c < 1e-6, d_c
-    assert max(gerr) < 2e-2, gerr            # the backward pass keeps fp16 operands in both modes
+    assert max(gerr) < 2e-3, gerr            # backward at the reference's precision; what is left is the grid's fp32 coordinate rounding (measured 3.2e-4)
 
 
 def test_config4_training_steps_reduce_compliance():
