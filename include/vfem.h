@@ -212,6 +212,33 @@ int vfem_mg_pcg(vfem_mg *mg, double *x, const double *b, int max_iter, double to
                 vfem_residual_cb residual_cb, void *cb_user,
                 int *iterations_out_host, double *relres_out_host, void *stream);
 
+/* A rank's whole slab-decomposed MG-PCG solve in one call (DistributedMGSolver.pcg of ndr_amd/distributed.py, i.e.
+ * preconditionedConjugateGradient / vcycle / fullMultigrid of MG.hh:486-553, 679-732 over x-slabs).  `local` = the rank's
+ * vfem_mg_create_slab hierarchy (levels 0 .. first_replicated_level), `replicated` = the vfem_mg_create_partial hierarchy of the
+ * whole grid that every rank cycles identically from that level down.  All work vectors are the caller's (device memory):
+ * per level the iterate / right-hand side / residual of the local node grid, the replicated level's two vectors, two PCG vectors of
+ * the local fine grid and 8 doubles of scalars.  The two operations only the caller can do are callbacks, invoked on the calling
+ * thread with the stream's work enqueued so far ordered before them:
+ *   halo(user, level, field, left, right, phase): refresh the ghost planes of `field` (one of the vectors handed in) from the
+ *        left / right neighbour; phase 0 = exchange and return, 1 = start (the interior planes are swept meanwhile), 2 = finish;
+ *   allreduce(user, buf, n): sum n doubles at `buf` (device) over the ranks, in place.
+ * Both return 0 on success.  Operators must be current (vfem_mg_update_operators on both hierarchies, plus the caller's own
+ * assembly of the replicated level for sharded densities). */
+typedef struct {
+    int64_t n_planes, plane_nodes;      /* local node planes of the level, nodes per plane */
+    int64_t first_owned, last_owned;    /* local planes this rank computes (ghost planes lie outside) */
+    int64_t xoffn;                      /* global plane index of local plane 0 */
+    int32_t gl, gr;                     /* ghost planes towards the left / right neighbour (0 or 1) */
+    double *x, *b, *r;                  /* work vectors [n_planes * plane_nodes][3] (r unused on the last level) */
+} vfem_dist_level;
+typedef int (*vfem_halo_fn)(void *user, int level, double *field, int left, int right, int phase);
+typedef int (*vfem_allreduce_fn)(void *user, double *device_buffer, int64_t n);
+int vfem_mg_pcg_slab(vfem_mg *local, vfem_mg *replicated, int first_replicated_level, const vfem_dist_level *levels_host, int rank,
+                     int world, double *replicated_x, double *replicated_b, double *x, const double *b, double *work_d, double *work_Ad,
+                     double *scalars8, int max_iter, double tol, int mg_iterations, int mg_smoothing_iterations, int full_multigrid,
+                     int overlap_sweeps, vfem_halo_fn halo, vfem_allreduce_fn allreduce, void *callback_user,
+                     vfem_residual_cb residual_cb, void *residual_user, int *iterations_out, double *relres_out, void *stream);
+
 /* ---- generic path: every instantiation other than the tuned <1,1,1> one.  TensorProductSimulator<1,1> / <2,2> (2-D, plane
  * stress, ElasticityTensor.hh:100-133; the reference binds <1,1>, VoxelFEM.cc:226) and <2,2,2>; MultigridSolver of the same
  * degrees (MG.hh, templates generic in Degrees...).  Nodal fields [numNodes][N], node grid (p*ne+1) per axis, last axis

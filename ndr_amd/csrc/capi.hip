@@ -1073,6 +1073,184 @@ int vfem_mg_pcg(vfem_mg *mg, double *x, const double *b, int max_iter, double to
     VFEM_CATCH
 }
 
+// ---- slab-decomposed MG-PCG driven from here (round 4) ----------------------------------------------------------------------
+// ndr_amd/distributed.py drove the distributed cycle from Python: ~600 ctypes calls per PCG iteration, 5-6.6 ms of host time per
+// iteration measured by the rank proxy (profiles/r04_rank_proxy_python_driver.json) against the 2.0 / 12 ms a rank has at 256^3 /
+// 512^3 on eight ranks.  Here a rank's whole solve is ONE call; the two things only the host language can do -- refresh ghost planes
+// from the neighbours, sum a few doubles over the ranks (torch.distributed: RCCL on the GPU box, gloo in the tests) -- are callbacks.
+// Control flow = DistributedMGSolver's (vcycle / full_multigrid / smooth with the parity-aware, boundary-planes-first exchanges),
+// itself MG.hh:486-553, 679-732; all work vectors belong to the caller, so a callback can map a pointer back to its own array.
+}  // extern "C"
+namespace {
+struct DistDriver {
+    vfem_mg *loc, *rep;
+    int T, rank, world, nsmooth;
+    bool overlap;
+    const vfem_dist_level *g;
+    double *xT, *bT;
+    vfem_halo_fn halo_fn;
+    vfem_allreduce_fn allreduce_fn;
+    void *user;
+    hipStream_t s;
+
+    void halo(int l, double *f, bool left = true, bool right = true, int phase = 0) {
+        if (world == 1 || !(g[l].gl || g[l].gr)) return;
+        if (halo_fn(user, l, f, left ? 1 : 0, right ? 1 : 0, phase) != 0) throw Error("halo exchange callback failed");
+    }
+    void allreduce(double *buf, long long n) {
+        if (world > 1 && allreduce_fn(user, buf, (int64_t) n) != 0) throw Error("all-reduce callback failed");
+    }
+    // sum over the node planes this rank counts (interface planes belong to the lower rank), then over the ranks
+    void dot(const double *a, const double *b, double *out) {
+        const vfem_dist_level &G = g[0];
+        const long long lo = G.first_owned, hi = G.last_owned + (rank == world - 1 ? 1 : 0), per = 3 * G.plane_nodes;
+        launch_dot((hi - lo) * per, a + lo * per, b + lo * per, loc->scratch.p, out, s);
+        allreduce(out, 1);
+    }
+    void smooth_colors(int l, double *x, const double *b, int forward, int first) {
+        if (!mg_smooth_half(loc, l, x, b, forward, first / 4, s)) mg_smooth(loc, l, x, b, forward, s, first, 4);
+    }
+    // one sweep of a distributed level (DistributedMGSolver.smooth): a colour group changes the planes of one global x parity, so the
+    // neighbours' ghost planes go stale only if the planes they mirror have it; where the level is swept plane by plane, the planes a
+    // neighbour waits for are relaxed first and travel while the interior is relaxed
+    void smooth(int l, double *x, const double *b, int forward) {
+        const vfem_dist_level &G = g[l];
+        const bool by_planes = overlap && vfem_mg_can_smooth_planes(loc, l);
+        for (int group = 0; group < 2; ++group) {
+            const int cx = forward ? group : 1 - group;
+            const bool send_left = G.gl && ((G.xoffn + G.first_owned + 1) & 1) == cx;
+            const bool send_right = G.gr && ((G.xoffn + G.last_owned - 1) & 1) == cx;
+            if (!(send_left || send_right) || world == 1) { smooth_colors(l, x, b, forward, 4 * group); continue; }
+            if (!by_planes) {
+                smooth_colors(l, x, b, forward, 4 * group);
+                halo(l, x, send_left, send_right, 0);
+                continue;
+            }
+            auto sweep = [&](long long lo, long long hi) {
+                if (lo > hi) return;
+                if (!mg_smooth_half(loc, l, x, b, forward, group, s, (int) lo, (int) hi)) throw Error("plane-range sweep unavailable");
+            };
+            const long long lo_plane = G.first_owned + 1, hi_plane = G.last_owned - 1;
+            long long inner_lo = G.first_owned, inner_hi = G.last_owned;
+            if (send_left) { sweep(lo_plane, lo_plane); inner_lo = lo_plane + 1; }
+            if (send_right && !(send_left && hi_plane == lo_plane)) { sweep(hi_plane, hi_plane); inner_hi = hi_plane - 1; }
+            else if (send_right) inner_hi = hi_plane - 1;
+            halo(l, x, send_left, send_right, 1);
+            sweep(inner_lo, inner_hi);
+            halo(l, x, send_left, send_right, 2);
+        }
+    }
+    // the replicated coarse hierarchy: right-hand side = sum of the ranks' disjoint planes, every rank runs the same cycle and keeps its slab
+    void coarse_cycle(bool fmg) {
+        const vfem_dist_level &G = g[T];
+        MgLevel &R = rep->lv[(size_t) T];
+        const long long lo = G.first_owned, hi = G.last_owned + (rank == world - 1 ? 1 : 0), per = 3 * G.plane_nodes;
+        const size_t bytes = (size_t) R.d.nn * 3 * sizeof(double);
+        VFEM_HIP(hipMemsetAsync(bT, 0, bytes, s));
+        VFEM_HIP(hipMemcpyAsync(bT + (G.xoffn + lo) * per, G.b + lo * per, (size_t) ((hi - lo) * per) * sizeof(double), hipMemcpyDeviceToDevice, s));
+        allreduce(bT, (long long) R.d.nn * 3);
+        VFEM_HIP(hipMemcpyAsync(R.b.p, bT, bytes, hipMemcpyDeviceToDevice, s));
+        if (fmg) full_multigrid(rep, T, nsmooth, true, s);
+        else { R.x.zero(s); vcycle(rep, T, nsmooth, true, s); }
+        VFEM_HIP(hipMemcpyAsync(G.x, R.x.p + G.xoffn * per, (size_t) (G.n_planes * per) * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    void vcycle_d(int l) {
+        if (l == T) { coarse_cycle(false); return; }
+        const vfem_dist_level &G = g[l], &C = g[l + 1];
+        MgLevel &L = loc->lv[(size_t) l], &LC = loc->lv[(size_t) l + 1];
+        launch_zero_dirichlet(L.d.nn, L.maskp, G.x, s);                  // residual system
+        for (int i = 0; i < nsmooth; ++i) smooth(l, G.x, G.b, 1);
+        mg_apply(loc, l, G.x, G.b, 1, G.r, s);
+        halo(l, G.r);
+        launch_restrict(LC.d, L.d.NX, LC.xshift, G.r, C.b, s, C.x);      // ... and the zero initial guess of the coarse level
+        vcycle_d(l + 1);
+        launch_prolong(LC.d, L.d.NX, LC.xshift, C.x, G.x, 1, s);
+        halo(l, G.x);
+        for (int i = 0; i < nsmooth; ++i) smooth(l, G.x, G.b, loc->symmetric_gs ? 0 : 1);
+    }
+    void fmg_d(int l) {
+        if (l == T) { coarse_cycle(true); return; }
+        const vfem_dist_level &G = g[l], &C = g[l + 1];
+        MgLevel &L = loc->lv[(size_t) l], &LC = loc->lv[(size_t) l + 1];
+        halo(l, G.b);
+        launch_restrict(LC.d, L.d.NX, LC.xshift, G.b, C.b, s);
+        fmg_d(l + 1);
+        launch_prolong(LC.d, L.d.NX, LC.xshift, C.x, G.x, 0, s);
+        halo(l, G.x);
+        vcycle_d(l);
+    }
+};
+}  // namespace
+extern "C" {
+int vfem_mg_pcg_slab(vfem_mg *local, vfem_mg *replicated, int first_replicated_level, const vfem_dist_level *levels, int rank, int world,
+                     double *replicated_x, double *replicated_b, double *x, const double *b, double *work_d, double *work_Ad, double *scalars,
+                     int max_iter, double tol, int mg_iterations, int mg_smoothing, int fmg, int overlap_sweeps,
+                     vfem_halo_fn halo, vfem_allreduce_fn allreduce, void *cb_user, vfem_residual_cb residual_cb, void *residual_user,
+                     int *iters_out, double *relres_out, void *stream) {
+    VFEM_TRY
+    if (!local || !local->slab) throw Error("vfem_mg_pcg_slab: the local hierarchy must come from vfem_mg_create_slab");
+    const int T = first_replicated_level;
+    if (T < 1 || T != local->L) throw Error("vfem_mg_pcg_slab: the local hierarchy must end at the first replicated level");
+    if (!replicated || replicated->slab || T > replicated->L || T < replicated->first_active) throw Error("vfem_mg_pcg_slab: level not active in the replicated hierarchy");
+    if (world > 1 && (!halo || !allreduce)) throw Error("vfem_mg_pcg_slab: callbacks missing");
+    for (int l = 0; l <= T; ++l) {
+        const MgLevel &L = local->lv[(size_t) l];
+        if (levels[l].n_planes != L.d.NX || levels[l].plane_nodes != (int64_t) L.d.NY * L.d.NZ) throw Error("vfem_mg_pcg_slab: level geometry does not match the hierarchy");
+        if (!levels[l].x || !levels[l].b || (l < T && !levels[l].r)) throw Error("vfem_mg_pcg_slab: work vector missing");
+    }
+    DistDriver D{local, replicated, T, rank, world, mg_smoothing, overlap_sweeps != 0, levels, replicated_x, replicated_b, halo, allreduce, cb_user, S(stream)};
+    hipStream_t s = D.s;
+    const vfem_dist_level &G0 = levels[0];
+    const MgLevel &L0 = local->lv[0];
+    const long long nn = L0.d.nn, n3 = 3 * nn;
+    const size_t bytes = (size_t) n3 * sizeof(double);
+    // as in vfem_mg_pcg the residual lives in the level-0 right-hand side of the cycle and the preconditioned residual is its iterate
+    double *r = G0.b, *sv = G0.x, *d = work_d, *Ad = work_Ad, *sc = scalars;
+    launch_zero_dirichlet(nn, L0.maskp, x, s);                           // (zero Dirichlet values only: DistributedMGSolver.pcg)
+    update_operators(local, s);                                          // no-ops when the caller has done it (sharded densities: it must)
+    update_operators(replicated, s);
+    double host_sc[2];
+    D.dot(b, b, sc + 4);
+    D.halo(0, x);
+    mg_apply(local, 0, x, b, 1, r, s);
+    D.dot(r, r, sc + 3);
+    VFEM_HIP(hipMemcpyAsync(host_sc, sc + 3, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    VFEM_HIP(hipStreamSynchronize(s));
+    double rr = host_sc[0];
+    const double bb = host_sc[1];
+    int it = 0;
+    while (it < max_iter && rr > tol * tol * bb) {
+        ++it;
+        if (mg_smoothing == 0) {
+            VFEM_HIP(hipMemcpyAsync(sv, r, bytes, hipMemcpyDeviceToDevice, s));
+        } else if (fmg) {
+            D.fmg_d(0);
+            for (int i = 1; i < mg_iterations; ++i) D.vcycle_d(0);
+        } else {
+            VFEM_HIP(hipMemsetAsync(sv, 0, bytes, s));
+            for (int i = 0; i < mg_iterations; ++i) D.vcycle_d(0);
+        }
+        launch_zero_dirichlet(nn, L0.maskp, sv, s);
+        launch_shift_scalar(sc, s);                                     // rMr_old = rMr
+        D.dot(r, sv, sc + 0);
+        launch_pcg_direction(n3, sv, d, sc, it == 1, s);
+        D.halo(0, d);
+        mg_apply(local, 0, d, nullptr, 0, Ad, s);
+        launch_zero_dirichlet(nn, L0.maskp, Ad, s);
+        D.dot(d, Ad, sc + 2);
+        launch_pcg_step(n3, x, r, d, Ad, sc, s);                         // x += alpha d, r -= alpha Ad
+        D.dot(r, r, sc + 3);
+        VFEM_HIP(hipMemcpyAsync(host_sc, sc + 3, sizeof(double), hipMemcpyDeviceToHost, s));
+        VFEM_HIP(hipStreamSynchronize(s));
+        rr = host_sc[0];
+        if (!(rr == rr)) throw Error("PCG produced NaN residual");
+        if (residual_cb) residual_cb(residual_user, it, std::sqrt(rr));
+    }
+    if (iters_out) *iters_out = it;
+    if (relres_out) *relres_out = bb > 0 ? std::sqrt(rr / bb) : 0.0;
+    VFEM_CATCH
+}
+
 // ---- design-update path ----
 int vfem_box_filter(const int64_t n[3], int radius, const double *in, double *out, int transpose, void *stream) {
     VFEM_TRY

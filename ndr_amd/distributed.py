@@ -769,8 +769,81 @@ class DistributedMGSolver:
         return self.x[0]
 
     # ---- PCG (MG.hh:679-732) -------------------------------------------------------------------
+    C_DRIVER_AVAILABLE = True      # degree 1: libvfem's vfem_mg_pcg_slab runs the whole solve; this class's methods are its callbacks
+
+    def _pcg_c(self, x, b, max_iter, tol, mg_iterations, nsmooth, fmg, callback):
+        """The whole solve as ONE library call (vfem_mg_pcg_slab): the cycle, the sweeps' exchange logic and the CG loop run in C++;
+        Python is entered only for the halo exchanges and the all-reduces (torch.distributed), through two callbacks.  The Python
+        driver below (`use_c_driver = False`) is the same algorithm call by call and remains the cross-check."""
+        ct, lib = self._ct, self.lib
+        from . import _lib
+
+        class _DL(ct.Structure):
+            _fields_ = [("n_planes", ct.c_int64), ("plane_nodes", ct.c_int64), ("first_owned", ct.c_int64), ("last_owned", ct.c_int64),
+                        ("xoffn", ct.c_int64), ("gl", ct.c_int32), ("gr", ct.c_int32), ("x", ct.c_void_p), ("b", ct.c_void_p), ("r", ct.c_void_p)]
+        if getattr(self, "_cwork", None) is None:
+            self._cwork = (torch.zeros_like(self.x[0]), torch.zeros_like(self.x[0]), torch.zeros(8, dtype=torch.float64, device=self.dev))
+        d, Ad, sc = self._cwork
+        by_ptr = {}
+        for t in self.x + self.b + self.r + [self.xT, self.bT, d, Ad, sc, x]:
+            by_ptr[t.data_ptr()] = t
+        arr = (_DL * len(self.geom))()
+        for l, g in enumerate(self.geom):
+            arr[l].n_planes, arr[l].plane_nodes, arr[l].first_owned, arr[l].last_owned = g.n_planes, g.plane, g.first_owned, g.last_owned
+            arr[l].xoffn, arr[l].gl, arr[l].gr = g.xoffn, g.gl, g.gr
+            arr[l].x, arr[l].b = self.x[l].data_ptr(), self.b[l].data_ptr()
+            arr[l].r = self.r[l].data_ptr() if l < len(self.r) else None
+        pending, failure = [None], [None]
+
+        def halo_cb(_user, level, ptr, left, right, phase):
+            try:
+                hx, t = self.halos[level], by_ptr[ptr]
+                if phase == 0:
+                    hx.finish(hx.start(t, bool(left), bool(right)))
+                elif phase == 1:
+                    pending[0] = hx.start(t, bool(left), bool(right))
+                else:
+                    hx.finish(pending[0])
+                    pending[0] = None
+                return 0
+            except BaseException as e:                       # an exception must not unwind through the C frames
+                failure[0] = e
+                return 1
+
+        def allreduce_cb(_user, ptr, n):
+            try:
+                base = ptr if ptr in by_ptr else sc.data_ptr()          # (scalars: an address inside the 8-double block)
+                t = by_ptr[base].view(-1)
+                off = (ptr - base) // 8
+                self._allreduce(t[off:off + n])
+                return 0
+            except BaseException as e:
+                failure[0] = e
+                return 1
+
+        HALO = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int)
+        ALLR = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int64)
+        hcb, acb = HALO(halo_cb), ALLR(allreduce_cb)
+        rcb = _lib.RESIDUAL_CB((lambda _u, it, rn: callback(it, rn))) if callback else _lib.RESIDUAL_CB()
+        its, rel = ct.c_int(0), ct.c_double(0.0)
+        status = lib.vfem_mg_pcg_slab(self.lmg, self.gmg, self.T, arr, self.rank, self.world, self._p(self.xT), self._p(self.bT),
+                                      self._p(x), self._p(b), self._p(d), self._p(Ad), self._p(sc), int(max_iter), float(tol),
+                                      int(mg_iterations), int(nsmooth), int(bool(fmg)), int(bool(self.overlap_sweeps)),
+                                      ct.cast(hcb, ct.c_void_p), ct.cast(acb, ct.c_void_p), None, rcb, None, ct.byref(its), ct.byref(rel), self._s())
+        if failure[0] is not None:
+            raise failure[0]
+        self._chk(status)
+        self.last_iterations, self.last_relative_residual = its.value, rel.value
+        return x
+
     def pcg(self, x, b, max_iter, tol, mg_iterations=1, nsmooth=1, fmg=False, callback=None):
         self._nsmooth = nsmooth
+        if self.C_DRIVER_AVAILABLE and getattr(self, "use_c_driver", True):
+            self._mg("set_symmetric_gauss_seidel")(self.lmg, int(bool(self.symmetric_gs)))
+            self._mg("set_symmetric_gauss_seidel")(self.gmg, int(bool(self.symmetric_gs)))
+            self._chk(self._mg("zero_dirichlet")(self.lmg, 0, self._p(x), self._s()))
+            self.update_operators()
+            return self._pcg_c(x, b, max_iter, tol, mg_iterations, nsmooth, fmg, callback)
         self._chk(self._mg("zero_dirichlet")(self.lmg, 0, self._p(x), self._s()))      # zero Dirichlet values only
         self.update_operators()
         bb = self.dot(b, b)

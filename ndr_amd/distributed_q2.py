@@ -165,6 +165,7 @@ class DistributedMGSolverQ2(DistributedMGSolver):
     """Slab-decomposed multigrid PCG for TensorProductSimulator<2,2,2> (one instance per rank); the cycles, the PCG recurrence
     and the reductions are the base class's."""
 
+    C_DRIVER_AVAILABLE = False     # the degree-2 cycle (27 colours in three groups, four-plane halos) is driven from Python
     _MG_PREFIX = "vfem_gmg_"
     KE_DOUBLES = 81 * 81
     COLOR_GROUPS = ((0, 9), (9, 9), (18, 9))

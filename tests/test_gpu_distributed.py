@@ -168,6 +168,52 @@ def test_distributed_pcg_matches_single_process(world, ne, levels):
         assert err < 1e-7, err
 
 
+def _driver_worker(rank, world, port, ne, levels, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from helpers import BC_CANTILEVER, MATERIAL, seeded_density
+    from ndr_amd import distributed as vd
+    dom = ([0.0, 0.0, 0.0], [2.0, 1.0, 1.0])
+    rho = torch.from_numpy(seeded_density(ne, 88)).cuda()
+    ds = vd.DistributedMGSolver(ne, dom[0], dom[1], BC_CANTILEVER, MATERIAL, levels)
+    ds.set_global_densities(rho)
+    f = ds.local_loads()
+    out = {}
+    for params in ((1, 2, True, True), (2, 1, False, True), (1, 1, True, False)):      # (mgIterations, smoothing steps, FMG, symmetric GS)
+        ds.symmetric_gs = params[3]
+        res = []
+        for c_driver in (True, False):
+            ds.use_c_driver = c_driver
+            hist = []
+            u = ds.pcg(torch.zeros_like(f), f, 60, 1e-8, params[0], params[1], params[2], callback=lambda it, rn: hist.append(rn))
+            res.append((ds.last_iterations, hist, u.clone()))
+        (it_c, h_c, u_c), (it_p, h_p, u_p) = res
+        out[params] = (it_c, it_p, max(abs(a - b) / b for a, b in zip(h_c, h_p)) if h_p else 0.0, float((u_c - u_p).abs().max() / u_p.abs().max()))
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ne,levels", [(2, (32, 16, 16), 3), (3, (48, 16, 16), 3)])
+def test_c_driver_of_the_slab_solve_equals_the_python_driver(world, ne, levels):
+    """vfem_mg_pcg_slab (the rank's whole solve in one library call, halo / all-reduce by callbacks) against the same algorithm driven
+    call by call from Python: same iteration counts, residual histories and displacements to rounding (the two differ only in the
+    summation order of the dot products), for the parameterisations of tests/test_gpu_parity.py"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = __import__('helpers').free_port()
+    procs = [ctx.Process(target=_driver_worker, args=(r, world, port, ne, levels, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for rank, out in __import__('helpers').collect_from_ranks(q, procs):
+        for params, (it_c, it_p, herr, uerr) in out.items():
+            assert it_c == it_p and it_c > 0, (params, it_c, it_p)
+            assert herr < 1e-6 and uerr < 1e-9, (params, herr, uerr)
+
+
 @pytest.mark.parametrize("world,ne,levels", [(2, (32, 16, 16), 3), (4, (64, 16, 16), 4), (3, (48, 16, 16), 3)])
 def test_distributed_pcg_with_sharded_densities(world, ne, levels):
     """no rank holds the whole density field (set_local_densities): same iterations, compliance and displacements as the

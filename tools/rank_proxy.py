@@ -57,6 +57,24 @@ def _proxy(ne, levels, world, rank, iters, c_driver=None):
         ds.set_global_densities(whole)
     f = ds.local_loads()
     f += 1e-3 * torch.randn(f.shape, dtype=torch.float64, device="cuda", generator=g)      # (a slab away from the load has f = 0: PCG would stop at once)
+    if getattr(ds, "use_c_driver", True):
+        # one library call per solve: the host side is the callbacks (device copies here) and one blocking read per iteration
+        ds.pcg(torch.zeros_like(f), f, 2, 0.0, 1, 2, True)
+        torch.cuda.synchronize()
+        for hx in ds.halos:
+            hx.messages = 0
+        t0 = time.perf_counter()
+        ds.pcg(torch.zeros_like(f), f, iters, 0.0, 1, 2, True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        done = ds.last_iterations
+        out = {"seconds_per_iteration": dt / max(done, 1), "iterations_timed": done,
+               "messages_per_iteration": sum(getattr(hx, "messages", 0) for hx in ds.halos) / max(done, 1),
+               "distributed_levels": ds.Ld + 1, "slab_elements": [ds.geom[0].nx, ne[1], ne[2]],
+               "driver": "C (vfem_mg_pcg_slab: one call per solve, callbacks for halo / all-reduce)"}
+        del ds
+        torch.cuda.empty_cache()
+        return out
     waits = [0.0]
     plain_dot = ds.dot
 
@@ -95,8 +113,9 @@ def run(world=8, grids=(256, 512), iters=5):
         ne, levels = (n, n, n), {128: 4, 256: 5, 512: 6}[n]
         t1 = _single(ne, levels, iters)
         row = {"grid": "%dx%dx%d" % ne, "levels": levels, "ranks": world, "T_1_seconds_per_iteration": t1}
-        pr = _proxy(ne, levels, world, world // 2, iters)
+        pr = _proxy(ne, levels, world, world // 2, iters, c_driver=True)
         row["rank_proxy"] = pr
+        row["rank_proxy_python_driver"] = _proxy(ne, levels, world, world // 2, iters, c_driver=False)
         row["T_rank_over_T_1_per_rank"] = pr["seconds_per_iteration"] / (t1 / world)
         row["strong_scaling_upper_bound"] = t1 / pr["seconds_per_iteration"]
         res.append(row)
