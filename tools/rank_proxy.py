@@ -42,10 +42,10 @@ def _single(ne, levels, iters):
     return dt / iters
 
 
-def _proxy(ne, levels, world, rank, iters, c_driver=None):
+def _proxy(ne, levels, world, rank, iters, c_driver=None, dist_levels=None):
     from helpers import BC_CANTILEVER, MATERIAL
     from ndr_amd import distributed as vd
-    ds = vd.DistributedMGSolver(ne, [0.0, 0.0, 0.0], [2.0, 1.0, 1.0], BC_CANTILEVER, MATERIAL, levels, proxy=(world, rank))
+    ds = vd.DistributedMGSolver(ne, [0.0, 0.0, 0.0], [2.0, 1.0, 1.0], BC_CANTILEVER, MATERIAL, levels, dist_levels=dist_levels, proxy=(world, rank))
     if c_driver is not None:
         ds.use_c_driver = bool(c_driver)
     g = torch.Generator(device="cuda").manual_seed(88)
@@ -122,6 +122,23 @@ def run(world=8, grids=(256, 512), iters=5):
     return res
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "levels":
+    # python tools/rank_proxy.py levels N grid : one rank's iteration for every choice of the number of distributed levels
+    w, n = int(sys.argv[2]), int(sys.argv[3])
+    ne, levels = (n, n, n), {128: 4, 256: 5, 512: 6}[n]
+    for ld in range(0, levels):
+        try:
+            r = _proxy(ne, levels, w, w // 2, 5, c_driver=True, dist_levels=ld)
+            print(json.dumps({"grid": n, "ranks": w, "dist_levels_arg": ld, **r}), flush=True)
+        except RuntimeError as e:
+            print(json.dumps({"grid": n, "dist_levels_arg": ld, "error": str(e)}), flush=True)
+    sys.exit(0)
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "one":
+    # python tools/rank_proxy.py one N grid [dist_levels]: a single proxy run (for rocprofv3)
+    w, n = int(sys.argv[2]), int(sys.argv[3])
+    ne, levels = (n, n, n), {128: 4, 256: 5, 512: 6}[n]
+    print(json.dumps(_proxy(ne, levels, w, w // 2, 5, c_driver=True, dist_levels=int(sys.argv[4]) if len(sys.argv) > 4 else None)))
+    sys.exit(0)
 if __name__ == "__main__":
     w = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     grids = tuple(int(a) for a in sys.argv[2:]) or (256, 512)
