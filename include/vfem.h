@@ -53,6 +53,9 @@ enum {
     VFEM_OPT_Q2_IMPL      = 6,   /* vfem_gsim: degree-2 apply 0 marching, 1 dense gather, 2 pencil */
     VFEM_OPT_DMA_CHUNKS   = 7,   /* x-chunks of the marching apply (0 = default) */
     VFEM_OPT_DMA_STRIP    = 9,   /* z-remainder strip tiles: 0 off, 1 on, 2 on with the main chunk length */
+    VFEM_OPT_DMA_LX       = 11,  /* z tiling of the LDS-DMA apply whose tile boundaries fall on 128-byte lines of the result (tiles advance by 57 columns):
+                                    0 off (default: measured 8 % slower at 512^3 -- nine full tiles against eight and a strip --, profiles/r04_apply_lx.txt),
+                                    1 where it needs no extra tile (513 = 9 x 57), 2 always */
     VFEM_OPT_GS_PAIR      = 10,  /* level-0 Gauss-Seidel: fused z-colour pairs (1) or one launch per colour (0) */
     VFEM_OPT_L1_DIAG      = 12,  /* level-1 Gauss-Seidel: diagonal blocks precomputed per operator update (1) or inside every sweep (0) */
     VFEM_OPT_GS_RESIDENT  = 13,  /* level-0 Gauss-Seidel: K0 held in SGPRs (1, when K0 has the 36-value structure) or coefficient table (0) */

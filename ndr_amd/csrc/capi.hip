@@ -230,7 +230,7 @@ static void mg_apply(vfem_mg *mg, int l, const double *u, const double *b, int r
         const Tuning &t = sim->tune;
         if (t.apply_impl == 0 &&
             launch_apply_dma(L.d, sim->Dm, level_E(mg, 0), sim->E.p + sim->n_store(), u, out, s, 0, -1, t.dma_chunks, t.dma_strip,
-                             res ? b : nullptr, res ? L.maskp : nullptr)) return;
+                             res ? b : nullptr, res ? L.maskp : nullptr, t.dma_lx)) return;
         launch_apply_fast(L.d, sim->Dm, level_E(mg, 0), u, b, L.maskp, res, out, s, t.apply_pd);
     }
     else if (level_uses_merged_rows(mg, l)) launch_l1_merged_apply(L.d, mg->l1mtab.p, level_E(mg, l), u, b, L.maskp, res, out, s);
@@ -549,6 +549,7 @@ int vfem_sim_set_option(vfem_sim *sim, int key, int value) {
         case VFEM_OPT_APPLY_IMPL:    t.apply_impl = value != 0; break;
         case VFEM_OPT_DMA_CHUNKS:    if (value < 0) throw Error("negative chunk count"); t.dma_chunks = value; break;
         case VFEM_OPT_DMA_STRIP:     if (value < 0 || value > 2) throw Error("strip mode must be 0..2"); t.dma_strip = value; break;
+        case VFEM_OPT_DMA_LX:        if (value < 0 || value > 2) throw Error("line-exclusive tiling mode must be 0..2"); t.dma_lx = value; break;
         case VFEM_OPT_GS_PAIR:       t.gs_pair = value != 0; break;
         case VFEM_OPT_GS_RESIDENT:   t.gs_resident = (value != 0 && sim->gs_resident_ok) ? 1 : 0; break;
         case VFEM_OPT_L1_SPLIT:      if (value != 1 && value != 2 && value != 4 && value != 8) throw Error("level-1 slot split 1, 2, 4 or 8"); t.l1_split = value; break;
@@ -619,7 +620,7 @@ int vfem_sim_apply_k(const vfem_sim *sim, const double *u, double *out, int vari
         bool done = false;
         if (variant == 0 && sim->tune.apply_impl == 0)
             done = launch_apply_dma(sim->d, sim->Dm, sim->Ep(), sim->E.p + sim->n_store(), u, out, S(stream), 0, -1,
-                                    sim->tune.dma_chunks, sim->tune.dma_strip);
+                                    sim->tune.dma_chunks, sim->tune.dma_strip, nullptr, nullptr, sim->tune.dma_lx);
         if (!done) launch_apply_fast(sim->d, sim->Dm, sim->Ep(), u, nullptr, nullptr, 0, out, S(stream), sim->tune.apply_pd);
     }
     else launch_apply_gather(sim->d, OP_MF0, sim->dK0.p, sim->Ep(), u, nullptr, nullptr, 0, out, S(stream));
@@ -631,7 +632,7 @@ int vfem_sim_apply_k_planes(const vfem_sim *sim, const double *u, double *out, i
     if (plane_lo > plane_hi) return 0;
     if (!sim->fast_ok) throw Error("plane-range apply needs the mode-space kernel (box voxels, isotropic tensor)");
     if (!launch_apply_dma(sim->d, sim->Dm, sim->Ep(), sim->E.p + sim->n_store(), u, out, S(stream), (int) plane_lo, (int) plane_hi,
-                          sim->tune.dma_chunks, sim->tune.dma_strip))
+                          sim->tune.dma_chunks, sim->tune.dma_strip, nullptr, nullptr, sim->tune.dma_lx))
         throw Error("plane-range apply needs 8-byte aligned device buffers");
     VFEM_CATCH
 }

@@ -76,11 +76,11 @@ __device__ __forceinline__ void glds16(const void *g, void *l) {
 
 // RES: out = b - K u with 0 at the fixed components (the residual of the V-cycle) instead of K u: right-hand side and mask of the
 // node a thread emits are requested one phase ahead, before the arithmetic of the plane in between
-template <int EXP, class C, bool RES = false>
+template <int EXP, class C, bool RES = false, bool LX = false>
 __device__ __forceinline__ void apply_tile(const Dims &d, const DmArgs2 &dm, const double *__restrict__ E,
                                            const double *__restrict__ u, double *__restrict__ out,
                                            int planes_per_chunk, const char *u_last, const char *e_last,
-                                           int plane_lo, int plane_hi, int kz_origin, int ztile, int ytile,
+                                           int plane_lo, int plane_hi, int kz_origin, int ztile, int ytile, int adv, int hi_node,
                                            const double *__restrict__ rhs = nullptr, const uint8_t *__restrict__ fixed = nullptr) {
     using namespace dma;
     constexpr int TY = C::TY, TZ = C::TZ, PU = C::PU, PE = C::PE, ROW_D = C::ROW_D, EROW_D = C::EROW_D;
@@ -96,7 +96,13 @@ __device__ __forceinline__ void apply_tile(const Dims &d, const DmArgs2 &dm, con
 
     const int lane = threadIdx.x, wave = threadIdx.y;
     const int tz = lane % TZ, ty = wave * C::SUB + lane / TZ;     // element column / row inside the tile (compute waves)
-    const int k0 = kz_origin + ztile * (TZ - 1) - 1;
+    // The tile computes complete sums for the node columns k0 + 1 .. k0 + TZ - 1 and EMITS those in [k0 + 1, hi_node) -- the next tile's
+    // first column, `adv` columns on (TZ - 1 = 63 in the plain tiling).  Line-exclusive tiling (lx, round 4; VERDICT r03 item 5,
+    // profiles/r04_apply_storeprobe.txt): tiles advance by 57 columns, so neighbouring tiles share six complete columns, and the
+    // boundary between two tiles of a row is moved up to the next 128-byte boundary of the ADDRESS SPACE (16 doubles): every line of the
+    // result is then written whole by one wave -- inside the reference's layout, whose 12 312-byte row pitch shifts the line grid by
+    // one node per row and per plane.  (A 64-lane wave has 63 complete columns: 57 + the 6 a line can reach back over.)
+    const int k0 = kz_origin + ztile * adv - 1;
     const int j0 = ytile * (TY - 1) - 1;
     const int p0 = plane_lo + blockIdx.x * planes_per_chunk;      // output planes [p0, p1] of [plane_lo, plane_hi]
     int p1 = p0 + planes_per_chunk - 1;
@@ -194,7 +200,15 @@ __device__ __forceinline__ void apply_tile(const Dims &d, const DmArgs2 &dm, con
     // ---- compute waves ------------------------------------------------------------------------------
     const int ej = j0 + ty, ek = k0 + tz;
     const bool elem_ok = ej >= 0 && ej < d.ny && ek >= 0 && ek < d.nz;
-    const bool out_ok = ty >= 1 && tz >= 1 && ej < d.NY && ek < d.NZ;
+    const int hi_n = hi_node < d.NZ ? hi_node : d.NZ;
+    const bool out_ok = ty >= 1 && tz >= 1 && ej < d.NY && ek < d.NZ && (LX ? ek < hi_n + 6 : ek < hi_n);
+    // line-exclusive emission, in doubles relative to the first emitted column: this thread's first component sits at e_rel, the tile's
+    // range is [t_lo, 3 (hi_n - k0 - 1) + t_hi) with t_lo / t_hi = the distance from the tile's nominal boundaries up to the next
+    // multiple of 16 doubles of the address space (0 at the ends of a row), which depends on the row and the plane through s
+    const int span = 3 * (hi_n - (k0 + 1));
+    const int srow = LX ? (int) (((long long) (reinterpret_cast<uintptr_t>(out) >> 3) + 3LL * ((long long) ej * d.NZ + (k0 + 1))) & 15) : 0;
+    const int sp15 = (int) ((3 * ((long long) d.NY * d.NZ)) & 15);
+    const bool round_lo = LX && k0 + 1 > 0, round_hi = LX && hi_n < d.NZ;
     // parities of the rows this thread consumes (node rows ty, ty+1; element row ty)
     int rpar[2], erpar;
 #pragma unroll
@@ -273,6 +287,14 @@ __device__ __forceinline__ void apply_tile(const Dims &d, const DmArgs2 &dm, con
             return;
         }
         if (NT) { __builtin_nontemporal_store(w[0], &out[3 * n]); __builtin_nontemporal_store(w[1], &out[3 * n + 1]); __builtin_nontemporal_store(w[2], &out[3 * n + 2]); }
+        else if (LX) {
+            const int sl = (srow + i * sp15) & 15;                              // first emitted column of this row and plane, in doubles mod 16
+            const int t_lo = round_lo ? ((-sl) & 15) : 0, t_hi = span + (round_hi ? ((-(sl + span)) & 15) : 0);
+            const int e_rel = 3 * (tz - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (e_rel + c >= t_lo && e_rel + c < t_hi) out[3 * n + c] = w[c];
+        }
         else { out[3 * n] = w[0]; out[3 * n + 1] = w[1]; out[3 * n + 2] = w[2]; }
     };
 
@@ -406,32 +428,35 @@ __device__ __forceinline__ void apply_tile(const Dims &d, const DmArgs2 &dm, con
 // One launch for both tile shapes: blocks with blockIdx.y < n_main are main tiles; blockIdx.y == n_main is the strip over the
 // last node columns (origin `strip_origin`), which needs fewer y tiles -- the surplus blocks leave at once.  (As a launch of
 // its own the strip's few blocks marched alone at the end and gave back half of what they save.)
-template <int EXP>
+template <int EXP, bool LX>
 __global__ void __launch_bounds__(64 * (dma::WAVES + dma::NW)) k_apply_dma(Dims d, DmArgs2 dm, const double *__restrict__ E,
                                                       const double *__restrict__ u, double *__restrict__ out,
                                                       int planes_per_chunk, const char *u_last, const char *e_last,
-                                                      int plane_lo, int plane_hi, int n_main, int strip_origin, int strip_ytiles, int strip_ppc) {
+                                                      int plane_lo, int plane_hi, int n_main, int strip_origin, int strip_ytiles, int strip_ppc, int adv) {
     if ((int) blockIdx.y < n_main) {
         if ((int) blockIdx.z * (dma::Main::TY - 1) > d.NY - 1) return;      // the grid's z extent covers the main shape's y tiles
-        apply_tile<EXP, dma::Main>(d, dm, E, u, out, planes_per_chunk, u_last, e_last, plane_lo, plane_hi, 0, (int) blockIdx.y, (int) blockIdx.z);
+        const int hi = (int) blockIdx.y + 1 < n_main ? ((int) blockIdx.y + 1) * adv : strip_origin;
+        apply_tile<EXP, dma::Main, false, LX>(d, dm, E, u, out, planes_per_chunk, u_last, e_last, plane_lo, plane_hi, 0, (int) blockIdx.y, (int) blockIdx.z, adv, hi);
     } else {
         if (EXP != 0 || (int) blockIdx.z >= strip_ytiles) return;
         // the strip may use longer x-chunks than the main tiles (fewer, longer blocks); chunks beyond its last plane leave inside
-        if (EXP == 0) apply_tile<0, dma::Strip>(d, dm, E, u, out, strip_ppc, u_last, e_last, plane_lo, plane_hi, strip_origin, 0, (int) blockIdx.z);
+        if (EXP == 0) apply_tile<0, dma::Strip, false, LX>(d, dm, E, u, out, strip_ppc, u_last, e_last, plane_lo, plane_hi, strip_origin, 0, (int) blockIdx.z, dma::Strip::TZ - 1, d.NZ);
     }
 }
 
+template <bool LX>
 __global__ void __launch_bounds__(64 * (dma::WAVES + dma::NW)) k_residual_dma(Dims d, DmArgs2 dm, const double *__restrict__ E,
                                                       const double *__restrict__ u, double *__restrict__ out,
                                                       int planes_per_chunk, const char *u_last, const char *e_last,
-                                                      int plane_lo, int plane_hi, int n_main, int strip_origin, int strip_ytiles, int strip_ppc,
+                                                      int plane_lo, int plane_hi, int n_main, int strip_origin, int strip_ytiles, int strip_ppc, int adv,
                                                       const double *__restrict__ rhs, const uint8_t *__restrict__ fixed) {
     if ((int) blockIdx.y < n_main) {
         if ((int) blockIdx.z * (dma::Main::TY - 1) > d.NY - 1) return;
-        apply_tile<0, dma::Main, true>(d, dm, E, u, out, planes_per_chunk, u_last, e_last, plane_lo, plane_hi, 0, (int) blockIdx.y, (int) blockIdx.z, rhs, fixed);
+        const int hi = (int) blockIdx.y + 1 < n_main ? ((int) blockIdx.y + 1) * adv : strip_origin;
+        apply_tile<0, dma::Main, true, LX>(d, dm, E, u, out, planes_per_chunk, u_last, e_last, plane_lo, plane_hi, 0, (int) blockIdx.y, (int) blockIdx.z, adv, hi, rhs, fixed);
     } else {
         if ((int) blockIdx.z >= strip_ytiles) return;
-        apply_tile<0, dma::Strip, true>(d, dm, E, u, out, strip_ppc, u_last, e_last, plane_lo, plane_hi, strip_origin, 0, (int) blockIdx.z, rhs, fixed);
+        apply_tile<0, dma::Strip, true, LX>(d, dm, E, u, out, strip_ppc, u_last, e_last, plane_lo, plane_hi, strip_origin, 0, (int) blockIdx.z, dma::Strip::TZ - 1, d.NZ, rhs, fixed);
     }
 }
 
@@ -439,7 +464,7 @@ __global__ void __launch_bounds__(64 * (dma::WAVES + dma::NW)) k_residual_dma(Di
 // rhs != null: out = rhs - K u, 0 where `fixed` (may be null) has the component's bit set
 bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, const double *E_alloc_end, const double *u,
                       double *out, hipStream_t s, int plane_lo, int plane_hi, int g_dma_chunks, int g_dma_strip,
-                      const double *rhs, const uint8_t *fixed) {
+                      const double *rhs, const uint8_t *fixed, int g_dma_lx) {
     using namespace dma;
     if (plane_hi < 0 || plane_hi > d.NX - 1) plane_hi = d.NX - 1;
     if (plane_lo < 0) plane_lo = 0;
@@ -459,11 +484,18 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
     auto last_piece = [](const char *end) { return reinterpret_cast<const char *>((reinterpret_cast<uintptr_t>(end) - 1) & ~(uintptr_t) 15); };
     const int g_apply_skeleton = ablate_apply();
     // z tiling: 63 node columns per main tile; a remainder of at most 15 columns goes to the strip shape (47 x 15 per block)
-    const int wz = Main::TZ - 1;
+    int wz = Main::TZ - 1;
     int n_main = (d.NZ + wz - 1) / wz, rem = 0;
     if (g_dma_strip && g_apply_skeleton == 0 && d.NZ > wz) {
         const int r = d.NZ - wz * (d.NZ / wz);
         if (r > 0 && r <= Strip::TZ - 1) { n_main = d.NZ / wz; rem = r; }
+    }
+    // line-exclusive tiling (see apply_tile): main tiles advance by TZ - 7 = 57 columns and split rows on 128-byte boundaries.  g_dma_lx:
+    // 0 off, 2 on, 1 (default) on when it needs no more z tiles than the plain tiling has blocks in z (513 = 9 x 57: as many as 8 + strip)
+    int lx = 0;
+    if (VFEM_DMA_MAIN_SUB == 1 && g_apply_skeleton == 0 && d.NZ > Main::TZ - 1 && g_dma_lx != 0) {
+        const int alx = Main::TZ - 7, nlx = (d.NZ + alx - 1) / alx;
+        if (g_dma_lx == 2 || nlx <= n_main + (rem > 0 ? 1 : 0)) { lx = 1; wz = alx; n_main = nlx; rem = 0; }
     }
     const int ytiles = (d.NY + Main::TY - 2) / (Main::TY - 1), strip_ytiles = rem > 0 ? (d.NY + Strip::TY - 2) / (Strip::TY - 1) : 0;
     const dim3 grd(gx, (unsigned) (n_main + (rem > 0 ? 1 : 0)), (unsigned) ytiles), blk(64, WAVES + NW, 1);
@@ -471,25 +503,29 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
     const int strip_ppc = (g_dma_strip == 2 || gx < 2) ? ppc : 2 * ppc;
     static_assert(Main::LDS_BYTES == Strip::LDS_BYTES, "both tile shapes use the same dynamic LDS size");
     const char *ul = last_piece(u_end), *el = last_piece(e_end);
-#define VFEM_DMA_LAUNCH(X)                                                                                                   \
+#define VFEM_DMA_LAUNCH2(X, L)                                                                                               \
     do {                                                                                                                     \
         static bool attr = false;                                                                                            \
         if (!attr) {                                                                                                         \
-            VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) Main::LDS_BYTES)); \
+            VFEM_HIP(hipFuncSetAttribute((const void *) k_apply_dma<X, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) Main::LDS_BYTES)); \
             attr = true;                                                                                                     \
         }                                                                                                                    \
-        k_apply_dma<X><<<grd, blk, Main::LDS_BYTES, s>>>(d, dm, E, u, out, ppc, ul, el, plane_lo, plane_hi, n_main, wz * n_main, strip_ytiles, strip_ppc); \
+        k_apply_dma<X, L><<<grd, blk, Main::LDS_BYTES, s>>>(d, dm, E, u, out, ppc, ul, el, plane_lo, plane_hi, n_main, rem > 0 ? wz * n_main : d.NZ, strip_ytiles, strip_ppc, wz); \
     } while (0)
+#define VFEM_DMA_LAUNCH(X) VFEM_DMA_LAUNCH2(X, false)
     if (rhs) {
         static bool attr = false;
         if (!attr) {
-            VFEM_HIP(hipFuncSetAttribute((const void *) k_residual_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int) Main::LDS_BYTES));
+            VFEM_HIP(hipFuncSetAttribute((const void *) k_residual_dma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) Main::LDS_BYTES));
+            VFEM_HIP(hipFuncSetAttribute((const void *) k_residual_dma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) Main::LDS_BYTES));
             attr = true;
         }
-        k_residual_dma<<<grd, blk, Main::LDS_BYTES, s>>>(d, dm, E, u, out, ppc, ul, el, plane_lo, plane_hi, n_main, wz * n_main, strip_ytiles, strip_ppc, rhs, fixed);
+        if (lx) k_residual_dma<true><<<grd, blk, Main::LDS_BYTES, s>>>(d, dm, E, u, out, ppc, ul, el, plane_lo, plane_hi, n_main, rem > 0 ? wz * n_main : d.NZ, strip_ytiles, strip_ppc, wz, rhs, fixed);
+        else k_residual_dma<false><<<grd, blk, Main::LDS_BYTES, s>>>(d, dm, E, u, out, ppc, ul, el, plane_lo, plane_hi, n_main, rem > 0 ? wz * n_main : d.NZ, strip_ytiles, strip_ppc, wz, rhs, fixed);
         VFEM_HIP(hipGetLastError());
         return true;
     }
+    if (lx) { VFEM_DMA_LAUNCH2(0, true); VFEM_HIP(hipGetLastError()); return true; }
 #ifdef VFEM_ABLATION
     switch (g_apply_skeleton) {
         case 1: VFEM_DMA_LAUNCH(1); break;
@@ -509,6 +545,7 @@ bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, con
     VFEM_DMA_LAUNCH(0);
 #endif
 #undef VFEM_DMA_LAUNCH
+#undef VFEM_DMA_LAUNCH2
     VFEM_HIP(hipGetLastError());
     return true;
 }

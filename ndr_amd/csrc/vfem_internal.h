@@ -81,6 +81,7 @@ struct Tuning {
     int apply_pd = 2;       // register-staged kernel: node planes in flight (2..4)
     int dma_chunks = 0;     // x-chunks of the marching blocks (0 = default)
     int dma_strip = 1;      // 0: main tile shape only, 1: strip tiles for the left-over node columns, 2: strip with main-length chunks
+    int dma_lx = 0;         // line-exclusive z tiling of the LDS-DMA apply: 0 off (default: measured slower), 1 where it costs no extra z tile, 2 always
     int gs_variant = 0;     // 0: row-streaming / symmetric sweeps, 1: plain gather sweeps
     int gs_pair = 1;        // level 0: both z colours of a row in one launch
     int gs_resident = 0;    // level 0: K0 kept in 72 SGPRs (36 distinct values; set when build_gs_coef reproduces K0 bit for bit)
@@ -115,7 +116,7 @@ void launch_apply_fast(const Dims &d, const double *Dm_host, const double *E, co
 // LDS-DMA version of the plain apply (mode 0); returns false when it must not be used for these buffers
 bool launch_apply_dma(const Dims &d, const double *Dm_host, const double *E, const double *E_alloc_end, const double *u,
                       double *out, hipStream_t s, int plane_lo = 0, int plane_hi = -1, int chunks = 0, int strip = 1,
-                      const double *rhs = nullptr, const uint8_t *fixed = nullptr);      // rhs: out = rhs - K u, 0 at fixed components
+                      const double *rhs = nullptr, const uint8_t *fixed = nullptr, int line_exclusive = 0);      // rhs: out = rhs - K u, 0 at fixed components
 
 // colours are processed in the reference order (global parity); `xparity` = global x-parity of local plane 0,
 // [first, first+count) selects a sub-range of the 8 colours (half sweeps between halo exchanges)

@@ -1,6 +1,8 @@
 """-m gpu parity tests: every HIP operator (through the C ABI, via ndr_amd.pyVoxelFEM) against the CPU
 oracle on the same seeded inputs.  fp64 stencil-class operators must agree to 1e-11 relative (different
 summation order only); the converged solve to 1e-8 on compliance (north_star asks 1e-5)."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -56,6 +58,7 @@ def test_apply_k_tile_shapes_agree(ne):
     u = np.random.default_rng(4).standard_normal((o.num_nodes, 3))
     ud = torch.as_tensor(u, device="cuda")
     res = {}
+    _lib.check(lib.vfem_sim_set_option(t._h, 11, 0))               # VFEM_OPT_DMA_LX off: the plain 63-column tiling
     for mode in (1, 2, 0):
         _lib.check(lib.vfem_sim_set_option(t._h, 9, mode))         # VFEM_OPT_DMA_STRIP, a property of this simulator only
         out = torch.empty_like(ud)
@@ -63,6 +66,15 @@ def test_apply_k_tile_shapes_agree(ne):
         res[mode] = out
     assert torch.equal(res[1], res[0]) and torch.equal(res[2], res[0])
     assert relerr(res[1].cpu().numpy(), o.apply_k(u)) < 1e-12
+    # the line-exclusive tiling (57-column tiles, rows split on 128-byte boundaries of the result): every double is written by exactly
+    # one tile and has the value the plain tiling gives it, also into a result buffer that starts 8 or 24 bytes off a line
+    _lib.check(lib.vfem_sim_set_option(t._h, 11, 2))
+    for off in (0, 1, 3):
+        buf = torch.full((ud.numel() + 16,), float("nan"), dtype=torch.float64, device="cuda")
+        out = buf[off:off + ud.numel()]
+        _lib.check(lib.vfem_sim_apply_k(t._h, _ptr(ud), ctypes.c_void_p(out.data_ptr()), 0, _stream()))
+        assert torch.equal(out.view_as(res[0]), res[0]), off
+        assert bool(torch.isnan(buf[:off]).all()) and bool(torch.isnan(buf[off + ud.numel():]).all())
 
 
 def test_apply_k_linearity_and_symmetry_large():

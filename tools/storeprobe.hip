@@ -17,18 +17,24 @@
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-struct Geo { int NX, NY, NZ, pitch, width, rows, planes_per_chunk; };
+// round 4: `skew` = 1 keeps the REFERENCE layout (pitch 513) and lets the window a wave writes start on a 384-byte
+// boundary of the address space instead: a node is 24 B, 16 nodes are three whole lines, and the row pitch 513 = 1 (mod 16), so the
+// window of row (i, y) is shifted by s = (i NY + y) mod 16 nodes against the tile grid (a parallelogram tile): 64 nodes = 12 whole lines.
+struct Geo { int NX, NY, NZ, pitch, width, rows, planes_per_chunk, skew; };
 
 template <int VEC, int BARRIER, int MIX>
 __global__ void __launch_bounds__(768) k_store(Geo g, const double *__restrict__ in, double *__restrict__ out) {
     const int lane = threadIdx.x, w = threadIdx.y;
-    const int z = blockIdx.y * g.width + lane, y = blockIdx.z * g.rows + w;
-    const bool ok = lane < g.width && z < g.NZ && w < g.rows && y < g.NY;
+    const int y = blockIdx.z * g.rows + w;
+    const int z0 = blockIdx.y * g.width + lane;
+    const bool ok0 = lane < g.width && w < g.rows && y < g.NY;
     const int p0 = blockIdx.x * g.planes_per_chunk;
     int p1 = p0 + g.planes_per_chunk;
     if (p1 > g.NX) p1 = g.NX;
     double acc = 0.0;
     for (int i = p0; i < p1; ++i) {
+        const int z = g.skew ? z0 - (int) (((long long) i * g.NY + y) & 15) : z0;
+        const bool ok = ok0 && z >= 0 && z < g.NZ;
         const long long n = ((long long) i * g.NY + y) * g.pitch + z;
         if (ok) {
             double v0 = 1.0 + i, v1 = 2.0 + lane, v2 = 3.0 + w;
@@ -74,7 +80,7 @@ int main() {
         fflush(stdout);
     };
     run("linear fill, 8 B per lane (calibration)", (double) NX * NY * NZ * 24, [&] { k_fill<<<8192, 256>>>(out, (long long) NX * NY * NZ * 3); });
-    struct Case { const char *name; int pitch, width, vec, barrier, mix; };
+    struct Case { const char *name; int pitch, width, vec, barrier, mix, skew; };
     const Case cases[] = {
         {"apply geometry: pitch 513, 63 nodes per wave row, 3 x 8 B, barrier per plane", 513, 63, 0, 1, 0},
         {"same without the barrier", 513, 63, 0, 0, 0},
@@ -85,10 +91,13 @@ int main() {
         {"padded, 64 wide, 16 B + 8 B stores", 528, 64, 1, 1, 0},
         {"apply geometry + load of the same segment (1R + 1W)", 513, 63, 0, 1, 1},
         {"padded 528 / 64 wide + load of the same segment (1R + 1W)", 528, 64, 0, 1, 1},
+        {"REFERENCE layout, 64-node windows on 384-byte boundaries (parallelogram tile)", 513, 64, 0, 1, 0, 1},
+        {"same with 16 B + 8 B stores", 513, 64, 1, 1, 0, 1},
+        {"same + load of the same segment (1R + 1W)", 513, 64, 0, 1, 1, 1},
     };
     for (const Case &c : cases) {
-        Geo g{NX, NY, NZ, c.pitch, c.width, 11, (NX + 7) / 8};
-        const dim3 grd(8, (NZ + c.width - 1) / c.width, (NY + g.rows - 1) / g.rows), blk(64, 12, 1);
+        Geo g{NX, NY, NZ, c.pitch, c.width, 11, (NX + 7) / 8, c.skew};
+        const dim3 grd(8, (NZ + (c.skew ? 15 : 0) + c.width - 1) / c.width, (NY + g.rows - 1) / g.rows), blk(64, 12, 1);
         const double moved = (double) NX * NY * NZ * 24 * (c.mix ? 2 : 1);
         auto launch = [&] {
             if (c.vec == 0 && c.barrier == 1 && c.mix == 0) k_store<0, 1, 0><<<grd, blk>>>(g, in, out);
@@ -101,13 +110,16 @@ int main() {
     // occupancy: the apply runs ONE block per CU (147 KB of LDS); the cases above let up to two blocks share a CU.  Repeat the
     // reference geometry with 120 KB of dynamic LDS requested so that only one block fits
     {
-        Geo g{NX, NY, NZ, 513, 63, 11, (NX + 7) / 8};
+        Geo g{NX, NY, NZ, 513, 63, 11, (NX + 7) / 8, 0};
         const dim3 grd(8, (NZ + 62) / 63, (NY + 10) / 11), blk(64, 12, 1);
         hipFuncSetAttribute((const void *) k_store<0, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
         run("apply geometry, one block per CU (120 KB LDS requested)", (double) NX * NY * NZ * 24, [&] { k_store<0, 1, 0><<<grd, blk, 120 * 1024>>>(g, in, out); });
-        Geo gp{NX, NY, NZ, 528, 64, 11, (NX + 7) / 8};
+        Geo gp{NX, NY, NZ, 528, 64, 11, (NX + 7) / 8, 0};
         const dim3 grdp(8, (NZ + 63) / 64, (NY + 10) / 11);
         run("padded 528 / 64 wide, one block per CU", (double) NX * NY * NZ * 24, [&] { k_store<0, 1, 0><<<grdp, blk, 120 * 1024>>>(gp, in, out); });
+        Geo gs{NX, NY, NZ, 513, 64, 11, (NX + 7) / 8, 1};
+        const dim3 grds(8, (NZ + 15 + 63) / 64, (NY + 10) / 11);
+        run("reference layout, 64-node windows on 384-byte boundaries, one block per CU", (double) NX * NY * NZ * 24, [&] { k_store<0, 1, 0><<<grds, blk, 120 * 1024>>>(gs, in, out); });
     }
     return 0;
 }
