@@ -63,8 +63,6 @@ enum {
     VFEM_OPT_STENCIL_SPLIT = 18, /* stored-stencil levels: the 27 neighbour blocks of a node shared by three waves (1, default) or one lane (0) */
     VFEM_OPT_GS_MARCH     = 19,  /* level-0 Gauss-Seidel: plane-resident x-marching half sweeps on grids of at least 12 M nodes (1, default), always (2),
                                     or the row-streaming kernels (0); the two agree to rounding (different summation order) */
-    VFEM_OPT_GS_MARCH_FORM = 23, /* marching sweep: 1 a node as two x-mirrored half waves; 2 (default) one node per lane with the moduli summed per neighbour
-                                    (a quarter fewer operations in four waves instead of seven; 7.15 against 7.7 ms per sweep at 512^3); agree to rounding */
     VFEM_OPT_GS_MARCH_CHUNKS = 20, /* x-chunks of the marching sweep (0 = default) */
     VFEM_OPT_L1_STORED    = 21,  /* level 1 (degree 1): operator evaluated on the fly from the child moduli (0), stored as a 27-point block stencil, 1944 B
                                     per node (1), or stored as half of it using the symmetry, 1008 B per node (2); DESIGN section 3.2 */

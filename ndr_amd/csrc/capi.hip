@@ -254,22 +254,20 @@ static bool gs_march_wanted(const MgLevel &L, const Tuning &t) {
     return t.gs_march == 2 || (t.gs_march == 1 && L.d.nn >= 12000000);
 }
 
-// the marching sweep's form: one node per lane (the neighbour-kind table of K0) when K0 has the mirror symmetry it needs, else
-// (or by VFEM_OPT_GS_MARCH_FORM = 1) the mirrored half waves
-static const double *march_form2_table(const vfem_sim *sim) {
-    return (sim->tune.gs_march_form == 2 && sim->k0_mirror_ok) ? sim->dGsTab.p + GS_TABLE_DOUBLES + 84 : nullptr;
+// the marching sweep sums a node row per neighbour kind, which needs K0 with the mirror symmetry of a box voxel and an isotropic tensor:
+// the neighbour-kind table of K0, or null (then the row kernels do the sweep)
+static const double *march_table(const vfem_sim *sim) {
+    return sim->k0_mirror_ok ? sim->dGsTab.p + GS_TABLE_DOUBLES + 84 : nullptr;
 }
 
 // level 0: solve data of the marching sweeps, recomputed when the moduli (or the material / Dirichlet mask: both bump the version) changed
 static void gs_solve_data(vfem_mg *mg, hipStream_t s) {
     MgLevel &L = mg->lv[0];
     const vfem_sim *sim = mg->fine;
-    const int per = march_form2_table(sim) ? 3 : 6;
-    if (L.gs_sd.p && L.gs_sd_version == sim->operator_version && L.gs_sd_per == per) return;
-    L.gs_sd.reserve((size_t) L.d.nn * 6);
-    launch_gs_solve_data(L.d, sim->dK0.p, level_E(mg, 0), L.maskp, L.gs_sd.p, s, per);
+    if (L.gs_sd.p && L.gs_sd_version == sim->operator_version) return;
+    L.gs_sd.reserve((size_t) L.d.nn * 3);
+    launch_gs_solve_data(L.d, sim->dK0.p, level_E(mg, 0), L.maskp, L.gs_sd.p, s);
     L.gs_sd_version = sim->operator_version;
-    L.gs_sd_per = per;
 }
 
 // n consecutive sweeps of level l in one direction.  Level 0 runs them as marching half sweeps (kernels_gs_march.hip) when
@@ -279,22 +277,21 @@ static void mg_smooth_n(vfem_mg *mg, int l, double *u, const double *b, int forw
     MgLevel &L = mg->lv[l];
     const vfem_sim *sim = mg->fine;
     const Tuning &t = sim->tune;
-    if (!(l == 0 && L.kind == OP_MF0 && gs_march_wanted(L, t) && t.gs_variant == 0 && t.gs_resident && sim->dGsTab.p && n > 0)) {
+    if (!(l == 0 && L.kind == OP_MF0 && gs_march_wanted(L, t) && t.gs_variant == 0 && t.gs_resident && sim->dGsTab.p && sim->k0_mirror_ok && n > 0)) {
         for (int i = 0; i < n; ++i) mg_smooth(mg, l, u, b, forward, s);
         return;
     }
     L.tmp.reserve((size_t) L.d.nn * 3);
     gs_solve_data(mg, s);
     double *cur[2] = {u, u};                         // where the planes of local parity 0 / 1 currently live
-    const double *coef = sim->dGsTab.p + GS_TABLE_DOUBLES;
     for (int i = 0; i < n; ++i)
         for (int half = 0; half < 2; ++half) {
             const int cx = forward ? half : 1 - half;                    // colour groups 0-3 / 4-7 of MG.hh:292-310, reversed for a backward sweep
             const int cxl = cx ^ (L.xparity & 1);
             if (cxl > L.d.NX - 1) continue;
             double *dst = cur[cxl] == u ? L.tmp.p : u;
-            if (!launch_gs_march_mf0(L.d, coef, level_E(mg, 0), sim->E.p, sim->E.p + sim->n_store(), cur[cxl], cur[1 - cxl], dst, b, L.gs_sd.p,
-                                     cxl, forward, t.gs_march_chunks, s, 0, -1, march_form2_table(sim), t.gs_march_form)) {
+            if (!launch_gs_march_mf0(L.d, march_table(sim), level_E(mg, 0), cur[cxl], cur[1 - cxl], dst, b, L.gs_sd.p,
+                                     cxl, forward, t.gs_march_chunks, s, 0, -1)) {
                 // buffers the kernel cannot take: finish in place with the row kernels
                 for (int par = 0; par < 2; ++par)
                     if (cur[par] != u) { launch_copy_planes(L.d, par, cur[par], u, s); cur[par] = u; }
@@ -312,14 +309,14 @@ static bool mg_smooth_half(vfem_mg *mg, int l, double *u, const double *b, int f
     MgLevel &L = mg->lv[l];
     const vfem_sim *sim = mg->fine;
     const Tuning &t = sim->tune;
-    if (!(l == 0 && L.kind == OP_MF0 && gs_march_wanted(L, t) && t.gs_variant == 0 && t.gs_resident && sim->dGsTab.p)) return false;
+    if (!(l == 0 && L.kind == OP_MF0 && gs_march_wanted(L, t) && t.gs_variant == 0 && t.gs_resident && sim->dGsTab.p && sim->k0_mirror_ok)) return false;
     const int cx = forward ? half : 1 - half;
     const int cxl = cx ^ (L.xparity & 1);
     if (cxl > L.d.NX - 1) return true;
     L.tmp.reserve((size_t) L.d.nn * 3);
     gs_solve_data(mg, s);
-    if (!launch_gs_march_mf0(L.d, sim->dGsTab.p + GS_TABLE_DOUBLES, level_E(mg, 0), sim->E.p, sim->E.p + sim->n_store(), u, u, L.tmp.p, b, L.gs_sd.p,
-                             cxl, forward, t.gs_march_chunks, s, plane_lo, plane_hi, march_form2_table(sim), t.gs_march_form)) return false;
+    if (!launch_gs_march_mf0(L.d, march_table(sim), level_E(mg, 0), u, u, L.tmp.p, b, L.gs_sd.p,
+                             cxl, forward, t.gs_march_chunks, s, plane_lo, plane_hi)) return false;
     launch_copy_planes(L.d, cxl, L.tmp.p, u, s, plane_lo, plane_hi);
     return true;
 }
@@ -555,7 +552,6 @@ int vfem_sim_set_option(vfem_sim *sim, int key, int value) {
         case VFEM_OPT_L1_SPLIT:      if (value != 1 && value != 2 && value != 4 && value != 8) throw Error("level-1 slot split 1, 2, 4 or 8"); t.l1_split = value; break;
         case VFEM_OPT_STENCIL_SPLIT: t.stencil_split = value != 0; break;
         case VFEM_OPT_GS_MARCH:      if (value < 0 || value > 2) throw Error("marching sweep mode 0..2"); t.gs_march = value; break;
-        case VFEM_OPT_GS_MARCH_FORM: if (value != 1 && value != 2) throw Error("marching sweep form 1 or 2"); t.gs_march_form = value; break;
         case VFEM_OPT_GS_MARCH_CHUNKS: if (value < 0) throw Error("negative chunk count"); t.gs_march_chunks = value; break;
         case VFEM_OPT_L1_STORED:     if (value < 0 || value > 2) throw Error("level-1 storage mode 0..2"); t.l1_stored = value; ++sim->operator_version; break;
         case VFEM_OPT_L1_MERGED:     if (value < 0 || value > 2) throw Error("level-1 row mode 0..2"); t.l1_merged = value; break;
@@ -970,7 +966,7 @@ int vfem_mg_can_smooth_planes(vfem_mg *mg, int level) {
     if (!mg || level != 0 || level > mg->L) return 0;
     const vfem_sim *sim = mg->fine;
     const MgLevel &L = mg->lv[0];
-    return (L.kind == OP_MF0 && gs_march_wanted(L, sim->tune) && sim->tune.gs_variant == 0 && sim->tune.gs_resident && sim->dGsTab.p) ? 1 : 0;
+    return (L.kind == OP_MF0 && gs_march_wanted(L, sim->tune) && sim->tune.gs_variant == 0 && sim->tune.gs_resident && sim->dGsTab.p && sim->k0_mirror_ok) ? 1 : 0;
 }
 int vfem_mg_smooth_group_planes(vfem_mg *mg, int level, double *u, const double *b, int forward, int group, int64_t plane_lo, int64_t plane_hi,
                                 void *stream) {

@@ -89,8 +89,6 @@ struct Tuning {
     int stencil_split = 1;  // stored-stencil levels above the wave-per-node threshold: 27 neighbour blocks shared by three waves (1) or one lane (0)
     int gs_march = 1;       // level 0: plane-resident x-marching half sweeps (kernels_gs_march.hip) where whole colour groups are swept; 0: row kernels
     int gs_march_chunks = 0;   // x-chunks of the marching sweep (0 = default)
-    int gs_march_form = 2;     // marching sweep: 1 a node as two x-mirrored half waves (seven compute waves); 2 one node per lane, the moduli summed per
-                               // neighbour (four compute waves; a quarter fewer operations, 4 % faster: DESIGN 3.2)
     int l1_stored = 0;      // level 1: 0 virtual Galerkin operator (sum_f E_f cK0[f] at every visit), 1 stored 27-point block stencil (1944 B per
                             // node, built once per operator update; measured slower), 2 stored HALF stencil (symmetry: 1008 B per node)
     int l1_merged = 2;      // level 1: node rows evaluated per incident element (k_gs_color_mf1_sym*, k_apply_gather<1>; 0), per mirror class by
@@ -125,12 +123,10 @@ void launch_gs_sweep_mf(const Dims &d, OpKind kind, const double *K, const doubl
                         const Tuning &tune, bool mf1_sym, const double *mf1_diag = nullptr);
 // level 0: one half sweep (the four colours of local x parity cxl) marching along x with the planes in LDS; out of place:
 // relaxed planes read from uR, the others from uO, results to dst != uR.  false: cannot run on these buffers
-bool launch_gs_march_mf0(const Dims &d, const double *coef36, const double *E, const double *E_alloc_begin, const double *E_alloc_end,
-                         const double *uR, const double *uO, double *dst, const double *b, const double *solve_data,
-                         int cxl, int forward, int chunks, hipStream_t s, int plane_lo = 0, int plane_hi = -1,
-                         const double *tab_form2 = nullptr, int form = 1);     // form 2 needs the neighbour-kind table of K0
+bool launch_gs_march_mf0(const Dims &d, const double *neighbour_kind_table, const double *E, const double *uR, const double *uO, double *dst, const double *b,
+                         const double *solve_data, int cxl, int forward, int chunks, hipStream_t s, int plane_lo = 0, int plane_hi = -1);     // form 2 needs the neighbour-kind table of K0
 // per node { 1/M00, 1/M11, 1/M22 (0 where the component is fixed), M10, M20, M21 } of the level-0 diagonal blocks M = sum_e E_e K0[n-block]
-void launch_gs_solve_data(const Dims &d, const double *K0, const double *E, const uint8_t *mask, double *sd, hipStream_t s, int per = 6);
+void launch_gs_solve_data(const Dims &d, const double *K0, const double *E, const uint8_t *mask, double *sd, hipStream_t s);
 void launch_copy_planes(const Dims &d, int par, const double *src, double *dst, hipStream_t s, int plane_lo = 0, int plane_hi = -1);
 extern long long *g_gsm_stamps;         // diagnostic stamps of the marching kernel (tools/gs_march_stamps.py), null in production
 // level 1: diagonal 3x3 blocks of the virtual Galerkin operator, [nn][9] (once per operator update)
@@ -289,9 +285,8 @@ struct MgLevel {
     vfem::DevBuf<double> Mdiag;                 // level 1: precomputed diagonal blocks [nn][9] of the virtual operator
     vfem::DevBuf<double> x, b, r;               // work vectors (m_x, m_b of MG.hh:755-756 + residual)
     vfem::DevBuf<double> tmp;                   // level 0: second copy of the field for the out-of-place marching half sweeps
-    vfem::DevBuf<double> gs_sd;                 // level 0: solve data of the marching sweeps [nn][6] (launch_gs_solve_data)
+    vfem::DevBuf<double> gs_sd;                 // level 0: solve data of the marching sweeps [nn][3] (launch_gs_solve_data)
     long long gs_sd_version = 0;                // fine->operator_version gs_sd was computed for
-    int gs_sd_per = 0;                          // doubles per node in gs_sd: 6 (marching form 1) or 3 (form 2)
 };
 
 struct vfem_mg {

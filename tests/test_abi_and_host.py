@@ -102,7 +102,7 @@ def test_region_parser_matches_reference_semantics(tmp_path):
 @pytest.mark.parametrize("source,kernels,windows", [
     ("kernels_q2.hip", ["k_apply_q2_marchILi0"], 84),
     ("kernels_l1_merged.hip", ["k_l1_mergedILi0E", "k_l1_mergedILi1E", "k_l1_mergedILi2E", "k_l1_pair_rowsILi0E", "k_l1_pair_rowsILi1E"], None),
-    ("kernels_gs_march.hip", ["k_gs_march_mf0ILi%dELi%dELi%dELi2E" % (a, f, m) for a in (0, 1) for f in (0, 1) for m in (0, 1)], None)])
+    ("kernels_gs_march.hip", ["k_gs_march_mf0ILi%dELi%dELi%dEEE" % (a, f, m) for a in (0, 1) for f in (0, 1) for m in (0, 1)], None)])
 def test_pipelined_scalar_loads_are_hazard_free(tmp_path, source, kernels, windows):
     """k_apply_q2_march (sload12_issue / sload12_wait), the level-1 per-class kernels and the node-per-lane marching sweep (coef_rows.h:
     srow_issue / srow_wait) leave scalar loads in flight across compiler-generated code; that is only safe while no instruction

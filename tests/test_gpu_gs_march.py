@@ -1,6 +1,6 @@
 """-m gpu: the plane-resident marching level-0 Gauss-Seidel (kernels_gs_march.hip; MG.hh:193-340) against the CPU oracle and
 against the row-streaming kernels.  The library uses it by itself only on grids of at least 12 M nodes, so the tests force it
-(VFEM_OPT_GS_MARCH = 2) on grids the oracle finishes in seconds; shapes put tile seams (12 x 58 owned node columns per tile)
+(VFEM_OPT_GS_MARCH = 2) on grids the oracle finishes in seconds; shapes put tile seams (14 x 58 owned node columns per tile)
 and ragged edges inside the grid."""
 import numpy as np
 import pytest
@@ -9,29 +9,28 @@ import torch
 from helpers import BC_BRIDGE, BC_CANTILEVER, make_hip, make_oracle, seeded_density
 
 pytestmark = pytest.mark.gpu
-GS_MARCH, GS_MARCH_FORM = 19, 23      # form 1: a node as two x-mirrored half waves; 2: one node per lane, moduli summed per neighbour
+GS_MARCH = 19
 
 
 def relerr(a, b):
     return float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max())
 
 
-def _force(t, mode, form=1):
+def _force(t, mode):
     from ndr_amd import _lib
     _lib.check(_lib.load().vfem_sim_set_option(t._h, GS_MARCH, mode))
-    _lib.check(_lib.load().vfem_sim_set_option(t._h, GS_MARCH_FORM, form))
 
 
-@pytest.mark.parametrize("form", [1, 2])
-@pytest.mark.parametrize("ne,bc,dom", [((8, 14, 60), BC_CANTILEVER, ([0, 0, 0], [2, 1, 1])),        # one seam in y and in z
-                                       ((6, 26, 118), BC_BRIDGE, ([0, 0, 0], [4, 2, 1])),            # NZ odd / even planes, two seams each way
-                                       ((5, 12, 58), BC_CANTILEVER, ([0, 0, 0], [2, 1, 1]))])        # tile edge = grid edge, odd element count in x
-def test_marching_sweep_matches_oracle(ne, bc, dom, form):
+@pytest.mark.parametrize("ne,bc,dom", [((8, 16, 60), BC_CANTILEVER, ([0, 0, 0], [2, 1, 1])),        # one seam in y and in z
+                                       ((6, 30, 118), BC_BRIDGE, ([0, 0, 0], [4, 2, 1])),            # NZ odd / even planes, two seams each way
+                                       ((5, 14, 58), BC_CANTILEVER, ([0, 0, 0], [2, 1, 1])),         # tile edge = grid edge, odd element count in x
+                                       ((4, 13, 7), None, ([0, 0, 0], [2, 1, 1]))])                  # a grid smaller than one tile, odd everything, no constraints
+def test_marching_sweep_matches_oracle(ne, bc, dom):
     from oracle import vfem_oracle as vo
     rho = seeded_density(ne, 88, "proxy")
     o = make_oracle(ne, dom, bc, rho)
     t = make_hip(ne, dom, bc, rho)
-    _force(t, 2, form)
+    _force(t, 2)
     omg = vo.OracleMG(o, 0, nthreads=4)
     omg.update_element_stiffness()
     tmg = t.multigridSolver(0)
@@ -49,23 +48,22 @@ def test_marching_sweep_matches_oracle(ne, bc, dom, form):
         assert np.array_equal(got[fixed], u[fixed])                  # constrained components are not touched (MG.hh:258-262)
 
 
-@pytest.mark.parametrize("form", [1, 2])
-def test_marching_and_row_kernels_agree_over_sweep_sequences(form):
+@pytest.mark.parametrize("ne", [(9, 30, 70), (6, 44, 61), (3, 29, 118)])
+def test_marching_and_row_kernels_agree_over_sweep_sequences(ne):
     """forward / backward sweeps in sequence (the scratch vector ping-pong: even counts end in place, odd ones copy back), and the
     colour groups one by one as the slab solver calls them (vfem_mg_smooth_colors)"""
     import ctypes
     from ndr_amd import _lib
     from ndr_amd.pyVoxelFEM import _ptr, _stream
     lib = _lib.load()
-    ne = (9, 30, 70)
-    t = make_hip(ne, ([0, 0, 0], [2, 1, 1]), BC_CANTILEVER, seeded_density(ne, 3))
+    t = make_hip(ne, ([0, 0, 0], [2, 1, 1]), BC_CANTILEVER if ne[0] % 2 else None, seeded_density(ne, 3))
     mg = t.multigridSolver(0)
     g = torch.Generator(device="cuda").manual_seed(11)
     u = torch.randn((mg._nn(0), 3), dtype=torch.float64, device="cuda", generator=g)
     b = torch.randn((mg._nn(0), 3), dtype=torch.float64, device="cuda", generator=g)
     out = {}
     for mode in (0, 2):
-        _force(t, mode, form)
+        _force(t, mode)
         res = []
         for fwd, sweeps in ((1, 1), (0, 1), (1, 2), (0, 3)):
             x = u.clone()
