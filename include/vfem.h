@@ -61,7 +61,7 @@ enum {
     VFEM_OPT_GS_RESIDENT  = 13,  /* level-0 Gauss-Seidel: K0 held in SGPRs (1, when K0 has the 36-value structure) or coefficient table (0) */
     VFEM_OPT_L1_SPLIT     = 15,  /* level-1 Gauss-Seidel (degree 1): waves sharing the eight element slots of a node, 1 / 2 / 4 / 8 */
     VFEM_OPT_STENCIL_SPLIT = 18, /* stored-stencil levels: the 27 neighbour blocks of a node shared by three waves (1, default) or one lane (0) */
-    VFEM_OPT_GS_MARCH     = 19,  /* level-0 Gauss-Seidel: plane-resident x-marching half sweeps on grids of at least 12 M nodes (1, default), always (2),
+    VFEM_OPT_GS_MARCH     = 19,  /* level-0 Gauss-Seidel: plane-resident x-marching half sweeps on grids of at least 0.8 M nodes (1, default), always (2),
                                     or the row-streaming kernels (0); the two agree to rounding (different summation order) */
     VFEM_OPT_GS_MARCH_CHUNKS = 20, /* x-chunks of the marching sweep (0 = default) */
     VFEM_OPT_L1_STORED    = 21,  /* level 1 (degree 1): operator evaluated on the fly from the child moduli (0), stored as a 27-point block stencil, 1944 B

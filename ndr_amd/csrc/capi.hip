@@ -248,10 +248,11 @@ static void mg_smooth(vfem_mg *mg, int l, double *u, const double *b, int forwar
                             (l == 1 && mg->fine->tune.l1_diag) ? L.Mdiag.p : nullptr);
 }
 
-// gs_march: 0 row kernels, 1 marching kernel on grids where it wins (measured per sweep, marching / rows: 512^3 7.7 / 9.6 ms, 256^3
-// 1.30 / 1.35, 128^3 0.25 / 0.23: its 12 x 58 tiles fit 2^k + 1 nodes badly on small grids), 2 marching kernel always
+// gs_march: 0 row kernels, 1 marching kernel on grids where it wins (measured per sweep, marching / rows, profiles/r04_gs_march_chunks.txt:
+// 512^3 6.27 / 9.76 ms, 256^3 0.98 / 1.43, 160^3 0.26 / 0.44, 128^3 0.20 / 0.23, 96^3 0.08 / 0.105; slabs 64 x 512^2 0.90 / 1.42,
+// 32 x 256^2 0.18 / 0.23), 2 marching kernel always
 static bool gs_march_wanted(const MgLevel &L, const Tuning &t) {
-    return t.gs_march == 2 || (t.gs_march == 1 && L.d.nn >= 12000000);
+    return t.gs_march == 2 || (t.gs_march == 1 && L.d.nn >= 800000);
 }
 
 // the marching sweep sums a node row per neighbour kind, which needs K0 with the mirror symmetry of a box voxel and an isotropic tensor:

@@ -468,10 +468,11 @@ bool launch_gs_march_mf0(const Dims &d, const double *tab, const double *E, cons
     const int P = forward ? 0 : 1;
     const int nty = (d.NY + P + 2 * R - 1) / (2 * R), ntz = (d.NZ + P + 2 * C - 1) / (2 * C);
     if (chunks <= 0) {
-        // many more blocks than CUs (one block per CU is resident: short blocks even out the tail), chunks of at least 8 steps;
-        // measured at 512^3 (387 tiles): 4 chunks 8.7 ms per sweep, 9: 7.9, 13-26: 7.7-7.8 (tools/gs_march_probe.py)
+        // many more blocks than CUs (one block per CU is resident: short blocks even out the tail), chunks of at least 3 steps
+        // (profiles/r04_gs_march_chunks.txt: 512^3, 333 tiles: 15 chunks; 160^3, 36 tiles: 26 chunks 0.26 ms against 0.37 with the
+        // former floor of 8 steps and 0.44 for the row kernels)
         chunks = 1;
-        while ((long long) chunks * nty * ntz < 5000 && M / (chunks + 1) >= 8) ++chunks;
+        while ((long long) chunks * nty * ntz < 5000 && M / (chunks + 1) >= 3) ++chunks;
     }
     if (chunks > M) chunks = M;
     a.steps_per_chunk = (M + chunks - 1) / chunks;

@@ -1,5 +1,5 @@
 """-m gpu: the plane-resident marching level-0 Gauss-Seidel (kernels_gs_march.hip; MG.hh:193-340) against the CPU oracle and
-against the row-streaming kernels.  The library uses it by itself only on grids of at least 12 M nodes, so the tests force it
+against the row-streaming kernels.  The library uses it by itself only on grids of at least 0.8 M nodes, so the tests force it
 (VFEM_OPT_GS_MARCH = 2) on grids the oracle finishes in seconds; shapes put tile seams (14 x 58 owned node columns per tile)
 and ragged edges inside the grid."""
 import numpy as np
