@@ -519,6 +519,7 @@ class DistributedMGSolver:
         self.last_iterations, self.last_relative_residual = 0, 0.0
 
     # ---- small helpers -------------------------------------------------------------------
+    proxy = False                  # (instances built as a rank proxy set it; subclasses with their own constructor inherit the default)
     _MG_PREFIX = "vfem_mg_"        # C entry points of the hierarchy handles (the degree-2 subclass uses vfem_gmg_)
     KE_DOUBLES = 576               # doubles per element matrix of the first replicated level
     COLOR_GROUPS = ((0, 4), (4, 4))   # colours between two halo refreshes: all colours of one x index
