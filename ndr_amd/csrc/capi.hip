@@ -389,6 +389,12 @@ static void update_operators(vfem_mg *mg, hipStream_t s) {
     mg->Ainv.zero(s);
     launch_dense_from_stencil(cl.d, Sc, cl.maskp, mg->Ainv.p, s);
     dense_spd_inverse(n, mg->Ainv.p, mg->dense, s);      // own kernels, fixed summation order (dense_spd.hip)
+    // three further n x n work matrices: kept between operator updates while they are small (2 187 dofs: 115 MB), released when the
+    // coarsest level is large -- they would otherwise be held for the hierarchy's lifetime at three times the inverse's size
+    if ((size_t) n * (size_t) n * sizeof(double) > ((size_t) 256 << 20)) {
+        VFEM_HIP(hipStreamSynchronize(s));
+        mg->dense.L.release(); mg->dense.X.release(); mg->dense.Tm.release();
+    }
     launch_dense_finish_inverse(n, cl.maskp, mg->Ainv.p, s);
     VFEM_HIP(hipStreamSynchronize(s));   // tmpS lifetime
     mg->operators_valid = true;
@@ -937,7 +943,7 @@ int vfem_mg_interpolate(vfem_mg *mg, int fine_level, const double *coarse, doubl
 }
 int vfem_dense_spd_inverse(int64_t n, double *A, void *stream) {
     VFEM_TRY
-    if (n < 1 || n > 40000) throw Error("dense inverse: n must be in [1, 40000]");
+    if (n < 1 || n > 40000) throw Error("dense inverse: n must be in [1, 40000]");      // (n = 40 000: 12.8 GB + three work matrices of the padded size = 51 GB)
     DenseWork w;
     dense_spd_inverse(n, A, w, S(stream));
     VFEM_HIP(hipStreamSynchronize(S(stream)));      // the workspace is released on return
@@ -1338,6 +1344,17 @@ int vfem_mlp_load_weights(vfem_mlp *m, const float *B, const float *W1, const fl
     }
     up(m->bias, biases, (size_t) (nh + 1) * m->nn);
     up(m->wout, wout, (size_t) m->nn);
+    // the split operands carry fp16(w) as their high half: a weight of 65 504 or more would become inf (the fp32 reference has no
+    // such limit; networks of this kind have |w| < 10)
+    m->range_flag.alloc(1);
+    m->range_flag.zero(nullptr);
+    launch_range_check_f32((long long) m->nn * 2 * m->es, m->W1f.p, 65504.f, m->range_flag.p, nullptr);
+    if (nh) launch_range_check_f32((long long) nh * m->nn * m->nn, m->Whf.p, 65504.f, m->range_flag.p, nullptr);
+    {
+        int bad = 0;
+        VFEM_HIP(hipMemcpy(&bad, m->range_flag.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (bad) { m->loaded = false; throw Error("MLP weight of magnitude >= 65504 (or not finite): outside the range of the split fp16 operands"); }
+    }
     VFEM_HIP(hipStreamSynchronize(nullptr));      // the conversions ran on the null stream; consumers may launch on any stream
     m->bout = bout;
     m->loaded = true;
@@ -1345,8 +1362,22 @@ int vfem_mlp_load_weights(vfem_mlp *m, const float *B, const float *W1, const fl
 }
 }  // extern "C" (reopened below)
 #include "mlp_args.h"
+// a hidden activation left fp16's range in an earlier reference-precision launch: its high half was inf, the results of that launch
+// are not the network's.  Reported by the next entry point (the check costs one 4-byte read-back; launches stay asynchronous)
+static void mlp_check_range(vfem_mlp *m, hipStream_t s) {
+    if (!m->range_flag.p) return;
+    int bad = 0;
+    VFEM_HIP(hipMemcpyAsync(&bad, m->range_flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    VFEM_HIP(hipStreamSynchronize(s));
+    if (bad) {
+        m->range_flag.zero(s);
+        throw Error("MLP activation outside fp16's range (>= 65000 or not finite) in the previous reference-precision evaluation: "
+                    "its results are invalid; rescale the network or use torch for it");
+    }
+}
 static vfem::MlpArgs mlp_base_args(const vfem_mlp *m) {
     vfem::MlpArgs a{};
+    a.range_flag = m->range_flag.p;
     a.ablate = ablate_mlp();
     a.es = m->es; a.nn = m->nn; a.n_hidden = m->n_layers - 2; a.sigmoid = m->sigmoid;
     a.B = m->B.p; a.W1 = m->W1.p; a.Wh = m->Wh.p; a.bias = m->bias.p; a.wout = m->wout.p; a.bout = m->bout;
@@ -1400,6 +1431,7 @@ int vfem_mlp_forward_grid_range(vfem_mlp *m, const int64_t n[3], const double lo
 // argument formed as the reference forms it.  Nothing wider than the output scalar per voxel reaches HBM.
 static void mlp_forward_f32_impl(vfem_mlp *m, vfem::MlpArgs base, float *o32, double *o64, hipStream_t s) {
     if (!m->loaded) throw Error("vfem_mlp_load_weights has not been called");
+    mlp_check_range(m, s);
     base.out32 = o32; base.out64 = o64;
     launch_mlp_forward_x3(base, m->W1h.p, m->W1l.p, m->Whh.p, m->Whl.p, s);
 }
@@ -1432,6 +1464,7 @@ static void mlp_backward_impl(vfem_mlp *m, vfem::MlpArgs base, const float *coor
                               float *dW1, float *dWh, float *dbias, float *dwout, float *dbout, hipStream_t s) {
     if (!m->loaded) throw Error("vfem_mlp_load_weights has not been called");
     if (!(scale > 0.f)) throw Error("loss scale must be positive");
+    mlp_check_range(m, s);
     const long long V = base.nvox;
     const int nn = m->nn, K1 = 2 * m->es, nh = m->n_layers - 2, nact = nh + 1;
     if (V <= 0) throw Error("empty voxel set");
@@ -1494,6 +1527,7 @@ static void mlp_backward_impl(vfem_mlp *m, vfem::MlpArgs base, const float *coor
         launch_reduce_partials(cb, nn, m->partial.p, inv, beta, dwout, s);
         launch_sum_f32(rows, m->gs.p, inv, beta, dbout, m->partial.p, s);
     }
+    mlp_check_range(m, s);                               // (the pass's own forward)
 }
 extern "C" {
 int vfem_mlp_backward(vfem_mlp *m, const float *coords, int64_t nvox, const float *g_out, float loss_scale, float *dW1,

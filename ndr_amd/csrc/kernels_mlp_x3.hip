@@ -6,7 +6,9 @@
 // and a product of two operands is three MFMA products with fp32 accumulation,
 //     w x  ~=  wh xh  +  2^-11 (wh xl + wl xh)          (the dropped wl xl term is 2^-22 relative),
 // the first into one accumulator, the two cross terms into a second one that is folded in at 2^-11 in the epilogue.  Scaling
-// only the low halves keeps them in fp16's normal range whatever the magnitude of x; no per-tensor scale is needed.  An f16
+// only the low halves keeps THEM in fp16's normal range whatever the magnitude of x; the high half is fp16(x) itself, so |x| must stay
+// below fp16's largest number (65 504): weights are checked when they are loaded, hidden activations by a flag the kernel raises and the
+// next entry point reports (vfem_mlp_*: "activation outside fp16's range") -- the fp32 reference has no such limit.  An f16
 // product is exact in fp32 (11 x 11 bits), so the result differs from an fp32 FMA chain only by the dropped term and by the
 // summation order.  v_mfma_f32_32x32x2_f32 (exact fp32, 1/16 of the f16 rate) would spend 16 x the matrix cycles, this
 // spends 3 x; the rocBLAS SGEMM chain of rounds 1-2 ran at 33 Mvoxel/s and passed every activation through HBM.
@@ -101,6 +103,19 @@ void launch_split_f32_frag(int N, int K, const float *in, void *hi, void *lo, hi
     long long g = ((long long) N * K + 255) / 256;
     if (g > 4096) g = 4096;
     k_split_f32_frag<<<dim3((unsigned) (g < 1 ? 1 : g)), 256, 0, s>>>(N, K, pair_es, transposed, in, (_Float16 *) hi, (_Float16 *) lo);
+    VFEM_HIP(hipGetLastError());
+}
+// 1 in *flag when any |in[i]| is not below `limit` (weights of the split-operand kernels: fp16(w) must be finite)
+__global__ void __launch_bounds__(256) k_range_check_f32(long long n, const float *__restrict__ in, float limit, int *__restrict__ flag) {
+    bool bad = false;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) bad |= !(fabsf(in[i]) < limit);
+    if (bad) *flag = 1;
+}
+void launch_range_check_f32(long long n, const float *in, float limit, int *flag, hipStream_t s) {
+    if (n <= 0) return;
+    long long g = (n + 255) / 256;
+    if (g > 1024) g = 1024;
+    k_range_check_f32<<<dim3((unsigned) g), 256, 0, s>>>(n, in, limit, flag);
     VFEM_HIP(hipGetLastError());
 }
 void launch_split_f32(long long n, const float *in, void *hi, void *lo, hipStream_t s) {
@@ -233,6 +248,7 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
 
     // ---- epilogue of a layer: bias + ReLU, split into the two activation images --------------------------------------------
     auto store_layer = [&](const float *bias) {
+        float big = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (!FULL && !on[t]) continue;
@@ -247,6 +263,7 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
                     for (int q = 0; q < 4; ++q) {
                         const float vv = fmaf(accx[t][c][4 * g + q], LO_INV, acch[t][c][4 * g + q]) + bias[n + q];
                         const float y = vv > 0.f ? vv : 0.f;
+                        big = fmaxf(big, y);
                         _Float16 yh, yl;
                         split(y, yh, yl);
                         oh[q] = yh; ol[q] = yl;
@@ -256,6 +273,7 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
                 }
         }
         zero_acc();
+        if (!(big < 65000.f) && a.range_flag) *a.range_flag = 1;      // (also catches NaN; plain store: every writer writes 1)
     };
     // training: the finished layer's two [voxel][k] images to HBM in 16-byte pieces, the low halves unscaled (h = hi + lo)
     auto save_layer = [&](int layer) {

@@ -24,6 +24,7 @@ struct MlpArgs {
     void *save_act_lo;                      // reference-precision forward only: the low halves, UNSCALED (h = hi + lo), same layout
     long long act_rows;
     int ablate;                             // timing ablations (wrong results): 1 no feature generation, 2 no hidden layers, 3 no layer-1 MFMAs
+    int *range_flag;                        // reference-precision forward: set to 1 when a hidden activation leaves fp16's range (its high half would be inf)
 };
 
 // backward pass of one voxel chunk (networks.MLP under torch.autograd in the reference, train_xdg.py:282-329), split operands:

@@ -450,9 +450,13 @@ class DistributedMGSolver:
         self.ne = tuple(int(v) for v in ne)
         self.L = int(num_levels)
         if dist_levels is None:
+            # as many distributed levels as leave a rank at least MIN_LAYERS element layers on the deepest of them: below that a level
+            # is launch-floor-bound whether distributed or replicated (rank proxy, profiles/r04_rank_proxy_levels512.jsonl: 20.6 / 20.1 /
+            # 20.0 ms per iteration with 4 / 5 / 6 distributed levels at 512^3 / 8) while every further level adds ~60 messages per
+            # iteration (138 / 202 / 278)
             dist_levels = 0
             while (dist_levels + 1 < self.L and self.ne[0] % (self.world * 2 ** (dist_levels + 2)) == 0
-                   and self.ne[0] // (self.world * 2 ** (dist_levels + 1)) >= 2):
+                   and self.ne[0] // (self.world * 2 ** (dist_levels + 1)) >= self.MIN_LAYERS):
                 dist_levels += 1
         self.Ld = int(dist_levels)
         if self.Ld + 1 > self.L:
@@ -520,6 +524,7 @@ class DistributedMGSolver:
 
     # ---- small helpers -------------------------------------------------------------------
     proxy = False                  # (instances built as a rank proxy set it; subclasses with their own constructor inherit the default)
+    MIN_LAYERS = 8                 # owned element layers per rank on the deepest distributed level (automatic choice)
     _MG_PREFIX = "vfem_mg_"        # C entry points of the hierarchy handles (the degree-2 subclass uses vfem_gmg_)
     KE_DOUBLES = 576               # doubles per element matrix of the first replicated level
     COLOR_GROUPS = ((0, 4), (4, 4))   # colours between two halo refreshes: all colours of one x index

@@ -60,10 +60,12 @@ def _worker(rank, world, port, ne, levels, q, sharded, bc="cantilever", l1_mode=
     gs = t.complianceGradient_device(ug)[first:first + count]
     gerr = float((gd - gs).abs().max() / gs.abs().max())
     # the two runs sum in different orders (slab-local kernels, partial dot products), so the histories agree to rounding, not bit
-    # for bit: the WHOLE history is compared, on the scale of the first residual (the coarsest-level inverse is the library's own
-    # deterministic factorisation, dense_spd.hip: no tolerance is spent on it)
+    # for bit: the WHOLE history is compared entry by entry with a mixed bound -- 1e-6 of the entry itself plus 1e-12 of the first
+    # residual -- so that late iterations (residuals ~ tol x the first) are held as tightly as early ones; herr is the
+    # largest ratio of a deviation to its bound (the coarsest-level inverse is the library's own deterministic factorisation,
+    # dense_spd.hip: no tolerance is spent on it)
     n = min(len(hist), len(hist_s))
-    herr = max(abs(a - b) / hist_s[0] for a, b in zip(hist[:n], hist_s[:n])) if n else 0.0
+    herr = max(abs(a - b) / (1e-6 * b + 1e-12 * hist_s[0]) for a, b in zip(hist[:n], hist_s[:n])) if n else 0.0
     q.put((rank, ds.Ld, ds.last_iterations, mg.last_iterations, comp, cg, err, gerr, herr))
     dist.destroy_process_group()
 
@@ -100,7 +102,7 @@ def test_q2_distributed_pcg_matches_single_process(world, ne, levels, min_ld):
     for rank, Ld, it_d, it_s, comp, cg, err, gerr, herr in _run(world, ne, levels, False, 28800):
         assert Ld >= min_ld
         assert it_d == it_s, (it_d, it_s)
-        assert herr < 1e-9, herr                         # the residual history, iteration by iteration
+        assert herr < 1.0, herr                          # the residual history, iteration by iteration (mixed per-entry bound)
         assert abs(comp - cg) < 1e-9 * abs(cg), (comp, cg)
         assert err < 1e-7 and gerr < 1e-7, (err, gerr)
 
@@ -113,7 +115,7 @@ def test_q2_distributed_pcg_with_sharded_densities(world, ne, levels):
     for rank, Ld, it_d, it_s, comp, cg, err, gerr, herr in _run(world, ne, levels, True, 28600):
         assert Ld >= 1
         assert it_d == it_s, (it_d, it_s)
-        assert herr < 1e-9, herr
+        assert herr < 1.0, herr
         assert abs(comp - cg) < 1e-9 * abs(cg), (comp, cg)
         assert err < 1e-7 and gerr < 1e-7, (err, gerr)
 
@@ -124,7 +126,7 @@ def test_q2_distributed_bridge_supports_cross_the_slab_logic():
     for rank, Ld, it_d, it_s, comp, cg, err, gerr, herr in _run(4, (64, 8, 16), 3, True, 28400, "bridge"):
         assert Ld >= 1
         assert it_d == it_s, (it_d, it_s)
-        assert herr < 1e-9 and abs(comp - cg) < 1e-9 * abs(cg), (herr, comp, cg)
+        assert herr < 1.0 and abs(comp - cg) < 1e-9 * abs(cg), (herr, comp, cg)
         assert err < 1e-7 and gerr < 1e-7, (err, gerr)
 
 
@@ -136,5 +138,5 @@ def test_q2_distributed_with_virtual_level1(world, ne, levels):
     for rank, Ld, it_d, it_s, comp, cg, err, gerr, herr in _run(world, ne, levels, True, 28200, "cantilever", 1):
         assert Ld >= 1
         assert it_d == it_s, (it_d, it_s)
-        assert herr < 1e-9 and abs(comp - cg) < 1e-9 * abs(cg), (herr, comp, cg)
+        assert herr < 1.0 and abs(comp - cg) < 1e-9 * abs(cg), (herr, comp, cg)
         assert err < 1e-7 and gerr < 1e-7, (err, gerr)

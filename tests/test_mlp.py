@@ -177,12 +177,41 @@ def test_hip_mlp_requires_weights_and_valid_shapes():
         m.forward(torch.zeros(4, 3))
 
 
+@pytest.mark.gpu
+def test_hip_mlp_reports_values_outside_the_split_operands_range():
+    """the reference-precision kernels carry fp16(x) as the high half of every operand: a weight >= 65504 is refused when it is loaded,
+    a hidden activation that large is reported by the next call instead of silently becoming inf -> NaN (the fp32 reference, and the
+    SGEMM path of rounds 1-2, stay finite there)"""
+    import torch
+    from ndr_amd.mlp import MLP
+    rng = np.random.default_rng(2)
+    es, nn_, nl = 32, 64, 3
+    B = rng.standard_normal((es, 3)).astype(np.float32)
+    Ws = [rng.standard_normal((nn_, 2 * es)).astype(np.float32) * 0.1, rng.standard_normal((nn_, nn_)).astype(np.float32) * 0.1,
+          rng.standard_normal((1, nn_)).astype(np.float32) * 0.1]
+    bs = [np.zeros(nn_, np.float32), np.zeros(nn_, np.float32), np.zeros(1, np.float32)]
+    m = MLP(3, 1, nn_, nl, es, 1.0)
+    big = [w.copy() for w in Ws]
+    big[1][3, 5] = 7.0e4
+    with pytest.raises(RuntimeError, match="65504"):
+        m.load_arrays(B, big, bs)
+    # weights in range, first-layer bias of 1e5: the first hidden activations leave fp16's range
+    m.load_arrays(B, Ws, [np.full(nn_, 1.0e5, np.float32), bs[1], bs[2]])
+    x = torch.rand(256, 3, device="cuda")
+    m.forward(x)                                       # raises the flag ...
+    with pytest.raises(RuntimeError, match="fp16's range"):
+        m.forward(x)                                   # ... which the next call reports
+    m.load_arrays(B, Ws, bs)                           # a sane network afterwards works
+    out = m.forward(x)
+    assert bool(torch.isfinite(out).all())
+    m.forward(x)
+
+
 def _rel_l2(a, b):
     return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / max(np.linalg.norm(np.asarray(b, np.float64)), 1e-300))
 
 
-# fp16 operands / fp32 accumulation in the backward GEMMs: relative L2 error of every gradient tensor against the
-# reference's fp32 autograd gradients; set from measurement
+# relative L2 error of every gradient tensor against the reference's fp32 autograd gradients; set from measurement
 TOL_GRAD = 5e-6           # explicit coordinates: fp32 autograd to rounding (measured <= 6.5e-7)
 TOL_GRAD_GRID = 1e-3      # grid entry point: its fp32 coordinates are one rounding away from torch.linspace's (see above)
 
