@@ -281,6 +281,22 @@ def mlp_rate(side=(512, 256, 256), es=1024, nn_=512, nl=4, sigma=4.0, reps=3):
     m.backward_grid(side, g)
     torch.cuda.synchronize()
     db = time.perf_counter() - t0
+    # a training step as TrainableMLP runs it: the forward keeps the first layer's activations (68.7 GB at this size), the backward starts from them
+    m.set_keep_first_layer(True)
+    m.forward_grid(side)
+    m.backward_grid(side, g)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m.forward_grid(side)
+    torch.cuda.synchronize()
+    tf = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    m.backward_grid(side, g)
+    torch.cuda.synchronize()
+    tb = time.perf_counter() - t0
+    m.set_keep_first_layer(False)
+    res["training_step"] = {"forward_seconds": tf, "backward_seconds": tb, "seconds": tf + tb,
+                            "note": "VFEM_MLP_OPT_KEEP_FIRST: first-layer activations kept by the forward, not recomputed by the backward; same gradients bit for bit"}
     macs = (3 * es + 2 * es * nn_ + (nl - 2) * nn_ * nn_ + nn_) + (nl - 2) * nn_ * nn_ + (2 * es * nn_ + (nl - 2) * nn_ * nn_ + nn_)
     res["backward"] = {"seconds": db, "voxels_per_s": nv / db, "tflops": 2.0 * macs * nv / db / 1e12,
                        "note": "reference precision throughout: forward recompute with saved split activations (kernels_mlp_x3.hip) + data pass + own "

@@ -326,6 +326,11 @@ int vfem_mlp_destroy(vfem_mlp *mlp);
 /* options of one network: VFEM_MLP_OPT_BWD_TERMS = 3 (default; every product of the backward pass is hi hi + hi lo + lo hi of split
  * fp16 operands: the reference's fp32 autograd to rounding) or 1 (hi hi only in the weight-gradient GEMMs, three times fewer MFMAs) */
 #define VFEM_MLP_OPT_BWD_TERMS 1
+/* VFEM_MLP_OPT_KEEP_FIRST = 1: a reference-precision GRID forward keeps the first layer's activations (2 KB per voxel: 68.7 GB at
+ * 512 x 256 x 256, at most 96 GB, dropped silently when the allocation fails), and vfem_mlp_backward_grid* of the same grid, voxel range
+ * and weights start from them instead of recomputing the first layer (two thirds of the forward's products).  0 (default): nothing is kept.
+ * Results are the same bit for bit. */
+#define VFEM_MLP_OPT_KEEP_FIRST 2
 int vfem_mlp_set_option(vfem_mlp *mlp, int key, int value);
 int vfem_mlp_load_weights(vfem_mlp *mlp, const float *B, const float *W_first, const float *W_hidden, const float *biases,
                           const float *w_out, float b_out);

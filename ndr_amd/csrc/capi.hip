@@ -1307,6 +1307,9 @@ int vfem_mlp_set_option(vfem_mlp *m, int key, int value) {
     if (key == VFEM_MLP_OPT_BWD_TERMS) {
         if (value != 1 && value != 3) throw Error("VFEM_MLP_OPT_BWD_TERMS: 3 (hi hi + hi lo + lo hi, reference precision) or 1 (hi hi)");
         m->bwd_terms = value;
+    } else if (key == VFEM_MLP_OPT_KEEP_FIRST) {
+        m->keep_first = value != 0;
+        if (!m->keep_first) { m->h0_valid = false; m->h0_hi.release(); m->h0_lo.release(); }
     } else throw Error("unknown MLP option");
     VFEM_CATCH
 }
@@ -1357,6 +1360,7 @@ int vfem_mlp_load_weights(vfem_mlp *m, const float *B, const float *W1, const fl
     }
     VFEM_HIP(hipStreamSynchronize(nullptr));      // the conversions ran on the null stream; consumers may launch on any stream
     m->bout = bout;
+    m->h0_valid = false;
     m->loaded = true;
     VFEM_CATCH
 }
@@ -1429,11 +1433,32 @@ int vfem_mlp_forward_grid_range(vfem_mlp *m, const int64_t n[3], const double lo
 // Reference-precision forward (the reference evaluates networks.MLP in fp32 end to end, networks.py:178-185): the fused kernel with
 // split fp16 operands (kernels_mlp_x3.hip) -- three MFMA products per product, fp32 accumulation, accurate fp32 sin / cos of the
 // argument formed as the reference forms it.  Nothing wider than the output scalar per voxel reaches HBM.
-static void mlp_forward_f32_impl(vfem_mlp *m, vfem::MlpArgs base, float *o32, double *o64, hipStream_t s) {
+static void mlp_forward_f32_impl(vfem_mlp *m, vfem::MlpArgs base, float *o32, double *o64, hipStream_t s,
+                                 const int64_t *grid_n = nullptr, const double *grid_lo = nullptr, const double *grid_hi = nullptr) {
     if (!m->loaded) throw Error("vfem_mlp_load_weights has not been called");
     mlp_check_range(m, s);
     base.out32 = o32; base.out64 = o64;
+    m->h0_valid = false;
+    bool keep = m->keep_first && grid_n && base.nvox > 0 && m->n_layers > 2 && (size_t) base.nvox * m->nn * 4 <= ((size_t) 96 << 30);
+    if (keep) {
+        // room for the padded rows of the backward pass's last chunk (they must exist and be finite: they meet dz = 0)
+        const size_t rows = (size_t) base.nvox + 4096;
+        try {
+            m->h0_hi.reserve(rows * m->nn);
+            m->h0_lo.reserve(rows * m->nn);
+        } catch (const Error &) { (void) hipGetLastError(); m->h0_hi.release(); m->h0_lo.release(); keep = false; }
+    }
+    if (keep) {
+        VFEM_HIP(hipMemsetAsync(m->h0_hi.p + (size_t) base.nvox * m->nn, 0, (size_t) 4096 * m->nn * 2, s));
+        VFEM_HIP(hipMemsetAsync(m->h0_lo.p + (size_t) base.nvox * m->nn, 0, (size_t) 4096 * m->nn * 2, s));
+        base.save_act = m->h0_hi.p; base.save_act_lo = m->h0_lo.p; base.act_rows = 0; base.save_first_only = 1;
+    }
     launch_mlp_forward_x3(base, m->W1h.p, m->W1l.p, m->Whh.p, m->Whl.p, s);
+    if (keep) {
+        for (int dd = 0; dd < 3; ++dd) { m->h0_n[dd] = grid_n[dd]; m->h0_lo_c[dd] = grid_lo[dd]; m->h0_hi_c[dd] = grid_hi[dd]; }
+        m->h0_first = base.v_offset; m->h0_count = base.nvox;
+        m->h0_valid = true;
+    }
 }
 extern "C" {
 int vfem_mlp_forward_f32(vfem_mlp *m, const float *coords, int64_t nvox, float *o32, double *o64, void *stream) {
@@ -1451,7 +1476,7 @@ int vfem_mlp_forward_grid_range_f32(vfem_mlp *m, const int64_t n[3], const doubl
     if (first_voxel < 0 || num_voxels < 0 || first_voxel + num_voxels > a.nvox) throw Error("voxel range outside the grid");
     if (num_voxels == 0) return 0;
     a.v_offset = first_voxel; a.nvox = num_voxels;
-    mlp_forward_f32_impl(m, a, o32, o64, S(stream));
+    mlp_forward_f32_impl(m, a, o32, o64, S(stream), n, lo, hi);
     VFEM_CATCH
 }
 }  // extern "C"
@@ -1461,7 +1486,8 @@ int vfem_mlp_forward_grid_range_f32(vfem_mlp *m, const int64_t n[3], const doubl
 // data pass, the weight gradients as voxel-reduction GEMMs of our own (first layer: Fourier features regenerated in the kernel),
 // column sums for the biases and the output layer.
 static void mlp_backward_impl(vfem_mlp *m, vfem::MlpArgs base, const float *coords, const float *g_out, float scale,
-                              float *dW1, float *dWh, float *dbias, float *dwout, float *dbout, hipStream_t s) {
+                              float *dW1, float *dWh, float *dbias, float *dwout, float *dbout, hipStream_t s,
+                              const int64_t *grid_n = nullptr, const double *grid_lo = nullptr, const double *grid_hi = nullptr) {
     if (!m->loaded) throw Error("vfem_mlp_load_weights has not been called");
     if (!(scale > 0.f)) throw Error("loss scale must be positive");
     mlp_check_range(m, s);
@@ -1490,6 +1516,10 @@ static void mlp_backward_impl(vfem_mlp *m, vfem::MlpArgs base, const float *coor
     m->partial.alloc(std::max(std::max((size_t) s1 * nn * K1, (size_t) sh * nn * nn), colblocks * (size_t) nn));
     m->partial_b.alloc((size_t) 128 * nn);
     const float inv = 1.f / scale;
+    // the first layer's activations as the forward pass of this step left them (VFEM_MLP_OPT_KEEP_FIRST), if they belong to this grid and range
+    bool kept = m->h0_valid && grid_n && !coords && nh >= 1 && m->h0_first == base.v_offset && m->h0_count == V;
+    if (kept)
+        for (int dd = 0; dd < 3; ++dd) kept = kept && m->h0_n[dd] == grid_n[dd] && m->h0_lo_c[dd] == grid_lo[dd] && m->h0_hi_c[dd] == grid_hi[dd];
     for (long long c0 = 0; c0 < V; c0 += Vc) {
         const long long n_c = std::min(Vc, V - c0);
         long long rows;
@@ -1499,11 +1529,14 @@ static void mlp_backward_impl(vfem_mlp *m, vfem::MlpArgs base, const float *coor
         vfem::MlpArgs a = base;
         a.nvox = n_c; a.v_offset = base.v_offset + c0; a.coords = coords ? coords + 3 * c0 : nullptr;
         a.out32 = m->out_chunk.p; a.out64 = nullptr; a.save_act = m->acts.p; a.save_act_lo = m->acts_lo.p; a.act_rows = rows;
+        const uint16_t *k_hi = kept ? m->h0_hi.p + (size_t) c0 * nn : nullptr, *k_lo = kept ? m->h0_lo.p + (size_t) c0 * nn : nullptr;
+        a.h0_hi = k_hi; a.h0_lo = k_lo;
         launch_mlp_forward_x3(a, m->W1h.p, m->W1l.p, m->Whh.p, m->Whl.p, s);
+        a.h0_hi = nullptr; a.h0_lo = nullptr;
         vfem::MlpBwdArgs b{};
         b.nn = nn; b.n_hidden = nh; b.sigmoid = m->sigmoid; b.WhTh = m->WhTh.p; b.WhTl = m->WhTl.p; b.wout = m->wout.p; b.g = g_out + c0;
         b.out32 = m->out_chunk.p; b.scale = scale; b.act_hi = m->acts.p; b.act_lo = m->acts_lo.p; b.dz_hi = m->dz.p; b.dz_lo = m->dz_lo.p;
-        b.gs = m->gs.p; b.act_rows = rows; b.nvox = n_c;
+        b.gs = m->gs.p; b.act_rows = rows; b.nvox = n_c; b.act0_hi = k_hi; b.act0_lo = k_lo;
         launch_mlp_backward_x3(b, rows, s);
         a.save_act = nullptr; a.save_act_lo = nullptr;
         vfem::MlpDwArgs w{};
@@ -1517,7 +1550,9 @@ static void mlp_backward_impl(vfem_mlp *m, vfem::MlpArgs base, const float *coor
         for (int l = 0; l < nh; ++l) {
             w.K = nn; w.slices = sh;
             w.dz_hi = m->dz.p + (size_t) (l + 1) * rows * nn; w.dz_lo = m->dz_lo.p + (size_t) (l + 1) * rows * nn;
-            w.h_hi = m->acts.p + (size_t) l * rows * nn; w.h_lo = m->acts_lo.p + (size_t) l * rows * nn;
+            w.h_hi = (l == 0 && kept) ? k_hi : m->acts.p + (size_t) l * rows * nn;
+            w.h_lo = (l == 0 && kept) ? k_lo : m->acts_lo.p + (size_t) l * rows * nn;
+            w.h_lo_scaled = (l == 0 && kept) ? 1 : 0;
             launch_mlp_dw(w, s);
             launch_reduce_partials(sh, (long long) nn * nn, m->partial.p, inv, beta, dWh + (size_t) l * nn * nn, s);
             launch_reduce_partials(sh, nn, m->partial_b.p, inv, beta, dbias + (size_t) (l + 1) * nn, s);
@@ -1549,7 +1584,7 @@ int vfem_mlp_backward_grid(vfem_mlp *m, const int64_t n[3], const double lo[3], 
         a.gstep[dd] = n[dd] > 1 ? (float) ((hi[dd] - lo[dd]) / (double) (n[dd] - 1)) : 0.f;
         a.nvox *= n[dd];
     }
-    mlp_backward_impl(m, a, nullptr, g_out, loss_scale, dW1, dWh, dbias, dwout, dbout, S(stream));
+    mlp_backward_impl(m, a, nullptr, g_out, loss_scale, dW1, dWh, dbias, dwout, dbout, S(stream), n, lo, hi);
     VFEM_CATCH
 }
 int vfem_mlp_backward_grid_range(vfem_mlp *m, const int64_t n[3], const double lo[3], const double hi[3], int64_t first_voxel,
@@ -1560,7 +1595,7 @@ int vfem_mlp_backward_grid_range(vfem_mlp *m, const int64_t n[3], const double l
     mlp_grid_args(a, n, lo, hi);
     if (first_voxel < 0 || num_voxels <= 0 || first_voxel + num_voxels > a.nvox) throw Error("voxel range outside the grid");
     a.v_offset = first_voxel; a.nvox = num_voxels;
-    mlp_backward_impl(m, a, nullptr, g_out, loss_scale, dW1, dWh, dbias, dwout, dbout, S(stream));
+    mlp_backward_impl(m, a, nullptr, g_out, loss_scale, dW1, dWh, dbias, dwout, dbout, S(stream), n, lo, hi);
     VFEM_CATCH
 }
 int vfem_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float lr, float beta1,

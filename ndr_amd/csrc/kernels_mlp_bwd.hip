@@ -35,6 +35,13 @@ __device__ __forceinline__ void split_scaled(float x, _Float16 &hi, _Float16 &lo
     hi = (_Float16) x;
     lo = (_Float16) ((x - (float) hi) * LO_SCALE);
 }
+// (the pair of x3::unscale_lo in kernels_mlp_x3.hip: same value for the same half)
+__device__ __forceinline__ _Float16 unscale_lo(_Float16 ls) {
+    const float f = (float) ls;
+    _Float16 u = (_Float16) (f * LO_INV);
+    if ((float) u == 0.f && f != 0.f) u = (_Float16) (f > 0.f ? 5.9604645e-8f : -5.9604645e-8f);
+    return u;
+}
 __device__ __forceinline__ void split_plain(float x, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16) x;
     lo = (_Float16) (x - (float) hi);
@@ -106,8 +113,10 @@ __global__ void __launch_bounds__(512) k_mlp_backward_x3(MlpBwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { oh[j] = (_Float16) 0.f; ol[j] = (_Float16) 0.f; ou[j] = (_Float16) 0.f; }
             if (v0 + v < a.nvox) {
-                const long long at = ((long long) layer * a.act_rows + v0 + v) * a.nn + 8 * c;
-                const h8_t hv = *reinterpret_cast<const h8_t *>(acth + at), lv = *reinterpret_cast<const h8_t *>(actl + at);
+                const bool kept = layer == 0 && a.act0_hi != nullptr;      // layer 0 from the activations the forward pass kept
+                const long long at = kept ? (v0 + v) * a.nn + 8 * c : ((long long) layer * a.act_rows + v0 + v) * a.nn + 8 * c;
+                const _Float16 *ph = kept ? reinterpret_cast<const _Float16 *>(a.act0_hi) : acth, *pl = kept ? reinterpret_cast<const _Float16 *>(a.act0_lo) : actl;
+                const h8_t hv = *reinterpret_cast<const h8_t *>(ph + at), lv = *reinterpret_cast<const h8_t *>(pl + at);
                 h8_t rh, rl;
                 if (!is_top) { rh = *reinterpret_cast<const h8_t *>(Hh + v * HS + 8 * c); rl = *reinterpret_cast<const h8_t *>(Hl + v * HS + 8 * c); }
                 const float g = gsl[v];
@@ -277,7 +286,13 @@ __global__ void __launch_bounds__(512) k_mlp_dw(MlpDwArgs a) {
             if (!FEATURES) {
                 if (b_in) {
                     rb[0][i] = *reinterpret_cast<const h8_t *>(Bh + v * a.K + k0 + 8 * pcol);
-                    if (TERMS == 3) rb[1][i] = *reinterpret_cast<const h8_t *>(Bl + v * a.K + k0 + 8 * pcol);
+                    if (TERMS == 3) {
+                        rb[1][i] = *reinterpret_cast<const h8_t *>(Bl + v * a.K + k0 + 8 * pcol);
+                        if (a.h_lo_scaled) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) rb[1][i][j] = unscale_lo(rb[1][i][j]);
+                        }
+                    }
                 } else { zero8(rb[0][i]); zero8(rb[1][i]); }
             }
         }

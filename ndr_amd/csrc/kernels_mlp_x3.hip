@@ -70,6 +70,15 @@ __device__ __forceinline__ void voxel_xyz(const MlpArgs &a, long long v, float x
     x[1] = a.glo[1] + a.gstep[1] * (float) j;
     x[2] = a.glo[2] + a.gstep[2] * (float) k;
 }
+// the low half without its 2^11 scale (what the backward pass's products take).  A nonzero half never becomes zero: an activation
+// of 1e-9 has hi = 0 and lives in its low half alone, whose unscaled value underflows fp16 -- and "h > 0" is the ReLU mask of the
+// backward pass (the smallest subnormal, 6e-8, stands in: its value is immaterial, its sign is not)
+__device__ __forceinline__ _Float16 unscale_lo(_Float16 ls) {
+    const float f = (float) ls;
+    _Float16 u = (_Float16) (f * LO_INV);
+    if ((float) u == 0.f && f != 0.f) u = (_Float16) (f > 0.f ? 5.9604645e-8f : -5.9604645e-8f);
+    return u;
+}
 }  // namespace x3
 
 struct MlpX3Weights { const _Float16 *W1h, *W1l, *Whh, *Whl; };
@@ -192,8 +201,11 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
         }
     };
 
+    constexpr int PD = KC / 16;
+    h8_t ah[PD][2], al[PD][2];
     // ---- layer 1: K = 2 es, features generated chunk by chunk ------------------------------------------------------------
     const int K1 = 2 * a.es, nchunks = K1 / KC;
+    if (a.h0_hi == nullptr) {
     // a chunk = the sines and the cosines of 32 rows of B (the K order of W1 is permuted to match, k_split_f32_frag): 64 voxels x 32
     // arguments, thread -> voxel tid & 63, rows 4 (tid >> 6) .. + 3, one sincos per argument
     auto make_features = [&](int chunk, int buf) {
@@ -222,8 +234,6 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
     __syncthreads();
     // weight fragments run PD k-steps ahead of their use in a register ring (an L2 hit is ~700 cycles away, a k-step of this wave 384
     // MFMA cycles, twice that with the other wave of the SIMD in between: one k-step of lookahead left the matrix pipe waiting)
-    constexpr int PD = KC / 16;
-    h8_t ah[PD][2], al[PD][2];
     {
         const int nks1 = K1 / 16;
 #pragma unroll
@@ -245,6 +255,7 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
             __syncthreads();
         }
     }
+    }   // (first layer)
 
     // ---- epilogue of a layer: bias + ReLU, split into the two activation images --------------------------------------------
     auto store_layer = [&](const float *bias) {
@@ -277,7 +288,7 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
     };
     // training: the finished layer's two [voxel][k] images to HBM in 16-byte pieces, the low halves unscaled (h = hi + lo)
     auto save_layer = [&](int layer) {
-        if (!a.save_act) return;
+        if (!a.save_act || (a.save_first_only && layer > 0)) return;
         _Float16 *dh = reinterpret_cast<_Float16 *>(a.save_act) + ((long long) layer * a.act_rows + v0) * a.nn;
         _Float16 *dl = reinterpret_cast<_Float16 *>(a.save_act_lo) + ((long long) layer * a.act_rows + v0) * a.nn;
         const int ppr = a.nn / 8;
@@ -286,15 +297,39 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
             if (v0 + v < a.nvox) {
                 *reinterpret_cast<h8_t *>(dh + (long long) v * a.nn + 8 * c) = *reinterpret_cast<const h8_t *>(Hh + v * HS + 8 * c);
                 h8_t l = *reinterpret_cast<const h8_t *>(Hl + v * HS + 8 * c);
+                // (the kept first layer stays SCALED, the exact image: the unscaled half can be subnormal, and a forward pass that resumed
+                // from it would differ from the recomputed one in the last bits -- enough to flip ReLU masks)
+                if (!a.save_first_only) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) l[j] = (_Float16) ((float) l[j] * LO_INV);
+                    for (int j = 0; j < 8; ++j) l[j] = unscale_lo(l[j]);
+                }
                 *reinterpret_cast<h8_t *>(dl + (long long) v * a.nn + 8 * c) = l;
             }
         }
     };
-    store_layer(a.bias);          // all waves passed the last barrier of the chunk loop: the feature buffers are dead
-    __syncthreads();
-    save_layer(0);
+    if (a.h0_hi == nullptr) {
+        store_layer(a.bias);      // all waves passed the last barrier of the chunk loop: the feature buffers are dead
+        __syncthreads();
+        save_layer(0);
+    } else {
+        // training, first-layer activations kept by the forward pass of this step (vfem_mlp: h0): two thirds of the forward's products
+        // are not recomputed -- the images are loaded exactly as that forward left them
+        const _Float16 *sh = reinterpret_cast<const _Float16 *>(a.h0_hi), *sl = reinterpret_cast<const _Float16 *>(a.h0_lo);
+        const int ppr = a.nn / 8;
+        for (int q = tid; q < TM * ppr; q += 512) {
+            const int v = q / ppr, c = q - v * ppr;
+            h8_t xh, xl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { xh[j] = (_Float16) 0.f; xl[j] = (_Float16) 0.f; }
+            if (v0 + v < a.nvox) {
+                xh = *reinterpret_cast<const h8_t *>(sh + (v0 + v) * a.nn + 8 * c);
+                xl = *reinterpret_cast<const h8_t *>(sl + (v0 + v) * a.nn + 8 * c);
+            }
+            *reinterpret_cast<h8_t *>(Hh + v * HS + 8 * c) = xh;
+            *reinterpret_cast<h8_t *>(Hl + v * HS + 8 * c) = xl;
+        }
+        __syncthreads();
+    }
 
     // ---- hidden layers ------------------------------------------------------------------------------------------------------
     for (int l = 0; l < a.n_hidden; ++l) {

@@ -24,6 +24,9 @@ struct MlpArgs {
     void *save_act_lo;                      // reference-precision forward only: the low halves, UNSCALED (h = hi + lo), same layout
     long long act_rows;
     int ablate;                             // timing ablations (wrong results): 1 no feature generation, 2 no hidden layers, 3 no layer-1 MFMAs
+    const void *h0_hi, *h0_lo;              // reference-precision forward, training: first-layer activations kept by an earlier forward
+                                            // ([nvox][nn] fp16 pairs, h = hi + lo 2^-11, indexed from the chunk's first voxel): the first layer is skipped
+    int save_first_only;                    // save_act / save_act_lo receive the first layer's activations only (the forward that keeps them)
     int *range_flag;                        // reference-precision forward: set to 1 when a hidden activation leaves fp16's range (its high half would be inf)
 };
 
@@ -37,6 +40,7 @@ struct MlpBwdArgs {
     const float *out32;                     // [nvox] forward outputs (sigmoid derivative)
     float scale;                            // loss scale applied to g
     const void *act_hi, *act_lo;            // [1 + n_hidden][act_rows][nn]: post-ReLU activations saved by the forward kernel
+    const void *act0_hi, *act0_lo;          // non-null: layer 0 lives here instead ([act_rows][nn], the kept first-layer activations)
     void *dz_hi, *dz_lo;                    // [1 + n_hidden][act_rows][nn]: scaled gradients wrt the pre-activations
     float *gs;                              // [act_rows] scaled dL/d(pre-sigmoid out), zero beyond nvox
     long long act_rows, nvox;
@@ -48,6 +52,7 @@ struct MlpDwArgs {
     int nn, K;                              // output rows (hidden width), columns (nn, or 2 es for the first layer)
     const void *dz_hi, *dz_lo;              // [rows][nn]
     const void *h_hi, *h_lo;                // [rows][K], null for the first layer
+    int h_lo_scaled;                        // the low halves of h carry the forward kernel's 2^11 scale (the kept first-layer activations)
     MlpArgs grid;                           // first layer: coordinates / grid of the chunk and B (es, B, coords, gn, glo, gstep, v_offset, nvox)
     long long rows;                         // voxels of the chunk, padded to a multiple of 32 x slices (rows beyond nvox hold dz = 0)
     int slices;                             // voxel slices: one block per (slice, output tile), partial sums [slice][nn][K]

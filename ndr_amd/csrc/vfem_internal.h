@@ -325,4 +325,12 @@ struct vfem_mlp {
     vfem::DevBuf<float> gs, partial, partial_b, out_chunk;
     int bwd_terms = 3;                           // VFEM_MLP_OPT_BWD_TERMS
     vfem::DevBuf<int> range_flag;                // raised by the reference-precision kernels when a value leaves fp16's range
+    // VFEM_MLP_OPT_KEEP_FIRST: the first layer's activations of the last reference-precision grid forward, (hi, lo) pairs [voxels][nn], and
+    // the grid / voxel range they belong to; the backward pass of the same range starts from them instead of recomputing two thirds of
+    // the forward's products (68.7 GB at 512 x 256 x 256: the part has 288)
+    int keep_first = 0;
+    vfem::DevBuf<uint16_t> h0_hi, h0_lo;
+    bool h0_valid = false;
+    int64_t h0_n[3] = {0, 0, 0}, h0_first = 0, h0_count = 0;
+    double h0_lo_c[3] = {0, 0, 0}, h0_hi_c[3] = {0, 0, 0};
 };

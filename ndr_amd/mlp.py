@@ -44,6 +44,11 @@ class MLP:
         """3 (default): hi hi + hi lo + lo hi in the weight-gradient products; 1: hi hi only (VFEM_MLP_OPT_BWD_TERMS)"""
         _lib.check(self._lib.vfem_mlp_set_option(self._h, 1, int(terms)))
 
+    def set_keep_first_layer(self, keep):
+        """training: a reference-precision grid forward keeps the first layer's activations (2 KB per voxel) and the backward pass of
+        the same grid starts from them instead of recomputing the first layer (VFEM_MLP_OPT_KEEP_FIRST); same results bit for bit"""
+        _lib.check(self._lib.vfem_mlp_set_option(self._h, 2, int(bool(keep))))
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h is not None and h.value:
@@ -236,6 +241,7 @@ class TrainableMLP(torch.nn.Module):
         super().__init__()
         self.kernel = MLP(in_features, out_features, n_neurons, n_layers, embedding_size, scale, dropout_rate, hidden_act,
                           output_act)
+        self.kernel.set_keep_first_layer(True)       # a training step is forward_grid followed by backward_grid of the same grid
         self.embedding_size, self.in_features, self.n_neurons, self.scale = embedding_size, in_features, n_neurons, scale
         self.B = (torch.normal(0, 1, size=(embedding_size, in_features)) * scale).to(_dev())
         layers = []

@@ -279,6 +279,57 @@ def test_hip_mlp_gradients_multi_chunk_and_linearity():
 
 
 @pytest.mark.gpu
+def test_backward_from_kept_first_layer_activations_is_bitwise_the_recomputed_one():
+    """VFEM_MLP_OPT_KEEP_FIRST: the grid forward keeps the first layer's activations and the backward pass of the same grid skips the
+    first layer's recomputation -- same gradients bit for bit, also over several chunks with a ragged tail and for a voxel range; a
+    backward pass of another grid, or after new weights, falls back to the recomputation"""
+    import torch
+    from ndr_amd.mlp import MLP
+    rng = np.random.default_rng(9)
+    es, nn_, nl = 64, 128, 4
+    B = (rng.standard_normal((es, 3)) * 2.0).astype(np.float32)
+    Ws = [rng.standard_normal((nn_, 2 * es)).astype(np.float32) / np.sqrt(2 * es)] + \
+         [rng.standard_normal((nn_, nn_)).astype(np.float32) / np.sqrt(nn_) for _ in range(nl - 2)] + \
+         [rng.standard_normal((1, nn_)).astype(np.float32) / np.sqrt(nn_)]
+    bs = [rng.standard_normal(nn_).astype(np.float32) * 0.1 for _ in range(nl - 1)] + [np.array([0.1], np.float32)]
+    m = MLP(3, 1, nn_, nl, es, 2.0)
+    m.load_arrays(B, Ws, bs)
+    side = (130, 96, 100)                                      # 1 248 000 voxels: two chunks, ragged tail
+    g = torch.randn(int(np.prod(side)), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    ref_w, ref_b = m.backward_grid(side, g, loss_scale=16.0)
+    ref = [t.clone() for t in ref_w + ref_b]
+    m.set_keep_first_layer(True)
+    out_keep = m.forward_grid(side)
+    got_w, got_b = m.backward_grid(side, g, loss_scale=16.0)
+    for a, b in zip(got_w + got_b, ref):
+        assert torch.equal(a, b)
+    m.set_keep_first_layer(False)
+    assert torch.equal(m.forward_grid(side), out_keep)
+    m.set_keep_first_layer(True)
+    # a voxel range (what a slab rank differentiates through)
+    first, count = 96 * 100 * 7 + 13, 96 * 100 * 40
+    m.set_keep_first_layer(False)
+    r_w, r_b = m.backward_grid_range(side, first, count, g[first:first + count], loss_scale=16.0)
+    r = [t.clone() for t in r_w + r_b]
+    m.set_keep_first_layer(True)
+    m.forward_grid_range(side, first, count)
+    k_w, k_b = m.backward_grid_range(side, first, count, g[first:first + count], loss_scale=16.0)
+    for a, b in zip(k_w + k_b, r):
+        assert torch.equal(a, b)
+    # another range than the kept one, and new weights: recomputation, same values
+    o_w, o_b = m.backward_grid(side, g, loss_scale=16.0)
+    for a, b in zip(o_w + o_b, ref):
+        assert torch.equal(a, b)
+    m.forward_grid(side)
+    m.load_arrays(B, [w * 1.5 for w in Ws], bs)
+    n_w, n_b = m.backward_grid(side, g, loss_scale=16.0)
+    m.set_keep_first_layer(False)
+    f_w, f_b = m.backward_grid(side, g, loss_scale=16.0)
+    for a, b in zip(n_w + n_b, f_w + f_b):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 def test_fused_adam_matches_torch_adam():
     import ctypes
     import torch

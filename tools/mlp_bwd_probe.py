@@ -47,3 +47,9 @@ if len(sys.argv) < 2:
         m.backward_grid(side, g); torch.cuda.synchronize()
         t0 = time.perf_counter(); m.backward_grid(side, g); torch.cuda.synchronize()
         print("terms", terms, "backward seconds", time.perf_counter() - t0, flush=True)
+    m.set_backward_terms(3)
+    m.set_keep_first_layer(True)
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); m.forward_grid(side); torch.cuda.synchronize(); tf = time.perf_counter() - t0
+        t0 = time.perf_counter(); m.backward_grid(side, g); torch.cuda.synchronize()
+        print("first layer kept: forward", tf, "backward", time.perf_counter() - t0, flush=True)
