@@ -237,40 +237,59 @@ void launch_mlp_backward_x3(const MlpBwdArgs &a, long long rows, hipStream_t s) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// weight gradients: one block = (voxel slice, 256 x 256 output tile); 8 waves as 2 (rows) x 4 (columns), a wave owns 4 x 2 tiles
-// of 32 x 32 = 128 accumulator registers.  Block ids are dealt to the XCDs round-robin, so the numbering puts all tiles of a
+// weight gradients: one block = (voxel slice, BN x BK output tile), 8 waves, a wave owns 4 x 2 tiles of 32 x 32 = 128 accumulator
+// registers.  The tile shape is a template parameter; both layers' kinds run 256 x 256 with stages of 32 voxels (waves 2 x 4).  A
+// 512 x 128 shape with stages of 16 voxels (waves 4 x 2: all rows in one block, so the first layer's Fourier features are regenerated
+// once per column tile and not once per row tile as well -- its kernel is as much vector as matrix work, 1 810 vector instructions per
+// voxel, profiles/r04_mlp_pipeline_pmc.json) was built and measured: correct, and 8 % SLOWER per backward pass (0.68 against 0.63 s
+// from the kept first layer; twice the barriers per voxel and twice the dz bytes through L2 outweigh the halved feature work).
+// Block ids are dealt to the XCDs round-robin, so the numbering puts all tiles of a
 // slice on ONE XCD: the slice's operands leave HBM once and the other tiles find them in that XCD's L2.
 // ---------------------------------------------------------------------------------------------------------------------------
 namespace dw {
-constexpr int BT = 256;                     // output tile edge
-constexpr int SV = 32;                      // voxels per stage (two k-steps of 16)
-constexpr int PITCH = BT * 2 + 64;          // bytes per staged row: + 64 puts the four rows of a transposing read on distinct banks
-constexpr int IMG = SV * PITCH;             // one image (one operand half, one stage)
-constexpr size_t LDS_BYTES = (size_t) 8 * IMG;   // (A hi, A lo, B hi, B lo) x 2 stages
+template <int BN_, int BK_, int SV_>
+struct Shape {
+    static constexpr int BN = BN_, BK = BK_, SV = SV_;       // output tile rows / columns, voxels per stage
+    static constexpr int WN = BN / 128, WK = 8 / WN;           // waves along the rows / columns (a wave: 128 rows x 64 columns)
+    static_assert(WN * WK == 8 && BK == 64 * WK, "eight waves of 4 x 2 tiles");
+    static_assert(SV % 16 == 0 && SV * BN / 8 == 1024 && (SV * BK / 8) % 512 == 0 || SV * BK / 8 == 256, "staging: two A pieces per thread");
+    static constexpr int PA = BN * 2 + 64, PB = BK * 2 + 64;  // bytes per staged row: + 64 puts the four rows of a transposing read on distinct banks
+    static constexpr int IA = SV * PA, IB = SV * PB;          // one image (one operand half, one stage)
+    static constexpr int STAGE = 2 * IA + 2 * IB;             // A hi, A lo, B hi, B lo
+    static constexpr size_t LDS_BYTES = (size_t) 2 * STAGE;
+    static_assert(LDS_BYTES <= 160 * 1024, "two stages must fit the LDS of a CU");
+};
+using Hidden = Shape<256, 256, 32>;
+using First = Shape<256, 256, 32>;      // (Shape<512, 128, 16>: measured slower, see above)
 }  // namespace dw
 
-template <int TERMS, bool FEATURES>
+template <int TERMS, bool FEATURES, class C>
 __global__ void __launch_bounds__(512) k_mlp_dw(MlpDwArgs a) {
     using namespace bw;
-    using namespace dw;
+    constexpr int BN = C::BN, BK = C::BK, SV = C::SV, PA = C::PA, PB = C::PB, IA = C::IA, IB = C::IB, STAGE = C::STAGE;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 1, wk = wave >> 1;
-    const int tiles_n = (a.nn + BT - 1) / BT, tiles_k = (a.K + BT - 1) / BT, ntile = tiles_n * tiles_k;
+    const int wn = wave % C::WN, wk = wave / C::WN;
+    const int tiles_n = (a.nn + BN - 1) / BN, tiles_k = (a.K + BK - 1) / BK, ntile = tiles_n * tiles_k;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int slice = (idx / ntile) * 8 + xcd, tile = idx % ntile;
     if (slice >= a.slices) return;
-    const int n0 = (tile / tiles_k) * BT, k0 = (tile % tiles_k) * BT;
+    const int n0 = (tile / tiles_k) * BN, k0 = (tile % tiles_k) * BK;
     const long long per_slice = a.rows / a.slices;
     const long long vbase = (long long) slice * per_slice;
     const int nstages = (int) (per_slice / SV);
     const _Float16 *Ah = reinterpret_cast<const _Float16 *>(a.dz_hi), *Al = reinterpret_cast<const _Float16 *>(a.dz_lo);
     const _Float16 *Bh = reinterpret_cast<const _Float16 *>(a.h_hi), *Bl = reinterpret_cast<const _Float16 *>(a.h_lo);
 
-    // staging: an image is 32 rows x 32 pieces of 16 bytes; thread -> pieces tid and tid + 512 of each image (rows tid / 32 and + 16)
-    const int prow = tid >> 5, pcol = tid & 31;
-    const bool a_in = n0 + 8 * pcol < a.nn, b_in = k0 + 8 * pcol < a.K;       // (widths are multiples of 8)
-    h8_t ra[2][2], rb[2][2];                                                  // [hi / lo][piece]
+    // staging: an A image is SV rows x BN / 8 pieces of 16 bytes = 1024 pieces, thread -> pieces tid and tid + 512; a B image likewise
+    constexpr int APR = BN / 8, BPR = BK / 8;                 // pieces per row
+    constexpr int NB = (SV * BPR + 511) / 512;                // B pieces per thread and image (hidden layers: 2)
+    int arow[2], acol[2], brow[NB], bcol[NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { arow[i] = (tid + 512 * i) / APR; acol[i] = (tid + 512 * i) % APR; }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) { brow[i] = (tid + 512 * i) / BPR; bcol[i] = (tid + 512 * i) % BPR; }
+    h8_t ra[2][2], rb[2][NB];                                 // [hi / lo][piece]
     auto zero8 = [](h8_t &x) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = (_Float16) 0.f;
@@ -278,16 +297,20 @@ __global__ void __launch_bounds__(512) k_mlp_dw(MlpDwArgs a) {
     auto fetch = [&](int st) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const long long v = vbase + (long long) st * SV + prow + 16 * i;
-            if (a_in) {
-                ra[0][i] = *reinterpret_cast<const h8_t *>(Ah + v * a.nn + n0 + 8 * pcol);
-                if (TERMS == 3) ra[1][i] = *reinterpret_cast<const h8_t *>(Al + v * a.nn + n0 + 8 * pcol);
+            const long long v = vbase + (long long) st * SV + arow[i];
+            if (n0 + 8 * acol[i] < a.nn) {                    // (widths are multiples of 8)
+                ra[0][i] = *reinterpret_cast<const h8_t *>(Ah + v * a.nn + n0 + 8 * acol[i]);
+                if (TERMS == 3) ra[1][i] = *reinterpret_cast<const h8_t *>(Al + v * a.nn + n0 + 8 * acol[i]);
             } else { zero8(ra[0][i]); zero8(ra[1][i]); }
-            if (!FEATURES) {
-                if (b_in) {
-                    rb[0][i] = *reinterpret_cast<const h8_t *>(Bh + v * a.K + k0 + 8 * pcol);
+        }
+        if (!FEATURES) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const long long v = vbase + (long long) st * SV + brow[i];
+                if (brow[i] < SV && k0 + 8 * bcol[i] < a.K) {
+                    rb[0][i] = *reinterpret_cast<const h8_t *>(Bh + v * a.K + k0 + 8 * bcol[i]);
                     if (TERMS == 3) {
-                        rb[1][i] = *reinterpret_cast<const h8_t *>(Bl + v * a.K + k0 + 8 * pcol);
+                        rb[1][i] = *reinterpret_cast<const h8_t *>(Bl + v * a.K + k0 + 8 * bcol[i]);
                         if (a.h_lo_scaled) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) rb[1][i][j] = unscale_lo(rb[1][i][j]);
@@ -298,63 +321,74 @@ __global__ void __launch_bounds__(512) k_mlp_dw(MlpDwArgs a) {
         }
     };
     auto commit = [&](int buf) {
-        unsigned char *base = smem + (size_t) buf * 4 * IMG;
+        unsigned char *base = smem + (size_t) buf * STAGE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int off = (prow + 16 * i) * PITCH + 16 * pcol;
+            const int off = arow[i] * PA + 16 * acol[i];
             *reinterpret_cast<h8_t *>(base + off) = ra[0][i];
-            if (TERMS == 3) *reinterpret_cast<h8_t *>(base + IMG + off) = ra[1][i];
-            if (!FEATURES) {
-                *reinterpret_cast<h8_t *>(base + 2 * IMG + off) = rb[0][i];
-                if (TERMS == 3) *reinterpret_cast<h8_t *>(base + 3 * IMG + off) = rb[1][i];
+            if (TERMS == 3) *reinterpret_cast<h8_t *>(base + IA + off) = ra[1][i];
+        }
+        if (!FEATURES) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (brow[i] >= SV) continue;
+                const int off = brow[i] * PB + 16 * bcol[i];
+                *reinterpret_cast<h8_t *>(base + 2 * IA + off) = rb[0][i];
+                if (TERMS == 3) *reinterpret_cast<h8_t *>(base + 2 * IA + IB + off) = rb[1][i];
             }
         }
     };
-    // first layer: the block's 256 columns are four 64-wide chunks of the forward kernel's K order (the sines of 32 rows of B, then
-    // their cosines): 32 voxels x 128 arguments per stage, thread -> voxel tid & 31, eight consecutive rows of B
+    // first layer: the block's BK columns are BK / 64 chunks of the forward kernel's K order (the sines of 32 rows of B, then their
+    // cosines): SV voxels x BK / 2 arguments per stage, thread -> voxel tid % SV, FR consecutive rows of B
+    constexpr int FG = 512 / SV, FR = (BK / 2) / FG;          // row groups, rows of B per thread (hidden shape: 16 x 8; first: 32 x 2)
+    static_assert(FR >= 1 && 32 % FR == 0, "a thread's rows of B lie in one chunk");
     auto features = [&](int st, int buf) {
-        unsigned char *base = smem + (size_t) buf * 4 * IMG;
-        const int v = tid & 31, rg = tid >> 5;                                      // 0..15 (two row groups per wave)
-        const int chunk = rg >> 2, ro = (rg & 3) * 8;
-        const int brow = ((k0 >> 6) + chunk) * 32 + ro;                              // first row of B
+        unsigned char *base = smem + (size_t) buf * STAGE + 2 * IA;
+        const int v = tid % SV, rg = tid / SV;
+        const int chunk = (rg * FR) >> 5, ro = (rg * FR) & 31;
+        const int brow0 = ((k0 >> 6) + chunk) * 32 + ro;                             // first row of B
         float x[3] = {0.f, 0.f, 0.f};
         const long long vv = vbase + (long long) st * SV + v;
         if (vv < a.grid.nvox) voxel_xyz(a.grid, vv, x);           // (padded rows carry dz = 0; their features only have to be finite)
         const float twopi = 6.283185307179586f;
         const float c0 = twopi * x[0], c1 = twopi * x[1], c2 = twopi * x[2];
-        h8_t sh, sl, ch, cl;
-        if (brow < a.grid.es) {
-            const float *Bp = a.grid.B + 3 * brow;
+        _Float16 sh[FR], sl[FR], ch[FR], cl[FR];
+        const bool in = brow0 < a.grid.es;
+        const float *Bp = a.grid.B + 3 * (in ? brow0 : 0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float arg = fmaf(c2, Bp[3 * j + 2], fmaf(c1, Bp[3 * j + 1], c0 * Bp[3 * j]));
-                float sn, cs;
-                sincos_f32(arg, sn, cs);
-                _Float16 fh, fl;
-                split_plain(sn, fh, fl);
-                sh[j] = fh; sl[j] = fl;
-                split_plain(cs, fh, fl);
-                ch[j] = fh; cl[j] = fl;
+        for (int j = 0; j < FR; ++j) {
+            const float arg = fmaf(c2, Bp[3 * j + 2], fmaf(c1, Bp[3 * j + 1], c0 * Bp[3 * j]));
+            float sn, cs;
+            sincos_f32(arg, sn, cs);
+            if (!in) { sn = 0.f; cs = 0.f; }
+            split_plain(sn, sh[j], sl[j]);
+            split_plain(cs, ch[j], cl[j]);
+        }
+        const int off = v * PB + 2 * (64 * chunk + ro);
+#pragma unroll
+        for (int j = 0; j < FR; ++j) {
+            *reinterpret_cast<_Float16 *>(base + off + 2 * j) = sh[j];
+            *reinterpret_cast<_Float16 *>(base + off + 64 + 2 * j) = ch[j];
+            if (TERMS == 3) {
+                *reinterpret_cast<_Float16 *>(base + IB + off + 2 * j) = sl[j];
+                *reinterpret_cast<_Float16 *>(base + IB + off + 64 + 2 * j) = cl[j];
             }
-        } else { zero8(sh); zero8(sl); zero8(ch); zero8(cl); }
-        const int off = v * PITCH + 2 * (64 * chunk + ro);
-        *reinterpret_cast<h8_t *>(base + 2 * IMG + off) = sh;
-        *reinterpret_cast<h8_t *>(base + 2 * IMG + off + 64) = ch;
-        if (TERMS == 3) {
-            *reinterpret_cast<h8_t *>(base + 3 * IMG + off) = sl;
-            *reinterpret_cast<h8_t *>(base + 3 * IMG + off + 64) = cl;
         }
     };
 
     // bias gradient of the layer = column sums of dz, the A operand: the blocks of the first column tile add up the pieces they stage
     // anyway (eight columns x two rows per thread and stage), no pass of its own over dz
     const bool colsum = a.colsum_partial != nullptr && k0 == 0;
-    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float cs[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[i][j] = 0.f;
     auto add_colsum = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) cs[j] += (float) ra[0][i][j] + (TERMS == 3 ? (float) ra[1][i][j] : 0.f);
+            for (int j = 0; j < 8; ++j) cs[i][j] += (float) ra[0][i][j] + (TERMS == 3 ? (float) ra[1][i][j] : 0.f);
     };
 
     f16_t acc[4][2];
@@ -370,12 +404,11 @@ __global__ void __launch_bounds__(512) k_mlp_dw(MlpDwArgs a) {
     // address of row (i >> 2), columns 4 (i & 3) .. + 3 of the block and RECEIVES column i of its four rows -- column col0 + (lane & 31),
     // voxels 8 (lane >> 5) + 4 t + 0..3 of the k-step: the MFMA operand layout.
     const int g4 = lane >> 4, i16 = lane & 15;
-    const int tr_lane_off = (8 * (g4 >> 1) + (i16 >> 2)) * PITCH + 2 * (16 * (g4 & 1) + 4 * (i16 & 3));
-    auto frag = [&](const unsigned char *img, int col0, int ks) {
+    auto frag = [&](const unsigned char *img, int pitch, int col0, int ks) {
         union { hf4_t q[2]; h8_t v; } u;
-        const unsigned char *p = img + tr_lane_off + (16 * ks) * PITCH + 2 * col0;
+        const unsigned char *p = img + (16 * ks + 8 * (g4 >> 1) + (i16 >> 2)) * pitch + 2 * (col0 + 16 * (g4 & 1) + 4 * (i16 & 3));
         u.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hf4_t *) (p));
-        u.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hf4_t *) (p + 4 * PITCH));
+        u.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hf4_t *) (p + 4 * pitch));
         return u.v;
     };
 
@@ -388,23 +421,23 @@ __global__ void __launch_bounds__(512) k_mlp_dw(MlpDwArgs a) {
     __syncthreads();
     for (int st = 0; st < nstages; ++st) {
         const int buf = st & 1;
-        const unsigned char *base = smem + (size_t) buf * 4 * IMG;
+        const unsigned char *base = smem + (size_t) buf * STAGE;
         if (st + 1 < nstages) fetch(st + 1);
         // waves 0-3 generate the next stage's features before their products, waves 4-7 after: the two waves of a SIMD are on the
         // vector and on the matrix pipe at different times
         if (FEATURES && wave < 4 && st + 1 < nstages) features(st + 1, 1 - buf);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < SV / 16; ++ks) {
             h8_t fa[4], fal[4], fb[2], fbl[2];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                fa[t] = frag(base, wn * 128 + 32 * t, ks);
-                if (TERMS == 3) fal[t] = frag(base + IMG, wn * 128 + 32 * t, ks);
+                fa[t] = frag(base, PA, wn * 128 + 32 * t, ks);
+                if (TERMS == 3) fal[t] = frag(base + IA, PA, wn * 128 + 32 * t, ks);
             }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                fb[c] = frag(base + 2 * IMG, wk * 64 + 32 * c, ks);
-                if (TERMS == 3) fbl[c] = frag(base + 3 * IMG, wk * 64 + 32 * c, ks);
+                fb[c] = frag(base + 2 * IA, PB, wk * 64 + 32 * c, ks);
+                if (TERMS == 3) fbl[c] = frag(base + 2 * IA + IB, PB, wk * 64 + 32 * c, ks);
             }
             // term by term over the eight tiles: products into the same accumulator are eight MFMAs apart, not back to back
 #pragma unroll
@@ -423,15 +456,17 @@ __global__ void __launch_bounds__(512) k_mlp_dw(MlpDwArgs a) {
         __syncthreads();
     }
     if (colsum) {
-        // the 16 threads that share a column piece (rows tid >> 5) meet in LDS (the staging buffers are dead), fixed order
-        float *red = reinterpret_cast<float *>(smem);
+        // the threads that share a column piece (rows arow) meet in LDS (the staging buffers are dead), fixed order
+        float *red = reinterpret_cast<float *>(smem);          // [SV rows][BN columns]
 #pragma unroll
-        for (int j = 0; j < 8; ++j) red[(prow * 32 + pcol) * 8 + j] = cs[j];
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[arow[i] * BN + 8 * acol[i] + j] = cs[i][j];
         __syncthreads();
-        if (tid < 256) {
+        for (int c = tid; c < BN; c += 512) {
             float sum = 0.f;
-            for (int q = 0; q < 16; ++q) sum += red[q * 256 + tid];
-            if (n0 + tid < a.nn) a.colsum_partial[(long long) slice * a.nn + n0 + tid] = sum;
+            for (int q = 0; q < SV; ++q) sum += red[q * BN + c];
+            if (n0 + c < a.nn) a.colsum_partial[(long long) slice * a.nn + n0 + c] = sum;
         }
     }
 
@@ -457,26 +492,27 @@ __global__ void __launch_bounds__(512) k_mlp_dw(MlpDwArgs a) {
 void launch_mlp_dw(const MlpDwArgs &a, hipStream_t s) {
     using namespace dw;
     if (a.slices % 8 || a.slices <= 0) throw Error("MLP weight gradient: the number of voxel slices must be a positive multiple of 8");
-    if (a.rows % ((long long) a.slices * SV)) throw Error("MLP weight gradient: chunk rows must be a multiple of 32 x slices");
+    if (a.rows % ((long long) a.slices * 32)) throw Error("MLP weight gradient: chunk rows must be a multiple of 32 x slices");
     if (a.nn % 8 || a.K % 8) throw Error("MLP weight gradient: widths must be multiples of 8");
     const bool feat = a.h_hi == nullptr;
     if (feat && (a.K != 2 * a.grid.es || a.grid.es % 32)) throw Error("MLP weight gradient: first layer needs K = 2 es, es % 32 == 0");
-    const int tiles_n = (a.nn + BT - 1) / BT, tiles_k = (a.K + BT - 1) / BT;
-    const unsigned blocks = (unsigned) ((a.slices / 8) * tiles_n * tiles_k * 8);
     static bool attr_set = false;
     if (!attr_set) {
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_dw<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_dw<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_dw<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_dw<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_BYTES));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_dw<3, false, Hidden>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) Hidden::LDS_BYTES));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_dw<1, false, Hidden>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) Hidden::LDS_BYTES));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_dw<3, true, First>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) First::LDS_BYTES));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_dw<1, true, First>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) First::LDS_BYTES));
         attr_set = true;
     }
-    if (a.terms == 3) {
-        if (feat) k_mlp_dw<3, true><<<dim3(blocks), dim3(512), LDS_BYTES, s>>>(a);
-        else      k_mlp_dw<3, false><<<dim3(blocks), dim3(512), LDS_BYTES, s>>>(a);
+    auto blocks_of = [&](int BN, int BK) { return (unsigned) ((a.slices / 8) * ((a.nn + BN - 1) / BN) * ((a.K + BK - 1) / BK) * 8); };
+    if (feat) {
+        const unsigned blocks = blocks_of(First::BN, First::BK);
+        if (a.terms == 3) k_mlp_dw<3, true, First><<<dim3(blocks), dim3(512), First::LDS_BYTES, s>>>(a);
+        else              k_mlp_dw<1, true, First><<<dim3(blocks), dim3(512), First::LDS_BYTES, s>>>(a);
     } else {
-        if (feat) k_mlp_dw<1, true><<<dim3(blocks), dim3(512), LDS_BYTES, s>>>(a);
-        else      k_mlp_dw<1, false><<<dim3(blocks), dim3(512), LDS_BYTES, s>>>(a);
+        const unsigned blocks = blocks_of(Hidden::BN, Hidden::BK);
+        if (a.terms == 3) k_mlp_dw<3, false, Hidden><<<dim3(blocks), dim3(512), Hidden::LDS_BYTES, s>>>(a);
+        else              k_mlp_dw<1, false, Hidden><<<dim3(blocks), dim3(512), Hidden::LDS_BYTES, s>>>(a);
     }
     VFEM_HIP(hipGetLastError());
 }
