@@ -282,6 +282,7 @@ def mlp_rate(side=(512, 256, 256), es=1024, nn_=512, nl=4, sigma=4.0, reps=3):
     torch.cuda.synchronize()
     db = time.perf_counter() - t0
     # a training step as TrainableMLP runs it: the forward keeps the first layer's activations (68.7 GB at this size), the backward starts from them
+    m.precision = "fp32"
     m.set_keep_first_layer(True)
     m.forward_grid(side)
     m.backward_grid(side, g)
