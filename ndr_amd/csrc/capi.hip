@@ -1330,7 +1330,8 @@ int vfem_mlp_load_weights(vfem_mlp *m, const float *B, const float *W1, const fl
     launch_f32_to_f16_frag(m->nn, 2 * m->es, 0, m->W1f.p, m->W1.p, nullptr);
     m->W1h.alloc((size_t) m->nn * 2 * m->es);
     m->W1l.alloc((size_t) m->nn * 2 * m->es);
-    launch_split_f32_frag(m->nn, 2 * m->es, m->W1f.p, m->W1h.p, m->W1l.p, nullptr, m->es);
+    m->kc = m->es % 64 == 0 ? 128 : 64;
+    launch_split_f32_frag(m->nn, 2 * m->es, m->W1f.p, m->W1h.p, m->W1l.p, nullptr, m->es, 0, m->kc);
     m->Whh.alloc((size_t) nh * m->nn * m->nn);
     m->Whl.alloc((size_t) nh * m->nn * m->nn);
     for (int l = 0; l < nh; ++l)
@@ -1453,7 +1454,7 @@ static void mlp_forward_f32_impl(vfem_mlp *m, vfem::MlpArgs base, float *o32, do
         VFEM_HIP(hipMemsetAsync(m->h0_lo.p + (size_t) base.nvox * m->nn, 0, (size_t) 4096 * m->nn * 2, s));
         base.save_act = m->h0_hi.p; base.save_act_lo = m->h0_lo.p; base.act_rows = 0; base.save_first_only = 1;
     }
-    launch_mlp_forward_x3(base, m->W1h.p, m->W1l.p, m->Whh.p, m->Whl.p, s);
+    launch_mlp_forward_x3(base, m->W1h.p, m->W1l.p, m->Whh.p, m->Whl.p, s, m->kc);
     if (keep) {
         for (int dd = 0; dd < 3; ++dd) { m->h0_n[dd] = grid_n[dd]; m->h0_lo_c[dd] = grid_lo[dd]; m->h0_hi_c[dd] = grid_hi[dd]; }
         m->h0_first = base.v_offset; m->h0_count = base.nvox;
@@ -1531,7 +1532,7 @@ static void mlp_backward_impl(vfem_mlp *m, vfem::MlpArgs base, const float *coor
         a.out32 = m->out_chunk.p; a.out64 = nullptr; a.save_act = m->acts.p; a.save_act_lo = m->acts_lo.p; a.act_rows = rows;
         const uint16_t *k_hi = kept ? m->h0_hi.p + (size_t) c0 * nn : nullptr, *k_lo = kept ? m->h0_lo.p + (size_t) c0 * nn : nullptr;
         a.h0_hi = k_hi; a.h0_lo = k_lo;
-        launch_mlp_forward_x3(a, m->W1h.p, m->W1l.p, m->Whh.p, m->Whl.p, s);
+        launch_mlp_forward_x3(a, m->W1h.p, m->W1l.p, m->Whh.p, m->Whl.p, s, m->kc);
         a.h0_hi = nullptr; a.h0_lo = nullptr;
         vfem::MlpBwdArgs b{};
         b.nn = nn; b.n_hidden = nh; b.sigmoid = m->sigmoid; b.WhTh = m->WhTh.p; b.WhTl = m->WhTl.p; b.wout = m->wout.p; b.g = g_out + c0;

@@ -33,8 +33,8 @@ typedef float f16_t __attribute__((ext_vector_type(16)));
 constexpr int TM = 64;                    // voxels per block
 constexpr int MAXN = 512;                 // hidden width limit
 constexpr int HS = MAXN + 8;              // halves per activation row (16-byte pad: conflict-free ds_read_b128)
-constexpr int KC = 64;                    // feature chunk
-constexpr int FS = KC + 8;                // halves per feature row
+// feature chunk of the first layer: KC columns = the sines of KC / 2 rows of B followed by their cosines (one barrier per chunk: 128
+// where the embedding size allows it -- a multiple of 64 --, else 64); FS = KC + 8 halves per staged feature row
 constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
 
 __device__ __forceinline__ void split(float x, _Float16 &hi, _Float16 &lo) {
@@ -92,26 +92,26 @@ __global__ void __launch_bounds__(256) k_split_f32(long long n, const float *__r
 // rows = 32 separate 32-byte pieces: the forward kernel then sits on the L2's REQUEST rate (profiles/r04_mlp_x3_pmc.json: 99 % L2 hits,
 // 0.74 requests per clock and channel, waves 63 % of their time in s_waitcnt).  Stored as [T][S][lane][8] the load is one contiguous KB
 // = eight whole 128-byte lines, and successive k-steps of a tile follow each other in memory.
-// pair_es > 0 (first layer): the K order is permuted so that a 64-wide chunk holds the sines of 32 rows of B followed by the cosines of
-// the same rows (the forward kernel forms both from one argument): logical feature f < es -> 64 (f / 32) + f % 32, f >= es -> the same + 32
+// pair_es > 0 (first layer): the K order is permuted so that a pair_kc-wide chunk holds the sines of pair_kc / 2 rows of B followed by the
+// cosines of the same rows (the forward kernel forms both from one argument)
 // transposed: `in` is the fp32 [K][N] matrix whose transpose is packed (hidden weights for the backward data pass)
-__global__ void __launch_bounds__(256) k_split_f32_frag(int N, int K, int pair_es, int transposed, const float *__restrict__ in, _Float16 *__restrict__ hi, _Float16 *__restrict__ lo) {
+__global__ void __launch_bounds__(256) k_split_f32_frag(int N, int K, int pair_es, int pair_kc, int transposed, const float *__restrict__ in, _Float16 *__restrict__ hi, _Float16 *__restrict__ lo) {
     const long long n = (long long) N * K;
     const int nks = K / 16;
     for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
         const int row = (int) (i / K);
         int k = (int) (i - (long long) row * K);
-        if (pair_es > 0) { const int f = k < pair_es ? k : k - pair_es; k = 64 * (f >> 5) + (f & 31) + (k < pair_es ? 0 : 32); }
+        if (pair_es > 0) { const int f = k < pair_es ? k : k - pair_es; k = pair_kc * (f / (pair_kc / 2)) + f % (pair_kc / 2) + (k < pair_es ? 0 : pair_kc / 2); }
         const long long o = ((((long long) (row >> 5) * nks + (k >> 4)) * 64) + (row & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
         x3::split(transposed ? in[(long long) (int) (i - (long long) row * K) * N + row] : in[i], hi[o], lo[o]);
     }
 }
-void launch_split_f32_frag(int N, int K, const float *in, void *hi, void *lo, hipStream_t s, int pair_es, int transposed) {
+void launch_split_f32_frag(int N, int K, const float *in, void *hi, void *lo, hipStream_t s, int pair_es, int transposed, int pair_kc) {
     if (N % 32 || K % 16) throw Error("fragment-order weights need N % 32 == 0 and K % 16 == 0");
-    if (pair_es > 0 && (K != 2 * pair_es || pair_es % 32)) throw Error("sine / cosine pairing needs K = 2 es and es % 32 == 0");
+    if (pair_es > 0 && (K != 2 * pair_es || pair_es % (pair_kc / 2) || (pair_kc != 64 && pair_kc != 128))) throw Error("sine / cosine pairing needs K = 2 es and es a multiple of half the chunk width (64 or 128)");
     long long g = ((long long) N * K + 255) / 256;
     if (g > 4096) g = 4096;
-    k_split_f32_frag<<<dim3((unsigned) (g < 1 ? 1 : g)), 256, 0, s>>>(N, K, pair_es, transposed, in, (_Float16 *) hi, (_Float16 *) lo);
+    k_split_f32_frag<<<dim3((unsigned) (g < 1 ? 1 : g)), 256, 0, s>>>(N, K, pair_es, pair_kc, transposed, in, (_Float16 *) hi, (_Float16 *) lo);
     VFEM_HIP(hipGetLastError());
 }
 // 1 in *flag when any |in[i]| is not below `limit` (weights of the split-operand kernels: fp16(w) must be finite)
@@ -134,9 +134,10 @@ void launch_split_f32(long long n, const float *in, void *hi, void *lo, hipStrea
     VFEM_HIP(hipGetLastError());
 }
 
-template <bool FULL>                // FULL: hidden width 512 = 16 row tiles, both tiles of every wave live: the branches on tile validity fold away
+template <bool FULL, int KC>        // FULL: hidden width 512 = 16 row tiles, both tiles of every wave live: the branches on tile validity fold away
 __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights w) {
     using namespace x3;
+    constexpr int FS = KC + 8;
     extern __shared__ __align__(16) unsigned char smem[];
     _Float16 *Hh = reinterpret_cast<_Float16 *>(smem);                       // [64][HS] high halves of the activations
     _Float16 *Hl = Hh + TM * HS;                                             // low halves
@@ -201,34 +202,45 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
         }
     };
 
-    constexpr int PD = KC / 16;
+    constexpr int PD = 4;
     h8_t ah[PD][2], al[PD][2];
     // ---- layer 1: K = 2 es, features generated chunk by chunk ------------------------------------------------------------
     const int K1 = 2 * a.es, nchunks = K1 / KC;
     if (a.h0_hi == nullptr) {
-    // a chunk = the sines and the cosines of 32 rows of B (the K order of W1 is permuted to match, k_split_f32_frag): 64 voxels x 32
-    // arguments, thread -> voxel tid & 63, rows 4 (tid >> 6) .. + 3, one sincos per argument
+    // a chunk = the sines and the cosines of KC / 2 rows of B (the K order of W1 is permuted to match, k_split_f32_frag): 64 voxels x
+    // KC / 2 arguments, thread -> voxel tid & 63, rows FR (tid >> 6) .. + FR - 1, one sincos per argument
+    constexpr int HR = KC / 2, FR = HR / 8;
     auto make_features = [&](int chunk, int buf) {
         _Float16 *Fh = F + (2 * buf) * (TM * FS), *Fl = Fh + TM * FS;
         const int v = tid & 63, fq = __builtin_amdgcn_readfirstlane(tid >> 6);
         const float c0 = xc[3 * v], c1 = xc[3 * v + 1], c2 = xc[3 * v + 2];
-        const float *Bp = a.B + 3 * (chunk * 32 + fq * 4);
-        h4_t sh, sl, ch, cl;
+        const float *Bp = a.B + 3 * (chunk * HR + fq * FR);
+        _Float16 sh[FR], sl[FR], ch[FR], cl[FR];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < FR; ++j) {
             const float arg = fmaf(c2, Bp[3 * j + 2], fmaf(c1, Bp[3 * j + 1], c0 * Bp[3 * j]));
             float sn, cs;
             sincos_f32(arg, sn, cs);
-            _Float16 fh, fl;
-            split(sn, fh, fl);
-            sh[j] = fh; sl[j] = fl;
-            split(cs, fh, fl);
-            ch[j] = fh; cl[j] = fl;
+            split(sn, sh[j], sl[j]);
+            split(cs, ch[j], cl[j]);
         }
-        *reinterpret_cast<h4_t *>(Fh + v * FS + fq * 4) = sh;
-        *reinterpret_cast<h4_t *>(Fl + v * FS + fq * 4) = sl;
-        *reinterpret_cast<h4_t *>(Fh + v * FS + 32 + fq * 4) = ch;
-        *reinterpret_cast<h4_t *>(Fl + v * FS + 32 + fq * 4) = cl;
+        if constexpr (FR == 8) {
+            h8_t p0, p1, p2, p3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { p0[j] = sh[j]; p1[j] = sl[j]; p2[j] = ch[j]; p3[j] = cl[j]; }
+            *reinterpret_cast<h8_t *>(Fh + v * FS + fq * 8) = p0;
+            *reinterpret_cast<h8_t *>(Fl + v * FS + fq * 8) = p1;
+            *reinterpret_cast<h8_t *>(Fh + v * FS + HR + fq * 8) = p2;
+            *reinterpret_cast<h8_t *>(Fl + v * FS + HR + fq * 8) = p3;
+        } else {
+            h4_t p0, p1, p2, p3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { p0[j] = sh[j]; p1[j] = sl[j]; p2[j] = ch[j]; p3[j] = cl[j]; }
+            *reinterpret_cast<h4_t *>(Fh + v * FS + fq * 4) = p0;
+            *reinterpret_cast<h4_t *>(Fl + v * FS + fq * 4) = p1;
+            *reinterpret_cast<h4_t *>(Fh + v * FS + HR + fq * 4) = p2;
+            *reinterpret_cast<h4_t *>(Fl + v * FS + HR + fq * 4) = p3;
+        }
     };
     make_features(0, 0);
     __syncthreads();
@@ -246,10 +258,10 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
             // the matrix pipe at different times
             if (wave < 4 && ch + 1 < nchunks) make_features(ch + 1, 1 - cur);
 #pragma unroll
-            for (int q = 0; q < PD; ++q) {
-                const int ks = ch * PD + q;
-                kstep(ah[q], al[q], Fh, Fl, FS, q * 16);
-                if (ks + PD < nks1) load_a(w.W1h, w.W1l, K1, ks + PD, ah[q], al[q]);
+            for (int q = 0; q < KC / 16; ++q) {
+                const int ks = ch * (KC / 16) + q;
+                kstep(ah[q % PD], al[q % PD], Fh, Fl, FS, q * 16);
+                if (ks + PD < nks1) load_a(w.W1h, w.W1l, K1, ks + PD, ah[q % PD], al[q % PD]);
             }
             if (wave >= 4 && ch + 1 < nchunks) make_features(ch + 1, 1 - cur);
             __syncthreads();
@@ -373,20 +385,29 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
     }
 }
 
-void launch_mlp_forward_x3(const MlpArgs &a, const void *W1h, const void *W1l, const void *Whh, const void *Whl, hipStream_t s) {
+void launch_mlp_forward_x3(const MlpArgs &a, const void *W1h, const void *W1l, const void *Whh, const void *Whl, hipStream_t s, int kc) {
     using namespace x3;
     if (a.nn % 32 || a.nn > MAXN || a.es % 32) throw Error("fused MLP kernel: hidden width must be a multiple of 32 up to 512, embedding size a multiple of 32");
+    if ((kc != 64 && kc != 128) || a.es % (kc / 2)) throw Error("fused MLP kernel: feature chunk 64 or 128, embedding size a multiple of half of it");
     const size_t lds = (size_t) 2 * TM * HS * 2 + TM * 3 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_forward_x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_forward_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_forward_x3<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_forward_x3<false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_forward_x3<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        VFEM_HIP(hipFuncSetAttribute((const void *) k_mlp_forward_x3<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         attr_set = true;
     }
     MlpX3Weights w{(const _Float16 *) W1h, (const _Float16 *) W1l, (const _Float16 *) Whh, (const _Float16 *) Whl};
     const long long blocks = (a.nvox + TM - 1) / TM;
-    if (a.nn == MAXN) k_mlp_forward_x3<true><<<dim3((unsigned) blocks), dim3(512), lds, s>>>(a, w);
-    else              k_mlp_forward_x3<false><<<dim3((unsigned) blocks), dim3(512), lds, s>>>(a, w);
+    const dim3 grd((unsigned) blocks), blk(512);
+    if (kc == 128) {
+        if (a.nn == MAXN) k_mlp_forward_x3<true, 128><<<grd, blk, lds, s>>>(a, w);
+        else              k_mlp_forward_x3<false, 128><<<grd, blk, lds, s>>>(a, w);
+    } else {
+        if (a.nn == MAXN) k_mlp_forward_x3<true, 64><<<grd, blk, lds, s>>>(a, w);
+        else              k_mlp_forward_x3<false, 64><<<grd, blk, lds, s>>>(a, w);
+    }
     VFEM_HIP(hipGetLastError());
 }
 

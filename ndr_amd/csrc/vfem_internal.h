@@ -231,8 +231,8 @@ void launch_colsum_split(long long rows, int ncols, const void *Xh, const void *
 // reference-precision fused forward (kernels_mlp_x3.hip): split fp16 operands (hi + lo 2^-11), three MFMA products per product
 void launch_f32_to_f16_frag(int N, int K, int transposed, const float *in, void *out, hipStream_t s);
 void launch_range_check_f32(long long n, const float *in, float limit, int *flag, hipStream_t s);
-void launch_split_f32_frag(int N, int K, const float *in, void *hi, void *lo, hipStream_t s, int pair_es, int transposed = 0);
-void launch_mlp_forward_x3(const MlpArgs &a, const void *W1h, const void *W1l, const void *Whh, const void *Whl, hipStream_t s);
+void launch_split_f32_frag(int N, int K, const float *in, void *hi, void *lo, hipStream_t s, int pair_es, int transposed = 0, int pair_kc = 64);
+void launch_mlp_forward_x3(const MlpArgs &a, const void *W1h, const void *W1l, const void *Whh, const void *Whl, hipStream_t s, int kc);
 void launch_split_f32(long long n, const float *in, void *hi, void *lo, hipStream_t s);
 void launch_reduce_partials(int nb, long long n, const float *partial, float alpha, float beta, float *out, hipStream_t s);
 void launch_sum_f32(long long n, const float *x, float alpha, float beta, float *out, float *scratch, hipStream_t s);
@@ -324,6 +324,7 @@ struct vfem_mlp {
     vfem::DevBuf<uint16_t> acts, acts_lo, dz, dz_lo;   // per chunk: saved activations / gradients wrt pre-activations as (hi, lo) pairs
     vfem::DevBuf<float> gs, partial, partial_b, out_chunk;
     int bwd_terms = 3;                           // VFEM_MLP_OPT_BWD_TERMS
+    int kc = 64;                                 // feature chunk of the reference-precision forward (the K order W1h / W1l are packed for)
     vfem::DevBuf<int> range_flag;                // raised by the reference-precision kernels when a value leaves fp16's range
     // VFEM_MLP_OPT_KEEP_FIRST: the first layer's activations of the last reference-precision grid forward, (hi, lo) pairs [voxels][nn], and
     // the grid / voxel range they belong to; the backward pass of the same range starts from them instead of recomputing two thirds of
