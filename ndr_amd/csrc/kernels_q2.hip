@@ -386,12 +386,22 @@ __device__ __forceinline__ void q2_element_product(double (&v)[81], const double
 
 constexpr int Q2M_OB = 448;                                   // doubles per parked row segment (7 x 64)
 
+typedef unsigned int q2u4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int q2u2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double q2_mkd(unsigned lo, unsigned hi) { return __longlong_as_double(((unsigned long long) hi << 32) | lo); }
+
+// Round 4: rows reach and leave the lanes DIRECTLY.  Rounds 1-3 loaded a row segment in lane-contiguous pieces and turned it into the
+// 9 values (3 nodes x 3 components) of every lane's element through LDS (7 writes + 9 reads and two wave barriers per row, twelve
+// rows per step), and took finished rows back through LDS the same way.  A lane's nine values are 72 contiguous bytes of the row, the
+// next lane's start 48 bytes on: buffer loads of 16 + 16 + 16 + 16 + 8 bytes per lane fetch them as they are (the node shared with the
+// next element twice -- from the vector cache), buffer stores of 3 x 16 bytes write the lane's two finished nodes; an element outside
+// the grid is an out-of-range offset (reads 0, stores nothing).  ~160 of ~250 LDS instructions per step and the 14 KB transpose buffer go.
 template <int EXP>      // 0 production; timing ablations (wrong results): 1 no element product, 2 no row stores, 3 no row loads
 __global__ void __launch_bounds__(256) k_apply_q2_march(DimsQ2 d, const double *__restrict__ tab, const double *__restrict__ E,
                                                         const double *__restrict__ u, double *__restrict__ out, int cb, int xsteps) {
-    __shared__ double lds[4][Q2_BUF];
-    // sums a row already holds when this wave stores it: [wave][2 par + rx] for the rows ry = 0 (what the wave below left, or, for
-    // wave 0 of a block of the second colour, what the block below wrote to `out`), [wave][4 + rx] for the rows ry = 2 of wave 3
+    // sums a row already holds when this wave stores it, in the lanes' own layout (element t of lane l at [6 l + t], the last element's
+    // final node at [6 l + 6 ..]): [wave][2 par + rx] for the rows ry = 0 (what the wave below left, or, for wave 0 of a block of the
+    // second colour, what the block below wrote to `out`), [wave][4 + rx] for the rows ry = 2 of wave 3
     __shared__ double ldso[4][6 * Q2M_OB];
     __shared__ double ldsk[4][27 * 64];                       // `carry`: contributions to the node plane shared with the next step
     const int lane = threadIdx.x, wy = threadIdx.y;
@@ -403,20 +413,13 @@ __global__ void __launch_bounds__(256) k_apply_q2_march(DimsQ2 d, const double *
     double *carry = ldsk[wy] + lane;                          // element t of this lane at carry[64 t]
     const int xa = blockIdx.z * xsteps;
     const int xb = xa + xsteps < d.nx ? xa + xsteps : d.nx;
-    double *buf = lds[wy], *obuf = ldso[wy];
+    double *obuf = ldso[wy];
     const int zb = Q2M_ZS * blockIdx.x - 1;                   // element of lane 0 (-1 in the first chunk: a dummy with zero modulus)
     const int ez = zb + lane;
     const bool elem_ok = ez >= 0 && ez < d.nz;
     const int ezc = ez < 0 ? 0 : (ez > d.nz - 1 ? d.nz - 1 : ez);
-    const long long rowlen = 3LL * d.NZ;
-    const long long seg = 6LL * zb;                           // first double of the chunk inside a node row (-6 in the first chunk)
-    int qa[7];                                                // this lane's doubles of a row segment (absolute inside the row, clamped)
-#pragma unroll
-    for (int s7 = 0; s7 < 7; ++s7) {
-        long long q = seg + lane + 64 * s7;
-        q = q < 0 ? 0 : (q > rowlen - 1 ? rowlen - 1 : q);
-        qa[s7] = (int) q;
-    }
+    const int rowbytes = 24 * d.NZ;                           // (launcher: below 2^31)
+    const unsigned eoff = elem_ok ? 48u * (unsigned) ez : 0x7ffffff0u;       // this lane's nine doubles inside a node row
     // who else adds to this wave's shared rows: the waves of a block hand their ry = 2 rows to the wave above through LDS; across
     // blocks the second colour (cb = 1, launched after cb = 0) reads what its neighbours wrote to `out`
     const bool from_below = wy >= 1;                          // rows ry = 0: the wave below (always active when this one is)
@@ -424,27 +427,27 @@ __global__ void __launch_bounds__(256) k_apply_q2_march(DimsQ2 d, const double *
     const bool hand_up = active && wy < 3 && ey + 1 < d.ny;   // rows ry = 2 go to the wave above instead of to memory
     const bool rmw2 = wy == 3 && cb == 1 && ey + 1 < d.ny;    // rows ry = 2 of wave 3: block B + 1 ran in the first launch
 
-    double v[81], keep[27], pre[6][7], pre_o[2][7], Enext = 0.0;
-    auto rows_to_regs = [&](auto &dst, const double *rowp) {
+    double v[81], keep[27], pre[6][9], pre_o[2][9], Enext = 0.0;
+    auto row_rsrc = [&](const double *base, int X, int Y) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(q2_row(base, d, X, Y)), 0, rowbytes, 0x00020000);
+    };
+    // the lane's nine values of a row: nodes 2 ez, 2 ez + 1, 2 ez + 2
+    auto load9 = [&](double (&dst)[9], __amdgpu_buffer_rsrc_t r) {
 #pragma unroll
-        for (int s7 = 0; s7 < 7; ++s7) dst[s7] = rowp[qa[s7]];
+        for (int q = 0; q < 4; ++q) {
+            const q2u4_t w = __builtin_amdgcn_raw_buffer_load_b128(r, eoff + 16 * q, 0, 0);
+            dst[2 * q] = q2_mkd(w.x, w.y); dst[2 * q + 1] = q2_mkd(w.z, w.w);
+        }
+        const q2u2_t w = __builtin_amdgcn_raw_buffer_load_b64(r, eoff + 64, 0, 0);
+        dst[8] = q2_mkd(w.x, w.y);
     };
     auto issue_loads = [&](int ex) {
         if (EXP == 3) { Enext = E[((long long) ex * d.ny + eyc) * d.nz + ezc]; return; }
         static_for<6>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
-            rows_to_regs(pre[r], q2_row(u, d, 2 * ex + 1 + r / 3, 2 * eyc + r % 3));
+            load9(pre[r], row_rsrc(u, 2 * ex + 1 + r / 3, 2 * eyc + r % 3));
         });
         Enext = E[((long long) ex * d.ny + eyc) * d.nz + ezc];
-    };
-    // one row segment -> the nine values (3 nodes x 3 components) of every lane's element
-    auto transpose_in = [&](const double (&src)[7], double *dst9) {
-#pragma unroll
-        for (int s7 = 0; s7 < 7; ++s7) buf[lane + 64 * s7] = src[s7];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 9; ++q) dst9[q] = buf[6 * lane + q];
-        __builtin_amdgcn_wave_barrier();
     };
     // hand a row to the wave above: bottom and middle node of every lane, and the final node plane from the last element
     auto deposit_row = [&](double *dst, const double *add9) {
@@ -455,38 +458,48 @@ __global__ void __launch_bounds__(256) k_apply_q2_march(DimsQ2 d, const double *
             for (int c = 0; c < 3; ++c) dst[6 * lane + 6 + c] = add9[6 + c];
         }
     };
-    // store one finished row: bottom and middle node of lanes 1..63; `add9` = the lane's 9 values of the row, `old` = parked sums
+    // store one finished row: bottom and middle node of lanes 1..63 (lane 0 belongs to the chunk below), the last element of the
+    // pencil also its top node (the final node plane, z = 2 nz); `add9` = the lane's 9 values of the row, `old` = parked sums
     auto store_row = [&](int X, int ry, const double *add9, bool has_old, const double *old) {
+        const bool last = ez == d.nz - 1;
+        double w9[9];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) buf[6 * lane + q] = add9[q];
-        __builtin_amdgcn_wave_barrier();
-        double *rowp = const_cast<double *>(q2_row(out, d, X, 2 * eyc + ry));
-        double w6[6];                                         // all LDS reads first, then the stores
-#pragma unroll
-        for (int s6 = 0; s6 < 6; ++s6) w6[s6] = buf[lane + 64 * s6];
+        for (int q = 0; q < 9; ++q) w9[q] = add9[q];
         if (has_old) {
 #pragma unroll
-            for (int s6 = 0; s6 < 6; ++s6) w6[s6] += old[lane + 64 * s6];
-        }
-        __builtin_amdgcn_wave_barrier();
+            for (int q = 0; q < 6; ++q) w9[q] += old[6 * lane + q];
+            if (last) {
 #pragma unroll
-        for (int s6 = 0; s6 < 6; ++s6) {
-            const int q = lane + 64 * s6;
-            const long long qabs = seg + q;
-            if (q >= 6 && qabs < rowlen - 3) rowp[qabs] = w6[s6];   // lane 0 belongs to the chunk below; the final node plane is written apart
+                for (int c = 0; c < 3; ++c) w9[6 + c] += old[6 * lane + 6 + c];
+            }
         }
-        if (ez == d.nz - 1) {                                 // the last element of the pencil also owns the final node plane (z = 2 nz)
-            double *np = rowp + 3LL * 2 * d.nz;
+        const __amdgpu_buffer_rsrc_t r = row_rsrc(out, X, 2 * eyc + ry);
+        const unsigned so = (lane >= 1 && elem_ok) ? eoff : 0x7ffffff0u;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) np[c] = has_old ? old[6 * lane + 6 + c] + add9[6 + c] : add9[6 + c];
+        for (int q = 0; q < 3; ++q) {
+            const unsigned long long a = (unsigned long long) __double_as_longlong(w9[2 * q]), bq = (unsigned long long) __double_as_longlong(w9[2 * q + 1]);
+            const q2u4_t w = {(unsigned) a, (unsigned) (a >> 32), (unsigned) bq, (unsigned) (bq >> 32)};
+            __builtin_amdgcn_raw_buffer_store_b128(w, r, so + 16 * q, 0, 0);
+        }
+        if (last && lane >= 1) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned long long a = (unsigned long long) __double_as_longlong(w9[6 + c]);
+                const q2u2_t w = {(unsigned) a, (unsigned) (a >> 32)};
+                __builtin_amdgcn_raw_buffer_store_b64(w, r, eoff + 48 + 8 * c, 0, 0);
+            }
         }
     };
 
     const int e0 = xa > 0 ? xa - 1 : xa;
     if (active) {   // raw values of the first node plane
-        double first[3][7];
-        static_for<3>([&](auto rc) { constexpr int r = decltype(rc)::value; rows_to_regs(first[r], q2_row(u, d, 2 * e0, 2 * ey + r)); });
-        static_for<3>([&](auto rc) { constexpr int r = decltype(rc)::value; transpose_in(first[r], &keep[9 * r]); });
+        static_for<3>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            double t9[9];
+            load9(t9, row_rsrc(u, 2 * e0, 2 * ey + r));
+#pragma unroll
+            for (int q = 0; q < 9; ++q) keep[9 * r + q] = t9[q];
+        });
 #pragma unroll
         for (int t = 0; t < 27; ++t) carry[64 * t] = 0.0;
         issue_loads(e0);
@@ -498,7 +511,11 @@ __global__ void __launch_bounds__(256) k_apply_q2_march(DimsQ2 d, const double *
         if (active) {
 #pragma unroll
             for (int t = 0; t < 27; ++t) v[t] = keep[t];
-            static_for<6>([&](auto rc) { constexpr int r = decltype(rc)::value; transpose_in(pre[r], &v[27 + 9 * r]); });
+            static_for<6>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) v[27 + 9 * r + q] = pre[r][q];
+            });
             const double Ee = elem_ok ? Enext : 0.0;
             if (ex + 1 < xb) issue_loads(ex + 1);
 #pragma unroll
@@ -506,7 +523,7 @@ __global__ void __launch_bounds__(256) k_apply_q2_march(DimsQ2 d, const double *
             if (store && (rmw0 || rmw2)) {                    // sums of the first colour: requested now, parked in LDS after the arithmetic
                 static_for<2>([&](auto rc) {
                     constexpr int rx = decltype(rc)::value;
-                    rows_to_regs(pre_o[rx], q2_row(out, d, 2 * ex + rx, 2 * ey + (rmw0 ? 0 : 2)));
+                    load9(pre_o[rx], row_rsrc(out, 2 * ex + rx, 2 * ey + (rmw0 ? 0 : 2)));
                 });
             }
 
@@ -527,7 +544,11 @@ __global__ void __launch_bounds__(256) k_apply_q2_march(DimsQ2 d, const double *
                         constexpr int rx = decltype(rc)::value;
                         double *dst = obuf + (rmw0 ? 2 * par + rx : 4 + rx) * Q2M_OB;
 #pragma unroll
-                        for (int s7 = 0; s7 < 7; ++s7) dst[lane + 64 * s7] = pre_o[rx][s7];
+                        for (int q = 0; q < 6; ++q) dst[6 * lane + q] = pre_o[rx][q];
+                        if (ez == d.nz - 1) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) dst[6 * lane + 6 + c] = pre_o[rx][6 + c];
+                        }
                     });
                 }
                 if (hand_up) {
@@ -556,10 +577,15 @@ __global__ void __launch_bounds__(256) k_apply_q2_march(DimsQ2 d, const double *
 #pragma unroll
             for (int t = 0; t < 27; ++t) last[t] = carry[64 * t];
             if (rmw0 || rmw2) {
-                const double *rowp = q2_row(out, d, 2 * d.nx, 2 * ey + (rmw0 ? 0 : 2));
+                double t9[9];
+                load9(t9, row_rsrc(out, 2 * d.nx, 2 * ey + (rmw0 ? 0 : 2)));
                 double *dst = obuf + (rmw0 ? 2 * par : 4) * Q2M_OB;
 #pragma unroll
-                for (int s7 = 0; s7 < 7; ++s7) dst[lane + 64 * s7] = rowp[qa[s7]];
+                for (int q = 0; q < 6; ++q) dst[6 * lane + q] = t9[q];
+                if (ez == d.nz - 1) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) dst[6 * lane + 6 + c] = t9[6 + c];
+                }
             }
             if (hand_up) deposit_row(ldso[wy + 1] + (2 * par) * Q2M_OB, &last[18]);
         }
