@@ -328,7 +328,7 @@ def degree2_rate(ne=(512, 512, 512), reps=3):
     return {"grid": "%dx%dx%d" % tuple(ne), "nodes": t.numNodes(), "seconds": dt, "gvoxel_per_s": nvox / dt / 1e9,
             "algorithmic_GBs": ab / dt / 1e9, "frac_of_8TBs": ab / dt / 1e9 / HBM_PEAK_GBS,
             "algorithmic_bytes_per_voxel": ab / nvox,
-            "note": "marching kernel: reflection-mode blocks (855 of 6561 multiply-adds), x-march with in-block y hand-off, 2 colour launches; 527 B/voxel moved by the counters (profiles/r04_q2march512_pmc.json: re-measured on the current kernel, 2 x FETCH_SIZE + WRITE_SIZE)"}
+            "note": "marching kernel: reflection-mode blocks (855 of 6561 multiply-adds), x-march with in-block y hand-off, rows loaded and stored per lane by buffer accesses (no LDS transposes), 2 colour launches"}
 
 
 def degree2_pcg_rate(n=128, levels=5):
