@@ -158,6 +158,10 @@ __global__ void __launch_bounds__(512) k_mlp_forward_x3(MlpArgs a, MlpX3Weights 
     }
     __syncthreads();
 
+    // the younger half of the workgroup (waves 4-7) runs at priority 1 throughout: the two waves of a SIMD then do not contend
+    // symmetrically for the matrix pipe (+1.5 %; raising the priority around every MFMA cluster instead: -1 %).  The guard is a scalar
+    // compare: s_setprio ignores EXEC
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
     f16_t acch[2][2], accx[2][2];         // [row tile of this wave][voxel tile]: hi x hi products / cross products (scaled by 2^11)
     auto zero_acc = [&]() {
 #pragma unroll
