@@ -252,7 +252,7 @@ struct Shape {
     static constexpr int BN = BN_, BK = BK_, SV = SV_;       // output tile rows / columns, voxels per stage
     static constexpr int WN = BN / 128, WK = 8 / WN;           // waves along the rows / columns (a wave: 128 rows x 64 columns)
     static_assert(WN * WK == 8 && BK == 64 * WK, "eight waves of 4 x 2 tiles");
-    static_assert(SV % 16 == 0 && SV * BN / 8 == 1024 && (SV * BK / 8) % 512 == 0 || SV * BK / 8 == 256, "staging: two A pieces per thread");
+    static_assert(SV % 16 == 0 && SV * BN / 8 == 1024 && ((SV * BK / 8) % 512 == 0 || SV * BK / 8 == 256), "staging: two A pieces per thread");
     static constexpr int PA = BN * 2 + 64, PB = BK * 2 + 64;  // bytes per staged row: + 64 puts the four rows of a transposing read on distinct banks
     static constexpr int IA = SV * PA, IB = SV * PB;          // one image (one operand half, one stage)
     static constexpr int STAGE = 2 * IA + 2 * IB;             // A hi, A lo, B hi, B lo
