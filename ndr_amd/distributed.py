@@ -402,6 +402,18 @@ def bench_apply(ne, steps, warmup, with_cg=True):
 # planes are refreshed; dot products count interface planes once and finish with one all-reduce.
 # ==============================================================================================
 
+def auto_dist_levels(nx, world, num_levels, min_layers=8):
+    """Number of coarsenings that stay distributed (Ld; levels 0 .. Ld are slab-decomposed, the rest replicated): as many as leave a
+    rank at least `min_layers` owned element layers on the deepest of them and keep every slab boundary on an even plane of the next
+    level.  Below that a level is launch-floor-bound whether distributed or replicated (rank proxy,
+    profiles/r04_rank_proxy_levels512.jsonl: 20.6 / 20.1 / 20.0 ms per iteration with 4 / 5 / 6 distributed levels at 512^3 / 8) while
+    every further level adds ~60 messages per iteration (138 / 202 / 278)."""
+    ld = 0
+    while ld + 1 < num_levels and nx % (world * 2 ** (ld + 2)) == 0 and nx // (world * 2 ** (ld + 1)) >= min_layers:
+        ld += 1
+    return ld
+
+
 class _LevelGeom:
     def __init__(self, part, l, Ld, ne0):
         s = 2 ** l
@@ -450,14 +462,7 @@ class DistributedMGSolver:
         self.ne = tuple(int(v) for v in ne)
         self.L = int(num_levels)
         if dist_levels is None:
-            # as many distributed levels as leave a rank at least MIN_LAYERS element layers on the deepest of them: below that a level
-            # is launch-floor-bound whether distributed or replicated (rank proxy, profiles/r04_rank_proxy_levels512.jsonl: 20.6 / 20.1 /
-            # 20.0 ms per iteration with 4 / 5 / 6 distributed levels at 512^3 / 8) while every further level adds ~60 messages per
-            # iteration (138 / 202 / 278)
-            dist_levels = 0
-            while (dist_levels + 1 < self.L and self.ne[0] % (self.world * 2 ** (dist_levels + 2)) == 0
-                   and self.ne[0] // (self.world * 2 ** (dist_levels + 1)) >= self.MIN_LAYERS):
-                dist_levels += 1
+            dist_levels = auto_dist_levels(self.ne[0], self.world, self.L, self.MIN_LAYERS)
         self.Ld = int(dist_levels)
         if self.Ld + 1 > self.L:
             raise RuntimeError("need at least one replicated level below the distributed ones")

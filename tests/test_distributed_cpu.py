@@ -168,3 +168,18 @@ def test_four_plane_halo_of_the_degree2_slabs(world):
     for rank, ok, width_ok, cnt, total in res:
         assert ok and width_ok, rank
         assert cnt == total, (cnt, total)
+
+
+def test_automatic_number_of_distributed_levels():
+    """levels stay distributed while a rank keeps at least eight owned element layers on them and slab boundaries stay on even planes
+    of the next level (ndr_amd.distributed.auto_dist_levels; the rule the rank proxy measurements of round 4 led to)"""
+    from ndr_amd.distributed import auto_dist_levels
+    assert auto_dist_levels(512, 8, 6) == 3            # 64 layers per rank: 32, 16, 8 on levels 1 .. 3
+    assert auto_dist_levels(256, 8, 5) == 2
+    assert auto_dist_levels(256, 2, 5) == 4            # 128 layers per rank: limited by the number of levels
+    assert auto_dist_levels(32, 2, 3) == 1 and auto_dist_levels(48, 3, 3) == 1 and auto_dist_levels(64, 4, 4) == 1
+    assert auto_dist_levels(24, 3, 3) == 0             # eight layers per rank: nothing to coarsen in place
+    assert auto_dist_levels(512, 8, 6, min_layers=2) == 5            # (the rule of rounds 2-3: at least two layers)
+    for nx, world, L in ((512, 8, 6), (256, 4, 5), (96, 3, 4)):
+        ld = auto_dist_levels(nx, world, L)
+        assert ld + 1 <= L and nx % (world * 2 ** (ld + 1)) == 0
