@@ -177,7 +177,10 @@ class DistributedMGSolverQ2(DistributedMGSolver):
                                    # matrices on level 1, so the automatic choice stops at two coarsenings
 
     def __init__(self, ne, bbmin, bbmax, bc_path, material_path, num_levels, dist_levels=None, E0=1.0, Emin=1e-4,
-                 gamma=3.0, group=None):
+                 gamma=3.0, group=None, proxy=None):
+        """proxy = (world, rank): the slab of ONE rank of `world` built in a single process (tools/rank_proxy.py q2 ...): messages
+        become device copies of the same bytes, reductions stay local, the replicated level's mask is this rank's planes of it plus a
+        clamped face x = 0 (values are meaningless, work, launches and memory are the real rank's)."""
         from . import _lib
         from . import pyVoxelFEM as pv
         self._ct, self._lib_mod, self._pv = ctypes, _lib, pv
@@ -185,6 +188,9 @@ class DistributedMGSolverQ2(DistributedMGSolver):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.proxy = proxy is not None
+        if self.proxy:
+            self.world, self.rank = int(proxy[0]), int(proxy[1])
         self.ne = tuple(int(v) for v in ne)
         self.L = int(num_levels)
         if dist_levels is None:
@@ -217,7 +223,11 @@ class DistributedMGSolverQ2(DistributedMGSolver):
         gT = self.geom[self.T]
         lo_p, hi_p = gT.reduction_weight_planes()
         mine = np.ascontiguousarray(maskT.reshape(gT.n_planes, -1)[lo_p:hi_p])
-        if self.world > 1:
+        if self.proxy and self.world > 1:
+            whole = np.zeros((P * neT[0] + 1, mine.shape[1]), dtype=mine.dtype)
+            whole[gT.xoffn + lo_p:gT.xoffn + hi_p] = mine
+            whole[0] = 7
+        elif self.world > 1:
             parts = [None] * self.world
             dist.all_gather_object(parts, mine, group=group)
             whole = np.concatenate(parts, axis=0)
@@ -257,7 +267,7 @@ class DistributedMGSolverQ2(DistributedMGSolver):
         h2 = ctypes.c_void_p()
         _lib.check(self.lib.vfem_gmg_create_slab(ctypes.byref(h2), self.lsim._h, len(self.geom), arr, mptrs))
         self.lmg = h2
-        self.halos = [HaloExchanger(g, group) for g in self.geom]
+        self.halos = [HaloExchanger(g, group, self.proxy) for g in self.geom]
         z = lambda g: torch.zeros((g.n_planes * g.plane, 3), dtype=torch.float64, device=self.dev)
         self.x = [z(g) for g in self.geom]
         self.b = [z(g) for g in self.geom]

@@ -140,3 +140,26 @@ def test_q2_distributed_with_virtual_level1(world, ne, levels):
         assert it_d == it_s, (it_d, it_s)
         assert herr < 1.0 and abs(comp - cg) < 1e-9 * abs(cg), (herr, comp, cg)
         assert err < 1e-7 and gerr < 1e-7, (err, gerr)
+
+
+def test_rank_proxy_of_the_degree2_slab_solver_runs_a_rank_of_four():
+    """tools/rank_proxy.py q2: ONE interior rank of four built in a single process (messages = device copies of the same bytes,
+    reductions local).  Values are not the distributed solve's (the ghost planes are not the neighbours'); what is checked is that
+    the rank's slab, hierarchy and cycle are the real ones: geometry of rank 2 of 4, the requested iterations with finite residuals, message counts."""
+    sys.path.insert(0, ROOT)
+    from helpers import BC_CANTILEVER, MATERIAL
+    from ndr_amd.distributed_q2 import DistributedMGSolverQ2, G
+    ne = (64, 16, 16)
+    ds = DistributedMGSolverQ2(ne, [0.0, 0.0, 0.0], [2.0, 1.0, 1.0], BC_CANTILEVER, MATERIAL, 3, proxy=(4, 2))
+    assert (ds.world, ds.rank) == (4, 2) and ds.part.x1 - ds.part.x0 == 16
+    g0 = ds.geom[0]
+    assert g0.nx == 16 + 2 * G and g0.n_planes == 2 * g0.nx + 1
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    own = 0.2 + 0.8 * torch.rand(16 * 16 * 16, dtype=torch.float64, device="cuda", generator=gen)
+    ds.set_local_densities(own)
+    f = torch.randn((g0.n_planes * g0.plane, 3), dtype=torch.float64, device="cuda", generator=gen)
+    hist = []
+    ds.pcg(torch.zeros_like(f), f, 6, 0.0, 1, 2, True, callback=lambda it, r: hist.append(r))
+    assert ds.last_iterations == 6 and len(hist) >= 6
+    assert all(np.isfinite(h) for h in hist)
+    assert sum(getattr(hx, "messages", 0) for hx in ds.halos) > 0

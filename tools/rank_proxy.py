@@ -107,6 +107,50 @@ def _proxy(ne, levels, world, rank, iters, c_driver=None, dist_levels=None):
     return out
 
 
+def _proxy_q2(ne, levels, world, rank, iters):
+    """one rank of `world` of the DEGREE-2 slab solver (BASELINE config 5: 512^3 over 8 ranks does not fit one device as a whole,
+    a rank's slab does): seconds per PCG iteration, the operator update, peak device memory"""
+    from helpers import BC_CANTILEVER, MATERIAL
+    from ndr_amd import distributed_q2 as vq
+    torch.cuda.reset_peak_memory_stats()
+    t0 = time.perf_counter()
+    ds = vq.DistributedMGSolverQ2(ne, [0.0, 0.0, 0.0], [2.0, 1.0, 1.0], BC_CANTILEVER, MATERIAL, levels, proxy=(world, rank))
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    g = torch.Generator(device="cuda").manual_seed(88)
+    own = torch.rand((ds.part.x1 - ds.part.x0) * ne[1] * ne[2], dtype=torch.float64, device="cuda", generator=g)
+    ds.set_local_densities(own)
+    f = ds.local_loads()
+    f += 1e-3 * torch.randn(f.shape, dtype=torch.float64, device="cuda", generator=g)
+    def solve(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ds.pcg(torch.zeros_like(f), f, n, 0.0, 1, 2, True)         # (every call refreshes the operators first, as the reference's solve does)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    t_first = solve(1)                                              # allocations, operator update, one iteration
+    t_one = solve(1)
+    for hx in ds.halos:
+        hx.messages = 0
+    dt = solve(1 + iters)
+    msgs = sum(getattr(hx, "messages", 0) for hx in ds.halos)
+    per_it = (dt - t_one) / iters
+    done = ds.last_iterations
+    g0 = ds.geom[0]
+    out = {"degree": 2, "grid": "%dx%dx%d" % tuple(ne), "ranks": world, "rank": rank, "levels": levels, "distributed_levels": ds.Ld + 1,
+           "slab_elements": [g0.nx, ne[1], ne[2]], "slab_nodes": int(g0.n_planes * g0.plane),
+           "seconds_build": t_build, "seconds_first_call": t_first, "seconds_solve_of_1_iteration": t_one,
+           "seconds_solve_of_%d_iterations" % (1 + iters): dt, "iterations_done": done,
+           "seconds_per_iteration": per_it, "seconds_operator_update": t_one - per_it,
+           "messages_per_solve": msgs,
+           "peak_device_GB": torch.cuda.max_memory_allocated() / 1e9,
+           "relative_residual": ds.last_relative_residual}
+    del ds
+    torch.cuda.empty_cache()
+    return out
+
+
 def run(world=8, grids=(256, 512), iters=5):
     res = []
     for n in grids:
@@ -132,6 +176,12 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "levels":
             print(json.dumps({"grid": n, "ranks": w, "dist_levels_arg": ld, **r}), flush=True)
         except RuntimeError as e:
             print(json.dumps({"grid": n, "dist_levels_arg": ld, "error": str(e)}), flush=True)
+    sys.exit(0)
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "q2":
+    # python tools/rank_proxy.py q2 N grid [levels] [iterations]: one rank of N of the degree-2 slab solver
+    w, n = int(sys.argv[2]), int(sys.argv[3])
+    levels = int(sys.argv[4]) if len(sys.argv) > 4 else {64: 4, 128: 5, 256: 6, 512: 7}[n]
+    print(json.dumps(_proxy_q2((n, n, n), levels, w, w // 2, int(sys.argv[5]) if len(sys.argv) > 5 else 4), indent=1))
     sys.exit(0)
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "one":
     # python tools/rank_proxy.py one N grid [dist_levels]: a single proxy run (for rocprofv3)
