@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
     // =========================== DMA wave ===========================
     if (wave == CW) {
         unsigned ugo[U_INSTR];                        // (double offset of the lane's piece from the plane start) * 2 + row-start parity
+        unsigned dm0[U_INSTR], dm1[U_INSTR];          // byte offset of the piece from 32 bytes in front of the plane, for an even / odd plane start
 #pragma unroll
         for (int t = 0; t < U_INSTR; ++t) {
             const int Pc = 64 * t + lane;
@@ -150,15 +151,29 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
             int jj = yl + r; jj = jj < 0 ? 0 : (jj > d.NY - 1 ? d.NY - 1 : jj);
             const long long rs = 3LL * ((long long) jj * d.NZ + k0u);   // >= -3
             ugo[t] = (unsigned) ((rs + 3 + 2LL * c) * 2 + (rs & 1));    // offset biased by +3 doubles so that it is never negative
+            const unsigned dbl = ugo[t] >> 1, bit = ugo[t] & 1u;
+            dm0[t] = 8u * dbl + 8u - 8u * bit;                          // (the piece that holds the row start is the one at or below it)
+            dm1[t] = 8u * dbl + 8u * bit;
         }
         auto issueU = [&](int j) {
             const int i = plane_of(j);
             const bool rel = j & 1;
             const double *buf = rel ? A.uR : A.uO;
             const char *first = rel ? A.uR_first : A.uO_first, *last = rel ? A.uR_last : A.uO_last;
-            const int par0 = (rel ? bparR : bparO) + (i & ppar);
-            const double *pb = buf + 3LL * i * plane - 3;               // (the bias of ugo)
+            const int par0 = ((rel ? bparR : bparO) + (i & ppar)) & 1;
             unsigned char *slot = reinterpret_cast<unsigned char *>(sU + (j % NU) * U_SLOT_D);
+            if (i >= 1 && i <= d.NX - 2 && plane >= 256) {
+                // An inner plane (of more than a staged row's bytes): whatever its staging touches in front of it or behind it is still the field -- no clamping, the address
+                // is the plane's (uniform) base plus the lane's offset: 2 vector instructions per piece instead of ~14.  The DMA wave
+                // shares its SIMD with compute wave 0, which every barrier waits for: what this wave issues, that one cannot
+                // (6.15 -> 5.75 ms per sweep at 512^3, 1.04 -> 0.95 ms at 256^3; with the load's scalar-base form, no vector instruction
+                // at all, it is no faster: 5.84 / 0.95).
+                const char *pp = reinterpret_cast<const char *>(buf + 3LL * i * plane) - 32;
+#pragma unroll
+                for (int t = 0; t < U_INSTR; ++t) gsm_glds16(pp + (par0 ? dm1[t] : dm0[t]), slot + 1024 * t);
+                return;
+            }
+            const double *pb = buf + 3LL * i * plane - 3;               // (the bias of ugo)
 #pragma unroll
             for (int t = 0; t < U_INSTR; ++t) {
                 const char *g = reinterpret_cast<const char *>(pb + (long long) (ugo[t] >> 1) - (long long) ((par0 + (int) (ugo[t] & 1)) & 1));
