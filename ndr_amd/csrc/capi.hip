@@ -457,9 +457,6 @@ int vfem_debug_set(int key, int value) {
 }
 #endif
 
-/* diagnostic, not part of include/vfem.h: per-phase s_memtime stamps of one workgroup of the marching Gauss-Seidel kernel */
-int vfem_debug_gsm_stamps(long long *device_buffer) { vfem::g_gsm_stamps = device_buffer; return 0; }
-
 int vfem_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -68,7 +68,6 @@ struct GsMarchArgs {
     int forward;                   // component order of the 3x3 solve (MG.hh:254-264)
     int steps_per_chunk;           // relaxed planes per block
     int first_plane, num_planes;   // relaxed planes: first_plane + 2 mm, mm in [0, num_planes)  (first_plane has the parity cxl)
-    long long *stamps;             // diagnostic (normally null): s_memtime stamps of one block, [wave][step < 8][16]
 };
 
 typedef double d2a_t __attribute__((ext_vector_type(2), aligned(16)));
@@ -91,12 +90,6 @@ __device__ __forceinline__ void read10(const double *s, int idx_aligned, double 
         const d2a_t a = *reinterpret_cast<const d2a_t *>(s + idx_aligned + 2 * q);
         w[2 * q] = a[0]; w[2 * q + 1] = a[1];
     }
-}
-
-__device__ __forceinline__ long long gsm_now() {
-    long long t;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");      // 100 MHz wall clock (s_memtime does not advance at the shader clock here)
-    return t;
 }
 
 // The parity of a window's first double (the consumer's offset into its ten doubles, see read10) is
@@ -196,14 +189,6 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
     const int z0s = zb < 0 ? 0 : zb;                                    // owned columns inside the grid: [z0s, z1s]
     const int z1s = zb + 2 * C - 1 > d.NZ - 1 ? d.NZ - 1 : zb + 2 * C - 1;
     const int nd_store = 3 * (z1s - z0s + 1);
-    const bool stamping = A.stamps && blockIdx.x == 0 && blockIdx.y == 1 && blockIdx.z == 1;
-    auto stamp = [&](int m, int slot) {
-        if (stamping && m < 8) {
-            const long long t = gsm_now();
-            if (lane == 0) A.stamps[(wave * 8 + m) * 16 + slot] = t;
-        }
-    };
-
     // the eight moduli of the node this lane relaxes in colour k of plane xx: element layers xx - 1 and xx, rows y - 1, y, columns
     // z - 1, z.  Buffer loads: an element outside the grid gets an out-of-range offset, a layer outside the grid a zero-length
     // buffer, and both read 0 -- no clamping, no select, nothing staged.  Requested ONE COLOUR AHEAD of their use (mod[k & 1]).
@@ -237,9 +222,7 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
 
     for (int m = 0; m < nsteps; ++m) {
         const int x = x0 + 2 * m;
-        stamp(m, 0);
         __builtin_amdgcn_s_barrier();                                   // B0
-        stamp(m, 1);
         const int midoff = ((2 * m + 1) % NU) * U_SLOT_D;
         const int shM = bparR + (x & ppar);                             // + row parity = alignment shift of the staged rows
         const int shF = bparO + (plane_of(2 * m) & ppar);               // (planes x-1 and x+1 have the same parity)
@@ -384,23 +367,17 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
         // ordered inside the wave (its LDS accesses execute in order) and need no workgroup barrier
         phase(std::integral_constant<int, 0>{});
         __builtin_amdgcn_wave_barrier();
-        stamp(m, 2);
         phase(std::integral_constant<int, 1>{});
         __builtin_amdgcn_wave_barrier();
-        stamp(m, 3);
         store_rows2(1 + 4 * wave);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        stamp(m, 4);
         __builtin_amdgcn_s_barrier();                                   // B1: the rows of parity P are final
-        stamp(m, 5);
         phase(std::integral_constant<int, 2>{});
         __builtin_amdgcn_wave_barrier();
-        stamp(m, 6);
         phase(std::integral_constant<int, 3>{});
         __builtin_amdgcn_wave_barrier();
         store_rows2(2 + 4 * wave);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        stamp(m, 7);
     }
 }
 
@@ -430,8 +407,6 @@ void launch_gs_solve_data(const Dims &d, const double *K0, const double *E, cons
     k_gs_solve_data<<<dim3((unsigned) ((d.nn + 255) / 256)), 256, 0, s>>>(d, K0, E, mask, sd);
     VFEM_HIP(hipGetLastError());
 }
-
-long long *g_gsm_stamps = nullptr;       // diagnostic: device buffer of 7 x 8 x 8 stamps (vfem_debug_gsm_stamps), null in production
 
 // planes of local parity `par` copied from src to dst (the odd sweep left them in the scratch vector)
 __global__ void __launch_bounds__(256) k_copy_planes(Dims d, int first, int last, const double *__restrict__ src, double *__restrict__ dst) {
@@ -477,7 +452,6 @@ bool launch_gs_march_mf0(const Dims &d, const double *tab, const double *E, cons
     a.uO_first = first_piece(uO); a.uO_last = last_piece(uO + 3 * d.nn);
     a.dst = dst; a.b = b; a.sd = solve_data;
     a.cxl = cxl; a.forward = forward;
-    a.stamps = g_gsm_stamps;
     const int M = (plane_hi - first_plane) / 2 + 1;
     a.first_plane = first_plane; a.num_planes = M;
     const int P = forward ? 0 : 1;

@@ -128,7 +128,6 @@ bool launch_gs_march_mf0(const Dims &d, const double *neighbour_kind_table, cons
 // per node { 1/M00, 1/M11, 1/M22 (0 where the component is fixed), M10, M20, M21 } of the level-0 diagonal blocks M = sum_e E_e K0[n-block]
 void launch_gs_solve_data(const Dims &d, const double *K0, const double *E, const uint8_t *mask, double *sd, hipStream_t s);
 void launch_copy_planes(const Dims &d, int par, const double *src, double *dst, hipStream_t s, int plane_lo = 0, int plane_hi = -1);
-extern long long *g_gsm_stamps;         // diagnostic stamps of the marching kernel (tools/gs_march_stamps.py), null in production
 // level 1: diagonal 3x3 blocks of the virtual Galerkin operator, [nn][9] (once per operator update)
 void launch_mf1_diag(const Dims &d, const double *Dtab, const double *E, double *Mdiag, hipStream_t s);
 void build_gs_table(const double *K0, double *tab /* 72*12 doubles */);
