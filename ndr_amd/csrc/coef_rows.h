@@ -79,10 +79,10 @@ struct DevCoef {                      // the `Coef` of l1m::side_class / mid_cla
 struct L0NodeRows {
     static constexpr int at(int r) { return (r < 4 ? 7 - r : r < 8 ? row_kind<true>(r - 4) : 7 - (r - 8)) * l1m::TAB_ROW * 8; }
 };
-// adapter of one part onto the node's pipeline; tie: the accumulator the rows' arithmetic chains through; after_first: called right
-// behind the wait for the part's first row -- the place to issue LDS reads that must not be drained by a row wait (LDS and scalar
-// loads share one counter, and a scalar load can only be awaited with lgkmcnt(0): whatever LDS read is in flight at a row wait is
-// waited for as well)
+// adapter of one part onto the node's pipeline; tie: the accumulator the rows' arithmetic chains through; after_first(position): called
+// right behind the wait for each of the part's four rows -- the places to issue LDS reads: LDS and scalar loads share one counter, and a
+// scalar load can only be awaited with lgkmcnt(0), so whatever LDS read is in flight at a row wait is waited for as well; a batch issued
+// behind a row wait has that row's ~33 multiply-adds to land in
 template <bool MID, int BASE, class Hook>
 struct L0Coef {
     RowPipe<12, L0NodeRows> &pipe;
@@ -92,7 +92,7 @@ struct L0Coef {
     __device__ __forceinline__ void get(double c[9]) {
         static_assert(G == 0, "level 0 has one class");
         pipe.template take<BASE + row_pos<MID>(W)>(c, tie);
-        if constexpr (row_pos<MID>(W) == 0) after_first();
+        after_first(std::integral_constant<int, row_pos<MID>(W)>{});       // (called behind every row wait, with the row's position in the part)
     }
 };
 template <bool MID, int BASE, class Hook>

@@ -266,14 +266,22 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
             const int shc = (shF + row_par(ry)) & 1, shs = (shF + row_par(rlo)) & 1;
             const int mhc = (shM + row_par(ry)) & 1, mhs = (shM + row_par(rlo)) & 1;
             // the three rows of a plane as the 3 x 3 window of l1m::side_class / mid_class
-            auto window = [&](int slotoff, int sh_c, int sh_s, auto offc, auto offs, double (&un)[3][9]) {
-                constexpr int oc = decltype(offc)::value, os = decltype(offs)::value;
-                double w0[10], w1[10], w2[10];
-                read10(sU, slotoff + rlo * ROW_D + 3 * ni + sh_s - os, w0);
-                read10(sU, slotoff + ry * ROW_D + 3 * ni + sh_c - oc, w1);
-                read10(sU, slotoff + rhi * ROW_D + 3 * ni + sh_s - os, w2);
+            // one row (R: 0 below, 1 the node's own, 2 above) of a plane's 3 x 3 window
+            auto window_row = [&](auto rc, int slotoff, int sh_c, int sh_s, auto offc, auto offs, double (&un)[3][9]) {
+                constexpr int R_ = decltype(rc)::value, oc = decltype(offc)::value, os = decltype(offs)::value, o = R_ == 1 ? oc : os;
+                double w[10];
+                read10(sU, slotoff + (R_ == 0 ? rlo : R_ == 1 ? ry : rhi) * ROW_D + 3 * ni + (R_ == 1 ? sh_c : sh_s) - o, w);
 #pragma unroll
-                for (int c = 0; c < 9; ++c) { un[0][c] = w0[os + c]; un[1][c] = w1[oc + c]; un[2][c] = w2[os + c]; }
+                for (int c = 0; c < 9; ++c) un[R_][c] = w[o + c];
+            };
+            // the next plane's window, a row behind each of a part's first three row waits, in the order the next part needs them (side
+            // rows first): a batch of five reads lands within the ~33 multiply-adds of a row, all fifteen behind the first wait (rounds
+            // 3-4) do not
+            auto window_by_rows = [&](auto pc, int slotoff, int sh_c, int sh_s, auto offc, auto offs, double (&un)[3][9]) {
+                constexpr int p_ = decltype(pc)::value;
+                if constexpr (p_ == 0) window_row(std::integral_constant<int, 0>{}, slotoff, sh_c, sh_s, offc, offs, un);
+                if constexpr (p_ == 1) window_row(std::integral_constant<int, 2>{}, slotoff, sh_c, sh_s, offc, offs, un);
+                if constexpr (p_ == 2) window_row(std::integral_constant<int, 1>{}, slotoff, sh_c, sh_s, offc, offs, un);
             };
             // moduli of the eight incident elements (layer, y - 1 + dj, z - 1 + dk), requested a colour ago; zero outside the grid
             double a0[2][2], a1[2][2];
@@ -291,7 +299,7 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
             double S[3] = {0.0, 0.0, 0.0}, M6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, uself[3];
             double unA[3][9], unB[3][9];
             __builtin_amdgcn_sched_barrier(0);
-            window(lowoff, shc, shs, std::integral_constant<int, OFC>{}, std::integral_constant<int, OFS>{}, unA);
+            static_for<3>([&](auto rc) { window_row(rc, lowoff, shc, shs, std::integral_constant<int, OFC>{}, std::integral_constant<int, OFS>{}, unA); });
             RowPipe<12, L0NodeRows> rows{A.tab};
             asm volatile("" : "+v"(S[0]) : "v"(a0[0][0]));               // (the chain of row waits starts behind the moduli)
             rows.prime();
@@ -300,22 +308,22 @@ __global__ void __launch_bounds__(64 * (gsm::CW + 1)) k_gs_march_mf0(GsMarchArgs
             // lgkmcnt(0) and would drain them (requested in front of it, every part paid the full LDS latency: waves 44 % of their
             // time in s_waitcnt, profiles/r03_gs_march_form2_pmc.json)
             {
-                auto cf = l0_coef<false, 0>(rows, S[0], [&] {
-                    window(midoff, mhc, mhs, std::integral_constant<int, OMC>{}, std::integral_constant<int, OMS>{}, unB);
+                auto cf = l0_coef<false, 0>(rows, S[0], [&](auto pc) {
+                    window_by_rows(pc, midoff, mhc, mhs, std::integral_constant<int, OMC>{}, std::integral_constant<int, OMS>{}, unB);
                 });
                 l1m::side_class<0, 0>(a0, unA, cf, S);
             }
             __builtin_amdgcn_sched_barrier(0);
             {
                 uself[0] = unB[1][3]; uself[1] = unB[1][4]; uself[2] = unB[1][5];
-                auto cf = l0_coef<true, 4>(rows, S[0], [&] {
-                    window(highoff, shc, shs, std::integral_constant<int, OFC>{}, std::integral_constant<int, OFS>{}, unA);
+                auto cf = l0_coef<true, 4>(rows, S[0], [&](auto pc) {
+                    window_by_rows(pc, highoff, shc, shs, std::integral_constant<int, OFC>{}, std::integral_constant<int, OFS>{}, unA);
                 });
                 l1m::mid_class<0>(a0, a1, unB, cf, S, M6);
             }
             __builtin_amdgcn_sched_barrier(0);
             {
-                auto cf = l0_coef<false, 8>(rows, S[0], [] {});
+                auto cf = l0_coef<false, 8>(rows, S[0], [](auto) {});
                 l1m::side_class<1, 0>(a1, unA, cf, S);
             }
             __builtin_amdgcn_sched_barrier(0);
