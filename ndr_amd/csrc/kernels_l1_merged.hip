@@ -126,6 +126,16 @@ __device__ __forceinline__ void node_group(const Dims &d, const double *__restri
                                            bool live, int role, int lane, int forward, double (&part)[2][3][64], double (*sE)[16][64]) {
     double un[3][9];
     load_nodes(plane_rsrc(u, 3LL * d.NY * d.NZ, i + role - 1, d.NX), d, j, k, un);
+    // the wave of the node's own plane finishes the node: its right-hand side and mask are requested here, with the node values, not
+    // behind the second barrier where nothing of this workgroup is left to hide them
+    const long long n = ((long long) i * d.NY + j) * d.NZ + k;
+    double bn[3] = {0.0, 0.0, 0.0};
+    uint8_t mk8 = 0;
+    if (MODE != 1 && role == 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bn[c] = b[3 * n + c];
+        mk8 = mask ? mask[n] : 0;
+    }
     if (role != 1) {
         // byte offsets of the lane's 4 x 2 pieces (16 B: two moduli) in a fine x-plane; pieces outside the grid read as 0
         unsigned eoff[4][2];
@@ -175,7 +185,6 @@ __device__ __forceinline__ void node_group(const Dims &d, const double *__restri
 #pragma unroll
     for (int c = 0; c < 3; ++c) S[c] = (part[0][c][lane] + S[c]) + part[1][c][lane];
     const double uc[3] = {un[1][3], un[1][4], un[1][5]};
-    const long long n = ((long long) i * d.NY + j) * d.NZ + k;
     const double M[9] = {M6[0], M6[1], M6[2], M6[1], M6[3], M6[4], M6[2], M6[4], M6[5]};
     if (MODE == 1) {
 #pragma unroll
@@ -184,8 +193,7 @@ __device__ __forceinline__ void node_group(const Dims &d, const double *__restri
     }
     double bms[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) bms[c] = b[3 * n + c] - (S[c] + (M[3 * c] * uc[0] + M[3 * c + 1] * uc[1] + M[3 * c + 2] * uc[2]));
-    const uint8_t mk8 = mask ? mask[n] : 0;
+    for (int c = 0; c < 3; ++c) bms[c] = bn[c] - (S[c] + (M[3 * c] * uc[0] + M[3 * c + 1] * uc[1] + M[3 * c + 2] * uc[2]));
     if (MODE == 2) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) out[3 * n + c] = ((mk8 >> c) & 1) ? 0.0 : bms[c];
