@@ -379,3 +379,70 @@ def test_direct_solve_cache_follows_boundary_condition_changes():
     o.dmask[last, 0] = 1
     o._lu = None
     assert relerr(t.solve(f), o.solve(f)) < 1e-8
+
+
+def test_tuning_and_cross_check_options_agree():
+    """Every runtime option of `vfem_sim_set_option` that no other test touches selects between implementations of the same
+    arithmetic (apply: LDS-DMA / register-staged, planes in flight, x-chunks; level-0 sweeps: plain gather / row streaming with or
+    without fused z colours and resident coefficients / marching with different chunk counts; level 1: diagonal blocks precomputed or
+    not): each value must reproduce the default's result (no compiled path without a test)."""
+    import torch
+    from ndr_amd import _lib
+    lib = _lib.load()
+    ne, dom = (48, 40, 72), ([0, 0, 0], [2, 1, 1])
+    t = make_hip(ne, dom, BC_CANTILEVER, None, v0=0.5)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    t.setElementDensities(torch.rand(t.numElements(), dtype=torch.float64, device="cuda", generator=g))
+    mg = t.multigridSolver(3)
+    mg.updateElementStiffnessMatrices()
+    u = torch.randn((t.numNodes(), 3), dtype=torch.float64, device="cuda", generator=g)
+    x = {l: torch.randn((mg._nn(l), 3), dtype=torch.float64, device="cuda", generator=g) for l in (0, 1)}
+    b = {l: torch.randn((mg._nn(l), 3), dtype=torch.float64, device="cuda", generator=g) for l in (0, 1)}
+
+    def opt(key, value):
+        _lib.check(lib.vfem_sim_set_option(t._h, key, value))
+
+    def close(a, r, tol, what):
+        assert float((a - r).abs().max()) <= tol * float(r.abs().max()), what
+
+    # ---- apply: key 4 implementation, key 0 planes in flight of the register-staged one, key 7 x-chunks of the LDS-DMA one
+    ref = t.applyK_device(u).clone()
+    opt(4, 1)
+    for planes in (2, 3, 4):
+        opt(0, planes)
+        close(t.applyK_device(u), ref, 1e-13, ("register-staged apply", planes))
+    opt(4, 0)
+    for chunks in (1, 2, 5, 0):
+        opt(7, chunks)
+        close(t.applyK_device(u), ref, 1e-13, ("x-chunks of the apply", chunks))
+
+    # ---- level-0 sweeps: key 19 marching off / forced, key 20 its chunks, key 2 plain gather, key 10 fused z colours, key 13 resident K0
+    def sweeps0():
+        return [mg.smoothing_device(0, x[0], b[0], fwd).clone() for fwd in (True, False)]
+
+    opt(19, 0)
+    ref0 = sweeps0()
+    for key, values in ((10, (0, 1)), (13, (0, 1)), (2, (1, 0))):
+        for v in values:
+            opt(key, v)
+            for got, r in zip(sweeps0(), ref0):
+                close(got, r, 1e-12, ("level-0 sweep", key, v))
+    opt(19, 2)
+    for chunks in (1, 3, 0):
+        opt(20, chunks)
+        for got, r in zip(sweeps0(), ref0):
+            close(got, r, 1e-12, ("marching sweep chunks", chunks))
+    opt(19, 1)
+
+    # ---- level 1: key 12 precomputed diagonal blocks (per-element kernels, key 22 = 0)
+    opt(22, 0)
+    ref1 = None
+    for v in (0, 1, 0):
+        opt(12, v)
+        mg.updateElementStiffnessMatrices()
+        got = [mg.smoothing_device(1, x[1], b[1], fwd).clone() for fwd in (True, False)]
+        if ref1 is None:
+            ref1 = got
+        for a, r in zip(got, ref1):
+            close(a, r, 1e-12, ("level-1 diagonal blocks", v))
+    opt(22, 2)
